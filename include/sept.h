@@ -1,0 +1,75 @@
+/* sept.h -- C ABI of libsept_hip.so: the MI355X (gfx950) hot path of
+ * usc-sail/speech-emotion-privacy-trust (batched STFT->mel->dB features + the
+ * cloak / CNN+GRU / gradient-reversal training step).
+ *
+ * The reference is pure Python and has no FFI layer; each entry point below names the
+ * reference call it stands behind (file:line relative to the reference tree) -- these are
+ * the points where a maintainer would bind this library.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative sept_status otherwise;
+ *     sept_last_error() returns a thread-local human-readable message for the last failure.
+ *   - all tensor pointers are caller-owned DEVICE pointers (hipMalloc'd / torch storage),
+ *     dense, row-major in the stated shape; no function allocates caller-visible memory.
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued, never synchronised,
+ *     and no entry point calls hipMalloc/hipFree/hipMemcpy (graph-capture safe), except the
+ *     *_plan_create / *_plan_destroy pair which own small device tables.
+ *   - no torch types appear in any signature.
+ */
+#ifndef SEPT_H
+#define SEPT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum sept_status {
+  SEPT_OK = 0,
+  SEPT_ERR_INVALID = -1,     /* bad argument (null pointer, non-positive size, ...) */
+  SEPT_ERR_UNSUPPORTED = -2, /* shape / parameter outside what the kernels implement */
+  SEPT_ERR_HIP = -3,         /* a HIP runtime call failed (text in sept_last_error) */
+  SEPT_ERR_NO_DEVICE = -4    /* no gfx950 device visible */
+} sept_status;
+
+const char* sept_last_error(void);
+/* library ABI version; bumped when a signature changes */
+int sept_abi_version(void);
+/* 0 if a HIP device is visible and is gfx950, else SEPT_ERR_NO_DEVICE */
+int sept_device_check(void);
+
+/* ------------------------------------------------------------------------------------
+ * Features: framed STFT (reflect-pad centred, periodic Hann, hop) -> |.|^2 -> mel
+ * filterbank -> 10 log10(clamp(., 1e-10)).
+ * Replaces: feature_extraction/audio_feature_extraction.py:29-46 mel_spectrogram()
+ *   = torchaudio MelSpectrogram(16000, n_mels, n_fft, win_length=n_fft, hop_length=160,
+ *     window_fn=hann_window) + AmplitudeToDB()  (torch.stft + MelScale matmul + log10).
+ * The plan owns the device tables the reference rebuilds on every call
+ * (audio_feature_extraction.py:36-43): window, FFT twiddles, sparse filterbank.
+ * ------------------------------------------------------------------------------------ */
+typedef struct sept_mel_plan sept_mel_plan;
+
+#define SEPT_MEL_LAYOUT_BFT 0 /* out[B][n_mels][T]  -- the reference's (C, n_mels, T)   */
+#define SEPT_MEL_LAYOUT_BTF 1 /* out[B][T][n_mels]  -- window-major, what training eats  */
+
+/* window_host[n_fft], fb_host[n_freq = n_fft/2+1][n_mels] are HOST float32 tables (the
+ * host side builds them exactly as torchaudio does).  Supported n_fft: 400, 800, 1024,
+ * 1600 (every size the reference uses); hop must be even; each filter's non-zeros must
+ * be one contiguous run of bins (true for any triangular bank). */
+int sept_mel_plan_create(int n_fft, int hop, int n_mels, const float* window_host,
+                         const float* fb_host, sept_mel_plan** plan_out);
+int sept_mel_plan_destroy(sept_mel_plan* plan);
+/* frames produced for a clip of `length` samples: 1 + length / hop */
+int sept_mel_num_frames(const sept_mel_plan* plan, int length);
+/* wav[B][L] float32 -> out (layout above) float32 dB.  Requires L > n_fft/2. */
+int sept_mel_forward(const sept_mel_plan* plan, const float* wav, int B, int L, float* out,
+                     int layout, void* stream);
+/* name of the device kernel sept_mel_forward launches for this plan (for rocprof filters) */
+const char* sept_mel_kernel_name(const sept_mel_plan* plan);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEPT_H */

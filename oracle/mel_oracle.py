@@ -1,0 +1,106 @@
+"""CPU oracle for the speech-feature half of the hot path (TEST INFRASTRUCTURE ONLY).
+
+PARITY UNPINNED at the torchaudio boundary: the reference computes its features with
+``torchaudio.transforms.MelSpectrogram`` + ``AmplitudeToDB``
+(reference ``feature_extraction/audio_feature_extraction.py:29-46``).  torchaudio is an
+un-vendored, un-pinned third-party dependency (no requirements file in the reference;
+the code dates to torchaudio ~0.9-0.11) and it is not installed here, and the reference
+ships no tests or golden vectors.  This file therefore *restates* torchaudio's published
+algorithm for exactly the argument set the reference call site uses, and is pinned by
+analytic known-answer vectors (tests/test_oracle_mel.py) and by an independent float64
+numpy implementation -- not by outputs of the reference itself.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py``
+may import this module.  The product path (``speech-emotion-privacy-trust_amd``) never does.
+
+Semantics restated (reference call site -> torchaudio defaults):
+  MelSpectrogram(sample_rate=16000, n_mels=F, n_fft=N, win_length=N, hop_length=160,
+                 window_fn=torch.hann_window)          audio_feature_extraction.py:36-43
+    f_min=0, f_max=None -> 8000, pad=0, power=2.0, normalized=False, center=True,
+    pad_mode="reflect", onesided=True, norm=None, mel_scale="htk"
+  AmplitudeToDB()  stype="power", top_db=None           audio_feature_extraction.py:45-46
+    -> 10*log10(clamp(x, min=1e-10)) - 10*log10(max(1e-10, 1.0)) = 10*log10(clamp(x,1e-10))
+"""
+import math
+
+import numpy as np
+import torch
+
+SAMPLE_RATE = 16000
+HOP = 160
+AMIN = 1e-10
+
+
+def hz_to_mel_htk(freq: float) -> float:
+    # torchaudio.functional._hz_to_mel, mel_scale="htk" (python float math)
+    return 2595.0 * math.log10(1.0 + (freq / 700.0))
+
+
+def melscale_fbanks_htk(n_freqs: int, n_mels: int, sample_rate: int = SAMPLE_RATE,
+                        f_min: float = 0.0, f_max=None) -> torch.Tensor:
+    """torchaudio.functional.melscale_fbanks(norm=None, mel_scale='htk') restated in the
+    same float32 torch-op order, so the table carries the same rounding the reference's
+    MelScale buffer would.  Returns (n_freqs, n_mels) float32."""
+    if f_max is None:
+        f_max = float(sample_rate // 2)
+    all_freqs = torch.linspace(0, sample_rate // 2, n_freqs)
+    m_min = hz_to_mel_htk(f_min)
+    m_max = hz_to_mel_htk(f_max)
+    m_pts = torch.linspace(m_min, m_max, n_mels + 2)
+    f_pts = 700.0 * (10.0 ** (m_pts / 2595.0) - 1.0)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+    zero = torch.zeros(1)
+    down_slopes = (-1.0 * slopes[:, :-2]) / f_diff[:-1]
+    up_slopes = slopes[:, 2:] / f_diff[1:]
+    fb = torch.max(zero, torch.min(down_slopes, up_slopes))
+    return fb
+
+
+def n_frames(length: int, hop: int = HOP) -> int:
+    return 1 + length // hop
+
+
+def mel_spectrogram_torch(audio: torch.Tensor, n_fft: int = 1024, feature_len: int = 128,
+                          hop: int = HOP, fb: torch.Tensor = None) -> torch.Tensor:
+    """fp32 oracle: the exact op chain torchaudio delegates to (torch.stft -> |.|^2 ->
+    matmul with fb -> 10 log10 clamp).  audio (C, L) float32 -> (C, F, 1 + L//hop)."""
+    audio = audio.detach().to(torch.float32).cpu()
+    window = torch.hann_window(n_fft)  # periodic=True (torch default)
+    spec = torch.stft(audio, n_fft, hop_length=hop, win_length=n_fft, window=window,
+                      center=True, pad_mode="reflect", normalized=False, onesided=True,
+                      return_complex=True)
+    power = spec.abs().pow(2.0)  # (C, n_freq, T)
+    if fb is None:
+        fb = melscale_fbanks_htk(n_fft // 2 + 1, feature_len)
+    mel = torch.matmul(power.transpose(-1, -2), fb).transpose(-1, -2)
+    return 10.0 * torch.log10(torch.clamp(mel, min=AMIN))
+
+
+def mel_power_f64(audio: np.ndarray, n_fft: int, feature_len: int, hop: int = HOP,
+                  fb: np.ndarray = None) -> np.ndarray:
+    """Independent float64 adjudicator: manual reflect pad + framing + numpy rfft.
+    audio (C, L) -> mel POWER (C, F, T) float64 (no dB).  The filterbank is the float32
+    table of ``melscale_fbanks_htk`` promoted to float64 (the table is part of the
+    reference semantics; the arithmetic after it is what is adjudicated)."""
+    x = np.asarray(audio, dtype=np.float64)
+    C, L = x.shape
+    pad = n_fft // 2
+    xp = np.pad(x, ((0, 0), (pad, pad)), mode="reflect")
+    T = 1 + L // hop
+    n = np.arange(n_fft)
+    window = 0.5 - 0.5 * np.cos(2.0 * np.pi * n / n_fft)  # periodic Hann
+    idx = hop * np.arange(T)[:, None] + n[None, :]
+    frames = xp[:, idx] * window  # (C, T, n_fft)
+    spec = np.fft.rfft(frames, axis=-1)
+    power = spec.real ** 2 + spec.imag ** 2  # (C, T, n_freq)
+    if fb is None:
+        fb = melscale_fbanks_htk(n_fft // 2 + 1, feature_len).numpy()
+    mel = power @ np.asarray(fb, dtype=np.float64)  # (C, T, F)
+    return np.transpose(mel, (0, 2, 1))
+
+
+def mel_spectrogram_f64(audio: np.ndarray, n_fft: int, feature_len: int, hop: int = HOP,
+                        fb: np.ndarray = None) -> np.ndarray:
+    mel = mel_power_f64(audio, n_fft, feature_len, hop, fb)
+    return 10.0 * np.log10(np.maximum(mel, AMIN))

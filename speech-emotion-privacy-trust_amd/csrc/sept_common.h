@@ -1,0 +1,51 @@
+// Shared host-side helpers for libsept_hip.so (error text, HIP call checking).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "sept.h"
+
+namespace sept {
+
+char* err_buf();  // thread-local, 512 bytes
+
+inline int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(err_buf(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define SEPT_HIP(expr)                                                                    \
+  do {                                                                                    \
+    hipError_t e__ = (expr);                                                              \
+    if (e__ != hipSuccess)                                                                \
+      return ::sept::fail(SEPT_ERR_HIP, "%s failed: %s (%s:%d)", #expr,                   \
+                          hipGetErrorString(e__), __FILE__, __LINE__);                    \
+  } while (0)
+
+#define SEPT_REQUIRE(cond, code, ...)                                                     \
+  do {                                                                                    \
+    if (!(cond)) return ::sept::fail(code, __VA_ARGS__);                                  \
+  } while (0)
+
+inline int launch_check(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(SEPT_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+  return SEPT_OK;
+}
+
+// wave-local LDS hand-off: the lanes of one wavefront execute in lockstep and a wave's LDS
+// operations retire in order, so data written by one lane is visible to a later read by
+// another lane of the SAME wave without a workgroup barrier; the fences only stop the
+// compiler from moving LDS accesses across this point.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+}  // namespace sept

@@ -1,0 +1,29 @@
+// libsept_hip.so: error text, ABI version, device check.
+#include "sept_common.h"
+
+#include <cstring>
+
+namespace sept {
+char* err_buf() {
+  static thread_local char buf[512] = {0};
+  return buf;
+}
+}  // namespace sept
+
+extern "C" const char* sept_last_error(void) { return sept::err_buf(); }
+
+extern "C" int sept_abi_version(void) { return 1; }
+
+extern "C" int sept_device_check(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return sept::fail(SEPT_ERR_NO_DEVICE, "sept_device_check: no HIP device visible");
+  int dev = 0;
+  hipDeviceProp_t prop;
+  SEPT_HIP(hipGetDevice(&dev));
+  SEPT_HIP(hipGetDeviceProperties(&prop, dev));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return sept::fail(SEPT_ERR_NO_DEVICE, "sept_device_check: device %d is %s, this library is built for gfx950",
+                      dev, prop.gcnArchName);
+  return SEPT_OK;
+}

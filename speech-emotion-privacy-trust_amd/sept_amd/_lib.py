@@ -1,0 +1,65 @@
+"""ctypes binding of libsept_hip.so (C ABI in include/sept.h).  Fails loudly when the
+library has not been built: the product path never falls back to CPU/eager code."""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "..", "csrc", "libsept_hip.so")
+
+
+class SeptError(RuntimeError):
+    """A libsept_hip entry point returned a negative status."""
+
+
+def _load():
+    path = os.path.abspath(LIB_PATH)
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C speech-emotion-privacy-trust_amd/csrc` (there is no CPU fallback)")
+    return ctypes.CDLL(path)
+
+
+lib = _load()
+
+# name -> (restype, argtypes); kept in one table so tests can check it against sept.h
+SIGNATURES = {
+    "sept_last_error": (c_char_p, []),
+    "sept_abi_version": (c_int, []),
+    "sept_device_check": (c_int, []),
+    "sept_mel_plan_create": (c_int, [c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), POINTER(c_void_p)]),
+    "sept_mel_plan_destroy": (c_int, [c_void_p]),
+    "sept_mel_num_frames": (c_int, [c_void_p, c_int]),
+    "sept_mel_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "sept_mel_kernel_name": (c_char_p, [c_void_p]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def check(status: int, what: str = "") -> int:
+    if status < 0:
+        msg = lib.sept_last_error()
+        raise SeptError(f"{what or 'libsept_hip'} failed with status {status}: "
+                        f"{msg.decode() if msg else '?'}")
+    return status
+
+
+def require_cuda(*tensors):
+    """Every op runs on the GPU through the HIP library; anything else is an error."""
+    import torch
+    for t in tensors:
+        if not isinstance(t, torch.Tensor):
+            raise TypeError(f"expected a torch.Tensor, got {type(t)}")
+        if not t.is_cuda:
+            raise SeptError("libsept_hip ops need CUDA(HIP) tensors: there is no CPU fallback "
+                            f"(got a tensor on {t.device})")
+
+
+def current_stream_ptr(device=None) -> int:
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream

@@ -1,0 +1,53 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads without a GPU and exports
+exactly the entry points include/sept.h declares; argument errors come back as status
+codes with text, never as crashes.  No compute is launched here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+HEADER = os.path.join(ROOT, "include", "sept.h")
+
+
+def _declared():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sept_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported():
+    from sept_amd import _lib
+    names = _declared()
+    assert len(names) >= 8
+    for n in names:
+        assert hasattr(_lib.lib, n), f"{n} declared in sept.h but not exported"
+    # and every symbol the Python host binds is declared in the header
+    for n in _lib.SIGNATURES:
+        assert n in names, f"{n} bound by the host but missing from sept.h"
+
+
+def test_abi_version_and_error_text():
+    from sept_amd import _lib
+    assert _lib.lib.sept_abi_version() >= 1
+    h = ctypes.c_void_p()
+    st = _lib.lib.sept_mel_plan_create(777, 160, 80, None, None, ctypes.byref(h))
+    assert st == -1 and b"null" in _lib.lib.sept_last_error()
+    buf = (ctypes.c_float * 4)()
+    st = _lib.lib.sept_mel_plan_create(777, 160, 80, buf, buf, ctypes.byref(h))
+    assert st == -2 and b"n_fft=777" in _lib.lib.sept_last_error()
+    with pytest.raises(_lib.SeptError):
+        _lib.check(st, "sept_mel_plan_create")
+
+
+def test_no_cpu_fallback():
+    """CPU tensors must be refused loudly (no silent eager path)."""
+    import torch
+    from sept_amd import _lib
+    with pytest.raises(_lib.SeptError):
+        _lib.require_cuda(torch.zeros(3))
+    if not torch.cuda.is_available():
+        from feature_extraction.audio_feature_extraction import mel_spectrogram
+        with pytest.raises(RuntimeError):
+            mel_spectrogram(torch.zeros(1, 16000), n_fft=800, feature_len=80)

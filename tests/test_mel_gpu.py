@@ -1,0 +1,129 @@
+"""GPU parity tests of the fused STFT->mel->dB HIP kernel (through the C ABI) against the
+feature oracle.  Tolerance (north-star): mel features within 1e-4 relative -- checked on
+mel POWER against the float64 oracle (dB is ill-conditioned only through the power), plus
+an absolute bound on dB.  Reference semantics: audio_feature_extraction.py:29-46."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mel_oracle as mo
+
+pytestmark = pytest.mark.gpu
+
+REL_POWER = 1e-4
+ABS_DB = 1e-3
+CASES = [(800, 80), (800, 128), (1600, 80), (1600, 128), (1024, 80), (1024, 128), (400, 128)]
+
+
+def _hip(x, n_fft, F, layout=0):
+    from sept_amd.mel import get_mel_plan
+    return get_mel_plan(n_fft, F).forward(x.cuda(), layout).cpu()
+
+
+def _check(x, n_fft, F):
+    got = _hip(x, n_fft, F).numpy().astype(np.float64)
+    want = mo.mel_spectrogram_f64(x.numpy(), n_fft, F)
+    assert got.shape == want.shape
+    pg, pw = 10 ** (got / 10), 10 ** (want / 10)
+    rel = np.abs(pg - pw) / np.maximum(pw, 1e-10)
+    assert rel.max() < REL_POWER, f"rel power err {rel.max():.3e} at {np.unravel_index(rel.argmax(), rel.shape)}"
+    assert np.abs(got - want).max() < ABS_DB
+    return got
+
+
+@pytest.mark.parametrize("n_fft,F", CASES)
+def test_seeded_noise_vs_oracle(n_fft, F):
+    torch.manual_seed(8)
+    x = torch.randn(4, 80000) * 0.1
+    _check(x, n_fft, F)
+
+
+@pytest.mark.parametrize("n_fft,F", [(800, 80), (800, 128), (1600, 80), (1024, 128)])
+def test_golden_slices(n_fft, F, golden_dir):
+    g = np.load(os.path.join(golden_dir, "mel_golden.npz"))
+    torch.manual_seed(8)
+    x = torch.randn(4, 80000) * 0.1
+    got = _hip(x, n_fft, F).numpy()
+    frames = list(g["frames"])
+    np.testing.assert_allclose(got[:, :, frames], g[f"n{n_fft}_f{F}_slices"], rtol=1e-4, atol=1e-3)
+    assert got.astype(np.float64).sum() == pytest.approx(float(g[f"n{n_fft}_f{F}_sum"]), rel=1e-5)
+
+
+@pytest.mark.parametrize("n_fft,F", [(800, 80), (1600, 128), (1024, 80)])
+def test_known_answers(n_fft, F):
+    # zeros -> clamp floor -> exactly -100 dB everywhere
+    assert torch.all(_hip(torch.zeros(2, 8000), n_fft, F) == -100.0)
+    # sinusoid at a bin centre and a constant, vs the f64 oracle
+    n = torch.arange(16000, dtype=torch.float64)
+    x = torch.stack([torch.cos(2 * np.pi * 37 * n / n_fft), torch.ones_like(n)]).float()
+    _check(x, n_fft, F)
+    # impulse at a frame centre: flat unit spectrum -> mel power = filterbank column sums
+    x = torch.zeros(1, 16000)
+    x[0, 160 * 40] = 1.0
+    got = _hip(x, n_fft, F)[0, :, 40].numpy()
+    fb = mo.melscale_fbanks_htk(n_fft // 2 + 1, F).numpy()
+    np.testing.assert_allclose(10 ** (got / 10), fb.sum(0), rtol=1e-4)
+
+
+@pytest.mark.parametrize("L", [401, 480, 799, 1599, 1600, 8000, 80000, 80159])
+def test_ragged_lengths_and_edges(L):
+    """Clip lengths around the reflect-pad minimum, non-multiples of the hop and of the
+    tile; T = 1 + L//160 as in the reference."""
+    torch.manual_seed(L)
+    x = torch.randn(3, L) * 0.1
+    got = _check(x, 800, 80)
+    assert got.shape == (3, 80, 1 + L // 160)
+
+
+def test_errors_and_empty():
+    from sept_amd._lib import SeptError
+    from sept_amd.mel import get_mel_plan
+    plan = get_mel_plan(800, 80)
+    with pytest.raises(SeptError):            # reflect pad needs L > n_fft/2 (torch.stft raises too)
+        plan.forward(torch.zeros(1, 400).cuda())
+    with pytest.raises(SeptError):            # CPU tensors are refused: no fallback
+        plan.forward(torch.zeros(1, 4000))
+    assert plan.forward(torch.zeros(0, 4000).cuda()).shape == (0, 80, 26)
+    with pytest.raises(SeptError):
+        get_mel_plan(1000, 80)
+
+
+@pytest.mark.parametrize("n_fft,F", [(800, 80), (800, 128)])
+def test_time_major_layout(n_fft, F):
+    torch.manual_seed(3)
+    x = torch.randn(5, 24000) * 0.1
+    a = _hip(x, n_fft, F, layout=0)
+    b = _hip(x, n_fft, F, layout=1)
+    assert b.shape == (5, 151, F)
+    assert torch.equal(a.transpose(1, 2).contiguous(), b)
+
+
+def test_drop_in_signature():
+    """Reference call shape: (1, L) CPU tensor in, (1, F, T) CPU tensor out."""
+    from feature_extraction.audio_feature_extraction import mel_spectrogram
+    torch.manual_seed(1)
+    audio = torch.randn(1, 80000) * 0.1
+    out = mel_spectrogram(audio, n_fft=800, feature_len=128)
+    assert out.shape == (1, 128, 501) and out.dtype == torch.float32 and not out.is_cuda
+    want = mo.mel_spectrogram_torch(audio, 800, 128)
+    np.testing.assert_allclose(out.numpy(), want.numpy(), rtol=1e-4, atol=1e-3)
+    assert mel_spectrogram(audio).shape == (1, 128, 501)      # defaults n_fft=1024, 128 mels
+
+
+def test_full_batch_properties():
+    """BASELINE config 2 size (256 clips x 5 s): size-independent properties instead of a
+    full oracle run -- batch rows are independent (a clip's features do not depend on its
+    batch position), scaling the waveform by 2 adds 10 log10(4) dB, and a sample of clips
+    matches the oracle."""
+    g = torch.Generator().manual_seed(8)
+    x = (torch.randn(256, 80000, generator=g) * 0.1).clamp(-1, 1)
+    full = _hip(x, 800, 80)
+    assert full.shape == (256, 80, 501) and torch.isfinite(full).all()
+    idx = [0, 17, 255]
+    assert torch.equal(_hip(x[idx], 800, 80), full[idx])
+    doubled = _hip(2 * x[:8], 800, 80)
+    assert torch.allclose(doubled, full[:8] + 10 * np.log10(4.0), atol=2e-4)
+    want = mo.mel_spectrogram_f64(x[idx].numpy(), 800, 80)
+    assert np.abs(full[idx].numpy() - want).max() < ABS_DB
