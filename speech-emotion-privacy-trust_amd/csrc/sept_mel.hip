@@ -61,6 +61,12 @@ struct MelCfg {
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~size_t(15); }
 
+// AmplitudeToDB: 10 log10(clamp(x, 1e-10)).  The clamp floor is emitted as exactly -100 dB,
+// which is what a correctly rounded log10f(1e-10f) gives (and what torch returns).
+__device__ __forceinline__ float power_to_db(float x) {
+  return x > 1e-10f ? 10.0f * log10f(x) : -100.0f;
+}
+
 template <int N1, int N2, int TPF>
 struct MelSmem {
   using C = MelCfg<N1, N2, TPF>;
@@ -257,13 +263,13 @@ __global__ __launch_bounds__(kWaves * 64) void sept_mel_stft_kernel(MelArgs a) {
     float* o = a.out + size_t(b) * F * T;
     for (int idx = tid; idx < F * a.tile; idx += nthr) {
       const int m = idx / a.tile, fl = idx - m * a.tile;
-      if (fl < nfr) o[size_t(m) * T + t0 + fl] = 10.0f * log10f(fmaxf(tile[fl * (F + 1) + m], 1e-10f));
+      if (fl < nfr) o[size_t(m) * T + t0 + fl] = power_to_db(tile[fl * (F + 1) + m]);
     }
   } else {
     float* o = a.out + (size_t(b) * T + t0) * F;
     for (int idx = tid; idx < F * nfr; idx += nthr) {
       const int fl = idx / F, m = idx - fl * F;
-      o[idx] = 10.0f * log10f(fmaxf(tile[fl * (F + 1) + m], 1e-10f));
+      o[idx] = power_to_db(tile[fl * (F + 1) + m]);
     }
   }
 }
@@ -451,8 +457,9 @@ extern "C" const char* sept_mel_kernel_name(const sept_mel_plan* plan) {
 
 extern "C" int sept_mel_forward(const sept_mel_plan* plan, const float* wav, int B, int L, float* out,
                                 int layout, void* stream) {
-  SEPT_REQUIRE(plan && wav && out, SEPT_ERR_INVALID, "sept_mel_forward: null argument");
+  SEPT_REQUIRE(plan, SEPT_ERR_INVALID, "sept_mel_forward: null plan");
   SEPT_REQUIRE(B >= 0 && L > 0, SEPT_ERR_INVALID, "sept_mel_forward: B=%d L=%d", B, L);
+  SEPT_REQUIRE(B == 0 || (wav && out), SEPT_ERR_INVALID, "sept_mel_forward: null argument");
   SEPT_REQUIRE(layout == SEPT_MEL_LAYOUT_BFT || layout == SEPT_MEL_LAYOUT_BTF, SEPT_ERR_INVALID,
                "sept_mel_forward: layout=%d", layout);
   // torch.stft(center=True, pad_mode='reflect') needs pad = n_fft/2 < L
