@@ -1,0 +1,282 @@
+"""CPU oracle for the model half of the hot path (TEST INFRASTRUCTURE ONLY).
+
+A plain-torch (fp32, autograd) restatement of the reference modules that sit on the path:
+    GradientReversalFunction / GradientReversal      model/reversal_gradient.py:5-32
+    cloak_noise                                      model/cloak_models.py:24-58
+    two_d_cnn_lstm (+ deep_two_d_cnn_lstm, one_d_cnn_lstm)   model/baseline_models.py:19-385
+    two_d_cnn_lstm_syn / two_d_cnn_lstm_syn_with_grl model/cloak_models.py:61-226
+    the per-step loss of train()                     training/training_cloak_with_grl.py:138-160
+with the reference's constructor signatures, attribute names and state-dict keys, so a
+state dict moves between the reference modules, this oracle and the HIP-backed product
+modules unchanged.
+
+Pinned by tests/golden/model_golden.npz, produced by tools/make_goldens_model.py which
+imports the REFERENCE modules from /root/reference/model in the build container, loads
+closed-form weights into them and records their outputs/gradients; tests/test_oracle_model.py
+checks this restatement against those vectors.
+
+Differences from the reference that are deliberate and test-only:
+  * dropout masks and the cloak epsilon can be injected (``eps=``, ``drop=``) so that train
+    mode is reproducible across implementations; with nothing injected the modules behave
+    like the reference (torch RNG).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this file.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+# ----------------------------------------------------------------------------------------
+# gradient reversal (reversal_gradient.py:5-32)
+# ----------------------------------------------------------------------------------------
+class GradientReversalFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, lambda_):
+        ctx.lambda_ = lambda_
+        return x.clone()
+
+    @staticmethod
+    def backward(ctx, grads):
+        return -ctx.lambda_ * grads, None
+
+
+class GradientReversal(nn.Module):
+    def __init__(self, lambda_=1):
+        super().__init__()
+        self.lambda_ = lambda_
+
+    def forward(self, x):
+        return GradientReversalFunction.apply(x, self.lambda_)
+
+
+# ----------------------------------------------------------------------------------------
+# cloak noise (cloak_models.py:24-58)
+# ----------------------------------------------------------------------------------------
+class cloak_noise(nn.Module):
+    def __init__(self, given_locs, given_scales, min_scale, max_scale, device):
+        super().__init__()
+        size = given_scales.shape
+        self.min_scale, self.max_scale = min_scale, max_scale
+        self.given_locs, self.given_scales = given_locs, given_scales
+        self.locs = nn.Parameter(torch.Tensor(size).copy_(given_locs))
+        self.rhos = nn.Parameter(torch.ones(size) - 3)
+        self.device = device
+        self.normal = torch.distributions.normal.Normal(0, 0.1)
+        self.eps = None  # test hook: injected epsilon
+
+    def scales(self):
+        return (1.0 + torch.tanh(self.rhos)) / 2 * (self.max_scale - self.min_scale) + self.min_scale
+
+    def sample_noise(self, mask=None):
+        eps = self.eps if self.eps is not None else self.normal.sample(self.rhos.shape).to(self.device)
+        if mask is not None:
+            eps = eps * mask
+        return self.locs + self.scales() * eps
+
+    def forward(self, input, mask=None):
+        noise = self.sample_noise(mask)
+        return input + noise if mask is None else input * mask + noise
+
+
+# ----------------------------------------------------------------------------------------
+# baseline classifiers (baseline_models.py)
+# ----------------------------------------------------------------------------------------
+def _rnn_cell(name):
+    if name.lower() == "lstm":
+        return nn.LSTM
+    if name.lower() == "gru":
+        return nn.GRU
+    raise ValueError("Unsupported RNN Cell: {0}".format(name))
+
+
+def _conv_block(cin, cout, p, pool=True):
+    layers = [nn.Conv2d(cin, cout, kernel_size=5, padding=2), nn.BatchNorm2d(cout), nn.ReLU()]
+    if pool:
+        layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+    layers.append(nn.Dropout2d(p))
+    return layers
+
+
+class _TwoDBase(nn.Module):
+    """Shared body of two_d_cnn_lstm (baseline_models.py:143-260) and deep_two_d_cnn_lstm
+    (:264-385).  `deep` adds a 4th conv without pooling and flattens instead of averaging."""
+
+    def __init__(self, deep, input_channel, input_spec_size, cnn_filter_size, lstm_hidden_size=128,
+                 num_layers_lstm=2, pred="emotion", bidirectional=True, rnn_cell="gru", attention_size=256,
+                 variable_lengths=False, global_feature=1, att=None):
+        super().__init__()
+        self.input_channel, self.input_spec_size = input_channel, input_spec_size
+        self.lstm_hidden_size, self.bidirectional = lstm_hidden_size, bidirectional
+        self.num_layers_lstm, self.dropout_p = num_layers_lstm, 0.2
+        self.variable_lengths = variable_lengths
+        self.num_emo_classes, self.num_gender_class = 4, 2
+        self.cnn_filter_size, self.attention_size = cnn_filter_size, attention_size
+        self.pred, self.att = pred, att
+        self.deep = deep
+        self.rnn_input_size = int(128 * input_spec_size / 8)
+        self.rnn_cell = _rnn_cell(rnn_cell)
+        self.dropout = nn.Dropout(p=self.dropout_p)
+        layers = _conv_block(1, 32, self.dropout_p) + _conv_block(32, 64, self.dropout_p) + \
+            _conv_block(64, 128, self.dropout_p)
+        if deep:
+            layers += _conv_block(128, 128, self.dropout_p, pool=False)
+        self.conv = nn.Sequential(*layers)
+        self.rnn = self.rnn_cell(input_size=self.rnn_input_size, hidden_size=lstm_hidden_size,
+                                 num_layers=num_layers_lstm, batch_first=True, dropout=self.dropout_p,
+                                 bidirectional=bidirectional)
+        d_att, n_att = attention_size, 16
+        self.att_linear1 = nn.Linear(lstm_hidden_size * 2, d_att, bias=False)
+        self.att_pool = nn.Tanh()
+        self.att_linear2 = nn.Linear(d_att, n_att, bias=False)
+        self.att_mat1 = nn.Parameter(torch.rand(d_att, lstm_hidden_size * 2))
+        self.att_mat2 = nn.Parameter(torch.rand(n_att, d_att))
+        self.dense_relu1, self.dense_relu2 = nn.ReLU(), nn.ReLU()
+        self.dense2 = nn.Linear(128, 64)
+        if global_feature == 1:
+            self.dense1 = nn.Linear(lstm_hidden_size * 2 + 88, 128)
+        else:
+            self.dense1 = nn.Linear(lstm_hidden_size * 2 * (25 if deep else 1), 128)
+        self.pred_emotion_layer = nn.Linear(128, self.num_emo_classes)
+        self.pred_gender_layer = nn.Linear(128, self.num_gender_class)
+        # reference init_weight() iterates the *names* in self._modules, so it changes
+        # nothing: weights stay at torch default init.
+
+    # the trunk shared with the cloak wrappers (cloak_models.py:165-193)
+    def features(self, x, global_feature=None, pooling="model"):
+        x = self.conv(x.float())
+        x = x.transpose(1, 2).contiguous()
+        s = x.size()
+        x = x.reshape(-1, s[1], s[2] * s[3])
+        x, _ = self.rnn(x)
+        if self.att is None:
+            flatten = self.deep if pooling == "model" else (pooling is None)
+            z = x.reshape(-1, x.size(1) * x.size(2)) if flatten else torch.mean(x, dim=1)
+        elif self.att == "self_att":
+            a = self.att_linear2(self.att_pool(self.att_linear1(x))).transpose(1, 2)
+            z = torch.mean(torch.matmul(torch.softmax(a, dim=2), x), dim=1)
+        if global_feature is not None:
+            z = torch.cat((z, global_feature), 1)
+        return self.dropout(self.dense_relu1(self.dense1(z)))
+
+    def head(self, z):
+        if self.pred == "multitask":
+            return self.pred_emotion_layer(z), self.pred_gender_layer(z)
+        if self.pred == "emotion":
+            return self.pred_emotion_layer(z)
+        return self.pred_gender_layer(z)
+
+    def forward(self, input_var, global_feature=None):
+        return self.head(self.features(input_var.float(), global_feature))
+
+
+class two_d_cnn_lstm(_TwoDBase):
+    def __init__(self, *a, **k):
+        super().__init__(False, *a, **k)
+
+
+class deep_two_d_cnn_lstm(_TwoDBase):
+    def __init__(self, *a, **k):
+        super().__init__(True, *a, **k)
+
+
+class one_d_cnn_lstm(nn.Module):
+    """baseline_models.py:19-140 -- a pure CNN: the RNN is constructed but never called."""
+
+    def __init__(self, input_channel, input_spec_size, cnn_filter_size, lstm_hidden_size=128, num_layers_lstm=2,
+                 pred="emotion", bidirectional=True, rnn_cell="gru", attention_size=256,
+                 variable_lengths=False, global_feature=1, att=None):
+        super().__init__()
+        self.input_spec_size, self.lstm_hidden_size = input_spec_size, lstm_hidden_size
+        self.dropout_p, self.pred, self.att = 0.2, pred, att
+        self.rnn_input_size = 512
+        p = self.dropout_p
+        self.dropout = nn.Dropout(p=p)
+        self.conv = nn.Sequential(
+            nn.Conv1d(input_spec_size, 128, kernel_size=5, padding=2), nn.ReLU(), nn.MaxPool1d(2, 2), nn.Dropout(p),
+            nn.Conv1d(128, 256, kernel_size=5, padding=2), nn.ReLU(), nn.MaxPool1d(5, 5), nn.Dropout(p),
+            nn.Conv1d(256, 512, kernel_size=5, padding=2), nn.ReLU(), nn.MaxPool1d(5, 5), nn.Dropout(p))
+        self.rnn = _rnn_cell(rnn_cell)(input_size=512, hidden_size=lstm_hidden_size, num_layers=num_layers_lstm,
+                                       batch_first=True, dropout=p, bidirectional=bidirectional)
+        d_att, n_att = attention_size, 8
+        self.att_linear1 = nn.Linear(lstm_hidden_size * 2, d_att)
+        self.att_pool = nn.Tanh()
+        self.att_linear2 = nn.Linear(d_att, n_att)
+        self.att_mat1 = nn.Parameter(torch.rand(d_att, lstm_hidden_size * 2))
+        self.att_mat2 = nn.Parameter(torch.rand(n_att, d_att))
+        self.dense_relu1, self.dense_relu2 = nn.ReLU(), nn.ReLU()
+        self.classifier = nn.Sequential(nn.Linear(512 * 4, 128), nn.ReLU(), nn.Dropout(p))
+        self.dense2 = nn.Linear(128, 64)
+        self.dense1 = nn.Linear(lstm_hidden_size * 2 + 88, 128) if global_feature == 1 else nn.Linear(512 * 4, 128)
+        self.pred_emotion_layer = nn.Linear(128, 4)
+        self.pred_gender_layer = nn.Linear(128, 2)
+
+    def forward(self, input_var, global_feature=None):
+        x = input_var.squeeze(dim=1).permute(0, 2, 1)
+        x = self.conv(x.float()).permute(0, 2, 1)
+        z = x.reshape(-1, x.size(1) * x.size(2))
+        if global_feature is not None:
+            z = torch.cat((z, global_feature), 1)
+        z = self.classifier(z)
+        if self.pred == "multitask":
+            return self.pred_emotion_layer(z), self.pred_gender_layer(z)
+        return self.pred_emotion_layer(z) if self.pred == "emotion" else self.pred_gender_layer(z)
+
+
+# ----------------------------------------------------------------------------------------
+# cloak wrappers (cloak_models.py:61-226)
+# ----------------------------------------------------------------------------------------
+def _freeze(model):
+    # cloak_models.py:69-76 / 142-149: only requires_grad is cleared; BatchNorm and Dropout
+    # stay in whatever mode .train()/.eval() puts them.
+    for p in model.parameters():
+        p.requires_grad = False
+
+
+class two_d_cnn_lstm_syn(nn.Module):
+    def __init__(self, original_model, noise_model):
+        super().__init__()
+        self.intermed, self.original_model = noise_model, original_model
+        _freeze(original_model)
+
+    def forward(self, input_var, global_feature=None, mask=None, pooling=None):
+        x = input_var.float()
+        x = self.intermed(x) if mask is None else self.intermed(x, mask)
+        noisy = x.detach()
+        m = self.original_model
+        z = m.features(x, global_feature, pooling)
+        return m.head(z), noisy
+
+
+class two_d_cnn_lstm_syn_with_grl(nn.Module):
+    def __init__(self, original_model, gender_model, noise_model, grl_lambda):
+        super().__init__()
+        self.intermed, self.original_model, self.gender_model = noise_model, original_model, gender_model
+        _freeze(original_model)
+        self.gender_model.conv = nn.Sequential(GradientReversal(grl_lambda), gender_model.conv)
+
+    def forward(self, input_var, global_feature=None, mask=None, grl=False, pooling=None):
+        x = input_var.float()
+        x = self.intermed(x) if mask is None else self.intermed(x, mask)
+        noisy = x.detach()
+        z1 = self.original_model.features(x, global_feature, pooling)
+        preds1 = self.original_model.pred_emotion_layer(z1)
+        z2 = self.gender_model.features(x, global_feature, pooling)
+        preds2 = self.gender_model.pred_gender_layer(z2)
+        return preds1, preds2, noisy
+
+
+# ----------------------------------------------------------------------------------------
+# the step loss (training_cloak_with_grl.py:141-160)
+# ----------------------------------------------------------------------------------------
+def grl_step_loss(preds, preds_grl, labels_emo, labels_gen, weights, gender_lambda, scale_lamda,
+                  cloak_model, training=True, suppression=False):
+    """sum_i w_i CE(emo_i)/B + gender_lambda * sum_i w_i CE(gen_i)/B - scale_lamda*log(mean(scales)).
+    `weights` (B,) per-sample speaker weights (ignored in validate mode, :153-154)."""
+    B = preds.shape[0]
+    ce_e = F.cross_entropy(preds, labels_emo.view(-1), reduction="none")
+    ce_g = F.cross_entropy(preds_grl, labels_gen.view(-1), reduction="none")
+    w = weights if training else torch.ones_like(ce_e)
+    total = (ce_e * w).sum() / B + float(gender_lambda) * (ce_g * w).sum() / B
+    if not suppression:
+        total = total - float(scale_lamda) * torch.log(torch.mean(cloak_model.intermed.scales()))
+    return total

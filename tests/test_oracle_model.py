@@ -1,0 +1,123 @@
+"""CPU tests pinning the model ORACLE (oracle/model_oracle.py) to golden vectors recorded
+from the REFERENCE modules (tools/make_goldens_model.py; reference model/*.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle import model_oracle as mo
+from tests.closed_form import (closed_form_eps, closed_form_input, closed_form_labels, closed_form_mask,
+                               closed_form_state)
+
+B, W = 8, 200
+
+
+@pytest.fixture(scope="module")
+def G(golden_dir):
+    return np.load(os.path.join(golden_dir, "model_golden.npz"))
+
+
+def mk(F, pred, cls=mo.two_d_cnn_lstm):
+    m = cls(1, F, 64, lstm_hidden_size=64, num_layers_lstm=2, pred=pred, attention_size=128, att=None,
+            global_feature=0)
+    m.load_state_dict(closed_form_state(m, prefix=pred + "."))
+    return m
+
+
+def zero_dropout(mod):
+    for m in mod.modules():
+        if isinstance(m, (nn.Dropout, nn.Dropout2d)):
+            m.p = 0.0
+        if isinstance(m, nn.GRU):
+            m.dropout = 0.0
+
+
+def build_grl(F):
+    emo, gen = mk(F, "emotion"), mk(F, "gender")
+    noise = mo.cloak_noise(torch.zeros(1, W, F), torch.ones(1, W, F), torch.tensor(0.01), torch.tensor(10.0), "cpu")
+    noise.load_state_dict(closed_form_state(noise, prefix="noise."))
+    noise.eps = closed_form_eps(W, F)
+    return mo.two_d_cnn_lstm_syn_with_grl(emo, gen, noise, 0.1)
+
+
+@pytest.mark.parametrize("F", [80, 128])
+def test_baseline_eval_logits(F, G):
+    x = closed_form_input(B, W, F)
+    for pred, key in (("emotion", "emo"), ("gender", "gen")):
+        m = mk(F, pred).eval()
+        with torch.no_grad():
+            np.testing.assert_allclose(m(x).numpy(), G[f"f{F}_{key}_eval_logits"], rtol=1e-5, atol=1e-6)
+    assert sum(p.numel() for p in mk(F, "emotion").parameters()) == int(G[f"f{F}_n_params_two_d"])
+
+
+@pytest.mark.parametrize("F", [80, 128])
+def test_grl_wrapper_eval_and_keys(F, G):
+    x, mask = closed_form_input(B, W, F), closed_form_mask(W, F)
+    grl = build_grl(F).eval()
+    assert sorted(grl.state_dict().keys()) == list(G[f"f{F}_keys_grl"])
+    with torch.no_grad():
+        p1, p2, nz = grl(x, mask=None, grl=False, pooling="mean")
+        np.testing.assert_allclose(p1.numpy(), G[f"f{F}_grl_eval_emo"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(p2.numpy(), G[f"f{F}_grl_eval_gen"], rtol=1e-5, atol=1e-6)
+        p1, p2, nz = grl(x, mask=mask, grl=False, pooling="mean")
+        np.testing.assert_allclose(p1.numpy(), G[f"f{F}_grl_eval_emo_masked"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(p2.numpy(), G[f"f{F}_grl_eval_gen_masked"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(nz.reshape(-1)[:64].numpy(), G[f"f{F}_grl_noisy_masked_slice"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("F", [80, 128])
+def test_grl_train_step_grads(F, G):
+    x = closed_form_input(B, W, F)
+    le, lg, wts = closed_form_labels(B)
+    grl = build_grl(F).train()
+    zero_dropout(grl)
+    p1, p2, _ = grl(x, mask=None, grl=False, pooling="mean")
+    loss = mo.grl_step_loss(p1, p2, le, lg, wts, 0.1, 0.05, grl)
+    loss.backward()
+    k = f"f{F}_"
+    np.testing.assert_allclose(p1.detach().numpy(), G[k + "train_emo"], rtol=1e-4, atol=1e-5)
+    assert loss.item() == pytest.approx(float(G[k + "train_loss"]), rel=1e-5)
+    np.testing.assert_allclose(grl.intermed.locs.grad.reshape(-1)[:256].numpy(), G[k + "grad_locs"], rtol=2e-3, atol=1e-8)
+    np.testing.assert_allclose(grl.intermed.rhos.grad.reshape(-1)[:256].numpy(), G[k + "grad_rhos"], rtol=2e-3, atol=1e-9)
+    assert grl.intermed.locs.grad.double().norm().item() == pytest.approx(float(G[k + "grad_locs_norm"]), rel=1e-4)
+    sd = dict(grl.gender_model.named_parameters())
+    for key in G.files:
+        if key.startswith(k + "gradnorm_"):
+            name = key[len(k + "gradnorm_"):]
+            assert sd[name].grad.double().norm().item() == pytest.approx(float(G[key]), rel=1e-3), name
+            np.testing.assert_allclose(sd[name].grad.reshape(-1)[:128].numpy(), G[k + "grad_" + name],
+                                       rtol=5e-3, atol=1e-6 * float(G[key]) + 1e-9)
+    assert all(p.grad is None for p in grl.original_model.parameters())
+    np.testing.assert_allclose(grl.original_model.conv[1].running_mean.numpy(), G[k + "emo_bn1_running_mean"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(grl.gender_model.conv[1][6].running_var.numpy(), G[k + "gen_bn2_running_var"], rtol=1e-5)
+    assert int(grl.gender_model.conv[1][1].num_batches_tracked) == int(G[k + "gen_bn1_batches"]) == 1
+
+
+@pytest.mark.parametrize("F", [80, 128])
+def test_syn_and_one_d(F, G):
+    x = closed_form_input(B, W, F)
+    noise = mo.cloak_noise(torch.zeros(1, W, F), torch.ones(1, W, F), torch.tensor(0.01), torch.tensor(10.0), "cpu")
+    np.testing.assert_allclose(noise.scales().reshape(-1)[:4].detach().numpy(), G[f"f{F}_scales_init"], rtol=1e-6)
+    assert noise.scales().flatten()[0].item() == pytest.approx(0.18970, abs=1e-4)
+    noise.load_state_dict(closed_form_state(noise, prefix="noise."))
+    noise.eps = closed_form_eps(W, F)
+    syn = mo.two_d_cnn_lstm_syn(mk(F, "emotion"), noise).eval()
+    with torch.no_grad():
+        p, nz = syn(x, pooling="mean")
+    np.testing.assert_allclose(p.numpy(), G[f"f{F}_syn_eval_logits"], rtol=1e-5, atol=1e-6)
+    od = mo.one_d_cnn_lstm(1, F, 64, lstm_hidden_size=64, num_layers_lstm=2, pred="emotion", attention_size=128,
+                           att=None, global_feature=0)
+    od.load_state_dict(closed_form_state(od, prefix="one_d."))
+    with torch.no_grad():
+        np.testing.assert_allclose(od.eval()(x).numpy(), G[f"f{F}_one_d_eval_logits"], rtol=1e-5, atol=1e-6)
+
+
+def test_grl_known_answer(G):
+    z = torch.arange(6.0).reshape(2, 3).requires_grad_()
+    y = mo.GradientReversalFunction.apply(z, 0.1)
+    assert torch.equal(y, z.detach())
+    (y * torch.arange(1.0, 7.0).reshape(2, 3)).sum().backward()
+    np.testing.assert_allclose(z.grad.numpy(), G["grl_kat_grad"])
+    np.testing.assert_allclose(z.grad.numpy(), -0.1 * np.arange(1.0, 7.0).reshape(2, 3), rtol=1e-6)
