@@ -69,6 +69,21 @@ int sept_mel_forward(const sept_mel_plan* plan, const float* wav, int B, int L, 
 /* name of the device kernel sept_mel_forward launches for this plan (for rocprof filters) */
 const char* sept_mel_kernel_name(const sept_mel_plan* plan);
 
+/* ------------------------------------------------------------------------------------
+ * Conv stack of two_d_cnn_lstm (model/baseline_models.py:171-189): Conv2d(k=5, pad=2) on
+ * bf16 MFMA with fp32 accumulation.  Activations are NHWC bf16 on the device
+ * ([B][H][W][C]); the reference's NCHW fp32 view exists only at the module boundary.
+ * ------------------------------------------------------------------------------------ */
+/* w_oihw: the nn.Conv2d weight (cout, cin, 5, 5) fp32 -> wt_bf16[25][o'][i'] bf16.
+ * mode 0: forward operand (o'=cout, i'=cin).  mode 1: data-gradient operand (o'=cin,
+ * i'=cout, taps flipped) so that dX = sept_conv5x5_forward(dY, wt_mode1, cin'=cout, cout'=cin). */
+int sept_conv5x5_prep_weights(const float* w_oihw, int cout, int cin, int mode, void* wt_bf16,
+                              void* stream);
+/* y[B][H][W][cout] = conv5x5(x[B][H][W][cin], wt) (+ bias[cout] if non-null), bf16 in/out.
+ * Channel pairs: 32->64, 64->128 (forward), 64->32, 128->64 (data gradient), 128->128. */
+int sept_conv5x5_forward(const void* x_bf16, const void* wt_bf16, const float* bias, void* y_bf16,
+                         int B, int H, int W, int cin, int cout, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

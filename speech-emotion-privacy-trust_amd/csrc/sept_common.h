@@ -38,6 +38,10 @@ inline int launch_check(const char* what) {
   return SEPT_OK;
 }
 
+// Raise a kernel's dynamic-LDS limit to the full 160 KiB once (not a stream operation; done
+// on first use so the launch functions themselves stay graph-capture safe afterwards).
+hipError_t allow_max_lds(const void* fn);
+
 // wave-local LDS hand-off: the lanes of one wavefront execute in lockstep and a wave's LDS
 // operations retire in order, so data written by one lane is visible to a later read by
 // another lane of the SAME wave without a workgroup barrier; the fences only stop the

@@ -1,0 +1,243 @@
+// 5x5 / pad 2 / stride 1 convolution as an implicit GEMM on bf16 MFMA (gfx950), NHWC.
+//
+// Stands behind the nn.Conv2d(.., kernel_size=5, padding=2) layers of the reference's
+// two_d_cnn_lstm conv stack (model/baseline_models.py:171-189) -- forward, and (with
+// channel roles swapped and taps flipped by sept_conv5x5_prep_weights) the data gradient.
+//
+// Formulation: out^T[cout][pixel] = sum_tap sum_cin Wt[tap][cout][cin] * X[pixel + tap][cin]
+//   A operand = weights  (rows = cout,  k = cin)   -> 16-B LDS reads from a per-tap weight tile
+//   B operand = activations (cols = pixel, k = cin) -> 16-B LDS reads from the input tile
+// so each lane ends up with 4 consecutive output channels of ONE pixel per accumulator
+// quad and the epilogue stores 8-byte packed bf16 runs in NHWC.
+//
+// A workgroup (4 waves) owns MT = 128*PB consecutive (flattened h*W+w) output pixels of one
+// image and ALL output channels.  The input rows those pixels touch (+2 halo rows/cols,
+// zero-filled outside the image) are staged ONCE in LDS and reused by all 25 taps and all
+// output channels; weights stream through a double-buffered per-tap LDS tile (prefetched
+// into registers under the MFMAs, one barrier per tap).  Pixel stride in LDS is padded by
+// 16 B so the 16-lane groups of ds_read_b128 hit distinct banks.
+#include "sept_common.h"
+
+namespace {
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int kTaps = 25;
+
+struct ConvArgs {
+  const bf16* x;      // [B][H][W][CIN]
+  const bf16* wt;     // [25][COUT][CIN]
+  const float* bias;  // [COUT] or null
+  bf16* y;            // [B][H][W][COUT]
+  int B, H, W, nr_max;
+};
+
+__host__ __device__ constexpr int conv_nr_max(int mt, int w) { return (mt + w - 2) / w + 5; }
+
+template <int CIN, int COUT, int PB>
+__global__ __launch_bounds__(256) void sept_conv5x5_mfma_kernel(ConvArgs a) {
+  constexpr int MT = 128 * PB;
+  constexpr int NB = COUT / 32;
+  constexpr int KS = CIN / 16;
+  constexpr int PS = CIN * 2 + 16;   // bytes per staged pixel (padded)
+  constexpr int PSW = CIN * 2 + 16;  // bytes per staged weight row (padded)
+  constexpr int CPP = CIN / 8;       // 16-B chunks per pixel
+  constexpr int WCH = (COUT * CPP + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int W = a.W, H = a.H, HW = H * W, W4 = W + 4;
+  unsigned char* tile = smem;
+  unsigned char* wbuf = smem + size_t(a.nr_max) * W4 * PS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y;
+  const int q0 = blockIdx.x * MT;
+  const int h_first = q0 / W;
+  const int h_last = min(q0 + MT - 1, HW - 1) / W;
+  const int NR = h_last - h_first + 5;
+
+  // ---- stage input rows [h_first-2, h_last+2] x cols [-2, W+2) ----
+  {
+    const bf16* xb = a.x + size_t(b) * HW * CIN;
+    const int total = NR * W4 * CPP;
+    for (int i = tid; i < total; i += 256) {
+      const int c = i % CPP, px = i / CPP;
+      const int col = px % W4, row = px / W4;
+      const int h = h_first - 2 + row, w = col - 2;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (h >= 0 && h < H && w >= 0 && w < W)
+        v = *reinterpret_cast<const uint4*>(xb + (size_t(h) * W + w) * CIN + c * 8);
+      *reinterpret_cast<uint4*>(tile + size_t(px) * PS + c * 16) = v;
+    }
+  }
+  auto wload = [&](int tap, uint4 (&r)[WCH]) {
+    const bf16* wsrc = a.wt + size_t(tap) * COUT * CIN;
+#pragma unroll
+    for (int j = 0; j < WCH; ++j) {
+      const int i = tid + 256 * j;
+      if (i < COUT * CPP) r[j] = *reinterpret_cast<const uint4*>(wsrc + size_t(i) * 8);
+    }
+  };
+  auto wstore = [&](int buf, const uint4 (&r)[WCH]) {
+    unsigned char* dst = wbuf + size_t(buf) * COUT * PSW;
+#pragma unroll
+    for (int j = 0; j < WCH; ++j) {
+      const int i = tid + 256 * j;
+      if (i < COUT * CPP) *reinterpret_cast<uint4*>(dst + (i / CPP) * PSW + (i % CPP) * 16) = r[j];
+    }
+  };
+  {
+    uint4 r[WCH];
+    wload(0, r);
+    wstore(0, r);
+  }
+  __syncthreads();
+
+  int lane_base[PB];
+#pragma unroll
+  for (int pb = 0; pb < PB; ++pb) {
+    const int q = min(q0 + (wave * PB + pb) * 32 + (lane & 31), HW - 1);
+    const int h = q / W, w = q - h * W;
+    lane_base[pb] = ((h - h_first) * W4 + w) * PS + (lane >> 5) * 16;
+  }
+  const int a_base = (lane & 31) * PSW + (lane >> 5) * 16;
+
+  f32x16 acc[PB][NB];
+#pragma unroll
+  for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[pb][nb][r] = 0.f;
+
+  for (int tap = 0; tap < kTaps; ++tap) {
+    const int kh = tap / 5, kw = tap - kh * 5;
+    const int tapoff = (kh * W4 + kw) * PS;
+    uint4 wreg[WCH];
+    if (tap + 1 < kTaps) wload(tap + 1, wreg);
+    const unsigned char* wb = wbuf + size_t(tap & 1) * COUT * PSW;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bf16x8 bfrag[PB], afrag[NB];
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb)
+        bfrag[pb] = *reinterpret_cast<const bf16x8*>(tile + lane_base[pb] + tapoff + ks * 32);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+        afrag[nb] = *reinterpret_cast<const bf16x8*>(wb + nb * 32 * PSW + a_base + ks * 32);
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          acc[pb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[nb], bfrag[pb], acc[pb][nb], 0, 0, 0);
+    }
+    if (tap + 1 < kTaps) wstore((tap + 1) & 1, wreg);
+    __syncthreads();
+  }
+
+  // ---- epilogue: + bias, round to bf16, 8-byte NHWC stores ----
+  bf16* yb = a.y + size_t(b) * HW * COUT;
+#pragma unroll
+  for (int pb = 0; pb < PB; ++pb) {
+    const int q = q0 + (wave * PB + pb) * 32 + (lane & 31);
+    if (q >= HW) continue;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = nb * 32 + 8 * g + 4 * (lane >> 5);
+        f32x4 v = {acc[pb][nb][4 * g + 0], acc[pb][nb][4 * g + 1], acc[pb][nb][4 * g + 2],
+                   acc[pb][nb][4 * g + 3]};
+        if (a.bias) {
+          const f32x4 bv = {a.bias[co], a.bias[co + 1], a.bias[co + 2], a.bias[co + 3]};
+          v += bv;
+        }
+        *reinterpret_cast<bf16x4*>(yb + size_t(q) * COUT + co) = __builtin_convertvector(v, bf16x4);
+      }
+    }
+  }
+}
+
+// weights: OIHW fp32 -> [tap][cout'][cin'] bf16.  mode 0: forward.  mode 1: data gradient
+// (cout' = cin, cin' = cout, taps flipped).
+__global__ void sept_conv5x5_prep_kernel(const float* w, bf16* wt, int cout, int cin, int mode) {
+  const int n = cout * cin * kTaps;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    // i indexes the destination [tap][o2][i2]
+    const int o2n = mode == 0 ? cout : cin, i2n = mode == 0 ? cin : cout;
+    const int i2 = i % i2n, o2 = (i / i2n) % o2n, tap = i / (i2n * o2n);
+    const int kh = tap / 5, kw = tap % 5;
+    float v;
+    if (mode == 0)
+      v = w[((size_t(o2) * cin + i2) * 5 + kh) * 5 + kw];
+    else
+      v = w[((size_t(i2) * cin + o2) * 5 + (4 - kh)) * 5 + (4 - kw)];
+    wt[i] = (bf16)v;
+  }
+}
+
+struct ConvVariant {
+  int cin, cout, pb;
+  const void* fn;
+};
+#define SEPT_CONV_VARIANT(ci, co, pb) \
+  { ci, co, pb, reinterpret_cast<const void*>(&sept_conv5x5_mfma_kernel<ci, co, pb>) }
+const ConvVariant kConvVariants[] = {
+    SEPT_CONV_VARIANT(32, 64, 2),  SEPT_CONV_VARIANT(64, 128, 2), SEPT_CONV_VARIANT(64, 128, 1),
+    SEPT_CONV_VARIANT(64, 32, 2),  SEPT_CONV_VARIANT(128, 64, 1), SEPT_CONV_VARIANT(128, 128, 1),
+};
+
+}  // namespace
+
+extern "C" int sept_conv5x5_prep_weights(const float* w_oihw, int cout, int cin, int mode, void* wt_bf16,
+                                         void* stream) {
+  SEPT_REQUIRE(w_oihw && wt_bf16, SEPT_ERR_INVALID, "sept_conv5x5_prep_weights: null argument");
+  SEPT_REQUIRE(cout > 0 && cin > 0 && (mode == 0 || mode == 1), SEPT_ERR_INVALID,
+               "sept_conv5x5_prep_weights: cout=%d cin=%d mode=%d", cout, cin, mode);
+  const int n = cout * cin * kTaps;
+  hipLaunchKernelGGL(sept_conv5x5_prep_kernel, dim3((n + 255) / 256), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), w_oihw, static_cast<bf16*>(wt_bf16), cout, cin, mode);
+  return sept::launch_check("sept_conv5x5_prep_kernel");
+}
+
+extern "C" int sept_conv5x5_forward(const void* x, const void* wt, const float* bias, void* y, int B, int H,
+                                    int W, int cin, int cout, void* stream) {
+  SEPT_REQUIRE(B >= 0 && H > 0 && W > 0, SEPT_ERR_INVALID, "sept_conv5x5_forward: B=%d H=%d W=%d", B, H, W);
+  if (B == 0) return SEPT_OK;
+  SEPT_REQUIRE(x && wt && y, SEPT_ERR_INVALID, "sept_conv5x5_forward: null argument");
+  SEPT_REQUIRE(B <= 65535, SEPT_ERR_UNSUPPORTED, "sept_conv5x5_forward: B=%d exceeds grid.y", B);
+  const ConvVariant* best = nullptr;
+  size_t best_smem = 0;
+  for (const ConvVariant& v : kConvVariants) {
+    if (v.cin != cin || v.cout != cout) continue;
+    const int mt = 128 * v.pb;
+    const size_t ps = size_t(cin) * 2 + 16;
+    const size_t smem = size_t(conv_nr_max(mt, W)) * (W + 4) * ps + 2 * size_t(cout) * ps;
+    if (smem > 160 * 1024) continue;
+    if (!best) {
+      best = &v;
+      best_smem = smem;
+    }
+  }
+  SEPT_REQUIRE(best, SEPT_ERR_UNSUPPORTED,
+               "sept_conv5x5_forward: no kernel for cin=%d cout=%d W=%d (supported channel pairs: 32->64, "
+               "64->128, 64->32, 128->64, 128->128)", cin, cout, W);
+  ConvArgs a;
+  a.x = static_cast<const bf16*>(x);
+  a.wt = static_cast<const bf16*>(wt);
+  a.bias = bias;
+  a.y = static_cast<bf16*>(y);
+  a.B = B;
+  a.H = H;
+  a.W = W;
+  const int mt = 128 * best->pb;
+  a.nr_max = conv_nr_max(mt, W);
+  SEPT_HIP(sept::allow_max_lds(best->fn));
+  dim3 grid((H * W + mt - 1) / mt, B), block(256);
+  void* args[] = {&a};
+  SEPT_HIP(hipLaunchKernel(best->fn, grid, block, args, best_smem, static_cast<hipStream_t>(stream)));
+  return SEPT_OK;
+}

@@ -2,11 +2,23 @@
 #include "sept_common.h"
 
 #include <cstring>
+#include <mutex>
+#include <set>
 
 namespace sept {
 char* err_buf() {
   static thread_local char buf[512] = {0};
   return buf;
+}
+
+hipError_t allow_max_lds(const void* fn) {
+  static std::mutex mu;
+  static std::set<const void*> done;
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.count(fn)) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) done.insert(fn);
+  return e;
 }
 }  // namespace sept
 

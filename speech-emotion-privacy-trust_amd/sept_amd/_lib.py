@@ -33,6 +33,9 @@ SIGNATURES = {
     "sept_mel_num_frames": (c_int, [c_void_p, c_int]),
     "sept_mel_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     "sept_mel_kernel_name": (c_char_p, [c_void_p]),
+    "sept_conv5x5_prep_weights": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "sept_conv5x5_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                     c_void_p]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

@@ -1,0 +1,61 @@
+"""GPU parity of the bf16-MFMA 5x5 convolution (forward and data-gradient form) against a
+plain fp32 torch conv on the same bf16-rounded operands (reference layers:
+model/baseline_models.py:171-189).  Tolerance: fp32 accumulation of bf16 products is exact
+up to summation order; the only rounding is the bf16 output (rel 2^-8)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [  # (B, H, W, cin, cout)
+    (3, 100, 40, 32, 64),    # conv2 @ 80 mels
+    (2, 100, 64, 32, 64),    # conv2 @ 128 mels
+    (3, 50, 20, 64, 128),    # conv3 @ 80 mels
+    (2, 50, 32, 64, 128),    # conv3 @ 128 mels
+    (2, 25, 10, 128, 128),   # deep model 4th conv
+    (1, 7, 9, 32, 64),       # ragged: tile tail + tiny image
+    (2, 33, 5, 64, 128),
+]
+
+
+def _ref(x_nhwc, w, bias):
+    y = F.conv2d(x_nhwc.float().permute(0, 3, 1, 2), w.bfloat16().float(), bias, padding=2)
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout", SHAPES)
+def test_conv_forward(B, H, W, cin, cout):
+    from sept_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    x = torch.randn(B, H, W, cin, generator=g).bfloat16().cuda()
+    w = (torch.randn(cout, cin, 5, 5, generator=g) / (cin * 25) ** 0.5).cuda()
+    bias = (0.1 * torch.randn(cout, generator=g)).cuda()
+    y = ops.conv5x5(x, ops.conv5x5_prep_weights(w, 0), bias).float()
+    want = _ref(x, w, bias)
+    assert torch.allclose(y, want, rtol=1e-2, atol=1e-2), (y - want).abs().max()
+    # exactness before the final rounding: error bounded by one bf16 ulp of the value
+    assert ((y - want).abs() <= want.abs() * 2 ** -7 + 1e-3).all()
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout", SHAPES[:4] + SHAPES[5:])
+def test_conv_data_gradient(B, H, W, cin, cout):
+    """dX = conv(dY, flipped/transposed W): compare with autograd of the fp32 conv."""
+    from sept_amd import ops
+    g = torch.Generator().manual_seed(7 + W)
+    dy = torch.randn(B, H, W, cout, generator=g).bfloat16().cuda()
+    w = (torch.randn(cout, cin, 5, 5, generator=g) / (cout * 25) ** 0.5).cuda()
+    dx = ops.conv5x5(dy, ops.conv5x5_prep_weights(w, 1)).float()
+    x = torch.zeros(B, cin, H, W, device="cuda", requires_grad=True)
+    F.conv2d(x, w.bfloat16().float(), None, padding=2).backward(dy.float().permute(0, 3, 1, 2))
+    want = x.grad.permute(0, 2, 3, 1)
+    assert torch.allclose(dx, want, rtol=1e-2, atol=1e-2), (dx - want).abs().max()
+
+
+def test_conv_errors():
+    from sept_amd import ops
+    from sept_amd._lib import SeptError
+    x = torch.zeros(1, 8, 8, 48, dtype=torch.bfloat16, device="cuda")
+    wt = torch.zeros(25, 64, 48, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(SeptError):
+        ops.conv5x5(x, wt)
