@@ -84,6 +84,40 @@ int sept_conv5x5_prep_weights(const float* w_oihw, int cout, int cin, int mode, 
 int sept_conv5x5_forward(const void* x_bf16, const void* wt_bf16, const float* bias, void* y_bf16,
                          int B, int H, int W, int cin, int cout, void* stream);
 
+/* First layer Conv2d(1 -> 32, k=5, pad=2) (baseline_models.py:172): x / dx fp32 [B][H][W],
+ * y / dy bf16 [B][H][W][32], w fp32 [32][1][5][5].  fp32 direct forward; packed-bf16 dot2
+ * data gradient (feeds the cloak parameters, cloak_models.py:45-58); deterministic weight
+ * gradient through a workspace of sept_conv1_workspace_floats() floats. */
+int sept_conv1_forward(const float* x, const float* w, const float* bias, void* y_bf16, int B, int H, int W,
+                       void* stream);
+int sept_conv1_backward_data(const void* dy_bf16, const float* w, float* dx, int B, int H, int W, void* stream);
+size_t sept_conv1_workspace_floats(void);
+int sept_conv1_backward_weight(const float* x, const void* dy_bf16, float* ws, float* dw, float* db /*nullable*/,
+                               int B, int H, int W, void* stream);
+
+/* BatchNorm2d + ReLU + MaxPool2d(pool in {1,2}) + Dropout2d (baseline_models.py:173-176 etc.),
+ * NHWC bf16, C in {32, 64, 128}.  `ws` is a float workspace of sept_bn_workspace_floats(C).
+ * sept_bn_stats: training-mode batch statistics of x[n_rows][C] (+ running-stat update with
+ * `momentum`, unbiased running_var, num_batches_tracked += 1; any of the three may be null).
+ * sept_bn_eval_stats: mean/invstd from the running buffers (module in eval mode).
+ * forward:  y[B][H/p][W/p][C] = dropscale[B][C] * maxpool_p(relu(gamma*(x-mean)*invstd+beta))
+ *           (dropscale null = no Dropout2d; entries are 0 or 1/(1-p))
+ * backward: dx[B][H][W][C] from dy[B][H/p][W/p][C] through dropout, pooling (first maximum,
+ *           as ATen), ReLU and training-mode BatchNorm; dgamma/dbeta optional. */
+size_t sept_bn_workspace_floats(int C);
+int sept_bn_stats(const void* x_bf16, long n_rows, int C, float* ws, float* mean, float* invstd,
+                  float* running_mean, float* running_var, long long* num_batches_tracked, float momentum,
+                  float eps, void* stream);
+int sept_bn_eval_stats(const float* running_mean, const float* running_var, int C, float eps, float* mean,
+                       float* invstd, void* stream);
+int sept_bn_relu_pool_forward(const void* x_bf16, const float* mean, const float* invstd, const float* gamma,
+                              const float* beta, const float* dropscale, void* y_bf16, int B, int H, int W,
+                              int C, int pool, void* stream);
+int sept_bn_relu_pool_backward(const void* dy_bf16, const void* x_bf16, const float* mean, const float* invstd,
+                               const float* gamma, const float* beta, const float* dropscale, float* ws,
+                               void* dx_bf16, float* dgamma, float* dbeta, int B, int H, int W, int C, int pool,
+                               void* stream);
+
 #ifdef __cplusplus
 }
 #endif

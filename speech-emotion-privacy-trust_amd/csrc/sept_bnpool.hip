@@ -1,0 +1,342 @@
+// BatchNorm2d (+ReLU +MaxPool2d(2,2) +Dropout2d) around the MFMA convs, NHWC bf16.
+//
+// Stands behind the nn.BatchNorm2d / nn.ReLU / nn.MaxPool2d / nn.Dropout2d members of the
+// reference conv stack (model/baseline_models.py:172-188; deep variant :293-314 has one
+// block without pooling).  BatchNorm runs with batch statistics whenever the module is in
+// train mode -- including the "frozen" emotion model.
+//
+// All kernels are HBM-bound elementwise / reduction passes: 16-byte (8 x bf16) accesses,
+// channel chunk per lane fixed so per-channel sums stay in registers, two-stage
+// deterministic reductions (per-block partials in a workspace, fixed-order finalize in
+// float64) instead of float atomics.
+#include <algorithm>
+#include <cmath>
+
+#include "sept_common.h"
+
+namespace {
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+
+constexpr int kParts = 512;  // partial-sum blocks (workspace rows)
+
+__device__ __forceinline__ f32x8 load8(const bf16* p) {
+  const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+  return __builtin_convertvector(v, f32x8);
+}
+__device__ __forceinline__ void store8(bf16* p, f32x8 v) {
+  *reinterpret_cast<bf16x8*>(p) = __builtin_convertvector(v, bf16x8);
+}
+__device__ __forceinline__ f32x8 loadf8(const float* p) {
+  f32x8 v;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = p[i];
+  return v;
+}
+
+// block-level deterministic reduction of per-thread (a[8], b[8]) over the threads sharing a
+// channel chunk; writes [2C] floats (sum_a[C], sum_b[C]) to dst.
+template <int CPP>
+__device__ __forceinline__ void block_reduce_2c(const f32x8& a, const f32x8& b, float* dst, float* lds) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    lds[tid * 16 + i] = a[i];
+    lds[tid * 16 + 8 + i] = b[i];
+  }
+  __syncthreads();
+  constexpr int C = CPP * 8;
+  if (tid < 2 * C) {
+    const int which = tid / C, c = tid % C, chunk = c / 8, e = c % 8;
+    float s = 0.f;
+    for (int t = chunk; t < 256; t += CPP) s += lds[t * 16 + which * 8 + e];
+    dst[tid] = s;
+  }
+}
+
+// ---- forward statistics -------------------------------------------------------------------
+template <int CPP>
+__global__ __launch_bounds__(256) void sept_bn_stats_partial_kernel(const bf16* x, long n_items, float* ws) {
+  __shared__ float lds[256 * 16];
+  f32x8 s = {0, 0, 0, 0, 0, 0, 0, 0}, ss = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (long i = long(blockIdx.x) * 256 + threadIdx.x; i < n_items; i += long(gridDim.x) * 256) {
+    const f32x8 v = load8(x + i * 8);
+    s += v;
+    ss += v * v;
+  }
+  block_reduce_2c<CPP>(s, ss, ws + size_t(blockIdx.x) * 2 * CPP * 8, lds);
+}
+
+__global__ void sept_bn_stats_finalize_kernel(const float* ws, int nparts, int C, double n, float* mean,
+                                              float* invstd, float* running_mean, float* running_var,
+                                              long long* nbt, float momentum, float eps) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && nbt) *nbt += 1;
+  if (c >= C) return;
+  double s = 0, ss = 0;
+  for (int p = 0; p < nparts; ++p) {
+    s += ws[size_t(p) * 2 * C + c];
+    ss += ws[size_t(p) * 2 * C + C + c];
+  }
+  const double m = s / n;
+  double var = ss / n - m * m;
+  var = var < 0 ? 0 : var;
+  mean[c] = float(m);
+  invstd[c] = float(1.0 / sqrt(var + double(eps)));
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * float(m);
+  if (running_var) {
+    const double unbiased = n > 1 ? var * n / (n - 1) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * float(unbiased);
+  }
+}
+
+__global__ void sept_bn_eval_stats_kernel(const float* rm, const float* rv, int C, float eps, float* mean,
+                                          float* invstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    mean[c] = rm[c];
+    invstd[c] = 1.0f / sqrtf(rv[c] + eps);
+  }
+}
+
+// ---- forward: y = dropscale * maxpool(relu(bn(x))) ---------------------------------------------
+struct BnFwdArgs {
+  const bf16* x;
+  const float *mean, *invstd, *gamma, *beta, *drop;
+  bf16* y;
+  int B, H, W, C, pool;
+};
+
+template <int CPP>
+__global__ __launch_bounds__(256) void sept_bn_relu_pool_fwd_kernel(BnFwdArgs a) {
+  const int C = CPP * 8, P = a.pool;
+  const int Ho = a.H / P, Wo = a.W / P;
+  const long n_items = long(a.B) * Ho * Wo * CPP;
+  const int chunk = threadIdx.x % CPP;  // 256 % CPP == 0: the chunk of a lane never changes
+  const f32x8 mu = loadf8(a.mean + chunk * 8), is = loadf8(a.invstd + chunk * 8);
+  const f32x8 ga = loadf8(a.gamma + chunk * 8), be = loadf8(a.beta + chunk * 8);
+  const f32x8 sc = ga * is, sh = be - mu * ga * is;
+  for (long i = long(blockIdx.x) * 256 + threadIdx.x; i < n_items; i += long(gridDim.x) * 256) {
+    const long px = i / CPP;
+    const int wo = px % Wo, ho = (px / Wo) % Ho, b = px / (long(Wo) * Ho);
+    const bf16* xp = a.x + ((long(b) * a.H + ho * P) * a.W + wo * P) * C + chunk * 8;
+    f32x8 m = {0, 0, 0, 0, 0, 0, 0, 0};  // relu floor
+    for (int dh = 0; dh < P; ++dh)
+      for (int dw = 0; dw < P; ++dw) {
+        const f32x8 v = load8(xp + (long(dh) * a.W + dw) * C) * sc + sh;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], v[e]);
+      }
+    if (a.drop) m *= loadf8(a.drop + long(b) * C + chunk * 8);
+    store8(a.y + px * C + chunk * 8, m);
+  }
+}
+
+// ---- backward ---------------------------------------------------------------------------------
+struct BnBwdArgs {
+  const bf16* dy;  // [B][Ho][Wo][C]
+  const bf16* x;   // pre-BN conv output [B][H][W][C]
+  const float *mean, *invstd, *gamma, *beta, *drop;
+  float* ws;        // partials [kParts][2C], then sums at ws + kParts*2C
+  bf16* dx;         // [B][H][W][C]
+  int B, H, W, C, pool;
+};
+
+// For one pooled position: the gradient reaching the pre-BN tensor is non-zero at one
+// position only (first maximum in window scan order, as ATen's max_pool2d picks) and only
+// if the ReLU was active there.  Returns g (gradient wrt the BN output at that position),
+// xh (normalised input there) and the window index `arg` per channel.
+template <int CPP>
+__device__ __forceinline__ void bn_bwd_window(const BnBwdArgs& a, long px, int chunk, const f32x8& mu,
+                                              const f32x8& is, const f32x8& sc, const f32x8& sh, f32x8& g,
+                                              f32x8& xh, int (&arg)[8]) {
+  const int C = CPP * 8, P = a.pool;
+  const int Ho = a.H / P, Wo = a.W / P;
+  const int wo = px % Wo, ho = (px / Wo) % Ho, b = px / (long(Wo) * Ho);
+  const bf16* xp = a.x + ((long(b) * a.H + ho * P) * a.W + wo * P) * C + chunk * 8;
+  f32x8 best, bx;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    best[e] = -INFINITY;
+    bx[e] = 0.f;
+    arg[e] = 0;
+  }
+  for (int dh = 0; dh < P; ++dh)
+    for (int dw = 0; dw < P; ++dw) {
+      const f32x8 xv = load8(xp + (long(dh) * a.W + dw) * C);
+      const f32x8 v = xv * sc + sh;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float r = fmaxf(v[e], 0.f);
+        if (r > best[e]) {
+          best[e] = r;
+          bx[e] = xv[e];
+          arg[e] = dh * P + dw;
+        }
+      }
+    }
+  g = load8(a.dy + px * C + chunk * 8);
+  if (a.drop) g *= loadf8(a.drop + long(b) * C + chunk * 8);
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    if (!(best[e] > 0.f)) g[e] = 0.f;  // ReLU inactive (or window all <= 0)
+  xh = (bx - mu) * is;
+}
+
+template <int CPP>
+__global__ __launch_bounds__(256) void sept_bn_bwd_reduce_kernel(BnBwdArgs a) {
+  __shared__ float lds[256 * 16];
+  const int P = a.pool;
+  const long n_items = long(a.B) * (a.H / P) * (a.W / P) * CPP;
+  const int chunk = threadIdx.x % CPP;
+  const f32x8 mu = loadf8(a.mean + chunk * 8), is = loadf8(a.invstd + chunk * 8);
+  const f32x8 ga = loadf8(a.gamma + chunk * 8), be = loadf8(a.beta + chunk * 8);
+  const f32x8 sc = ga * is, sh = be - mu * ga * is;
+  f32x8 s1 = {0, 0, 0, 0, 0, 0, 0, 0}, s2 = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (long i = long(blockIdx.x) * 256 + threadIdx.x; i < n_items; i += long(gridDim.x) * 256) {
+    f32x8 g, xh;
+    int arg[8];
+    bn_bwd_window<CPP>(a, i / CPP, chunk, mu, is, sc, sh, g, xh, arg);
+    s1 += g;
+    s2 += g * xh;
+  }
+  block_reduce_2c<CPP>(s1, s2, a.ws + size_t(blockIdx.x) * 2 * CPP * 8, lds);
+}
+
+__global__ void sept_bn_bwd_finalize_kernel(float* ws, int nparts, int C, float* dgamma, float* dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0, s2 = 0;
+  for (int p = 0; p < nparts; ++p) {
+    s1 += ws[size_t(p) * 2 * C + c];
+    s2 += ws[size_t(p) * 2 * C + C + c];
+  }
+  float* sums = ws + size_t(kParts) * 2 * C;
+  sums[c] = float(s1);      // sum dy      (= dbeta)
+  sums[C + c] = float(s2);  // sum dy*xhat (= dgamma)
+  if (dbeta) dbeta[c] = float(s1);
+  if (dgamma) dgamma[c] = float(s2);
+}
+
+template <int CPP>
+__global__ __launch_bounds__(256) void sept_bn_bwd_apply_kernel(BnBwdArgs a) {
+  const int C = CPP * 8, P = a.pool;
+  const int Ho = a.H / P, Wo = a.W / P;
+  const long n_items = long(a.B) * Ho * Wo * CPP;
+  const int chunk = threadIdx.x % CPP;
+  const f32x8 mu = loadf8(a.mean + chunk * 8), is = loadf8(a.invstd + chunk * 8);
+  const f32x8 ga = loadf8(a.gamma + chunk * 8), be = loadf8(a.beta + chunk * 8);
+  const f32x8 sc = ga * is, sh = be - mu * ga * is;
+  const float* sums = a.ws + size_t(kParts) * 2 * C;
+  const float inv_n = 1.0f / (float(a.B) * a.H * a.W);
+  const f32x8 m1 = loadf8(sums + chunk * 8) * inv_n, m2 = loadf8(sums + C + chunk * 8) * inv_n;
+  for (long i = long(blockIdx.x) * 256 + threadIdx.x; i < n_items; i += long(gridDim.x) * 256) {
+    const long px = i / CPP;
+    f32x8 g, xh;
+    int arg[8];
+    bn_bwd_window<CPP>(a, px, chunk, mu, is, sc, sh, g, xh, arg);
+    const int wo = px % Wo, ho = (px / Wo) % Ho, b = px / (long(Wo) * Ho);
+    const long base = ((long(b) * a.H + ho * P) * a.W + wo * P) * C + chunk * 8;
+    for (int dh = 0; dh < P; ++dh)
+      for (int dw = 0; dw < P; ++dw) {
+        const long off = base + (long(dh) * a.W + dw) * C;
+        const f32x8 xhat = (load8(a.x + off) - mu) * is;
+        f32x8 d;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float ge = (arg[e] == dh * P + dw) ? g[e] : 0.f;
+          d[e] = sc[e] * (ge - m1[e] - xhat[e] * m2[e]);
+        }
+        store8(a.dx + off, d);
+      }
+  }
+  // rows/cols dropped by floor-mode pooling (odd H or W) receive only the mean terms
+  if (a.H % P || a.W % P) {
+    const long n_px = long(a.B) * a.H * a.W * CPP;
+    for (long i = long(blockIdx.x) * 256 + threadIdx.x; i < n_px; i += long(gridDim.x) * 256) {
+      const long px = i / CPP;
+      const int w = px % a.W, h = (px / a.W) % a.H;
+      if (h < Ho * P && w < Wo * P) continue;
+      const long off = px * C + chunk * 8;
+      const f32x8 xhat = (load8(a.x + off) - mu) * is;
+      store8(a.dx + off, sc * (-m1 - xhat * m2));
+    }
+  }
+}
+
+int grid_for(long items) { return int(std::min<long>((items + 255) / 256, kParts)); }
+
+}  // namespace
+
+#define SEPT_CPP_DISPATCH(C, CALL)                                                              \
+  switch (C) {                                                                                  \
+    case 32: { constexpr int CPP = 4; CALL; } break;                                            \
+    case 64: { constexpr int CPP = 8; CALL; } break;                                            \
+    case 128: { constexpr int CPP = 16; CALL; } break;                                          \
+    default: return sept::fail(SEPT_ERR_UNSUPPORTED, "channels=%d (supported: 32, 64, 128)", C); \
+  }
+
+extern "C" size_t sept_bn_workspace_floats(int C) { return size_t(kParts + 1) * 2 * size_t(C); }
+
+extern "C" int sept_bn_stats(const void* x, long n_rows, int C, float* ws, float* mean, float* invstd,
+                             float* running_mean, float* running_var, long long* num_batches_tracked,
+                             float momentum, float eps, void* stream) {
+  SEPT_REQUIRE(x && ws && mean && invstd && n_rows > 0, SEPT_ERR_INVALID, "sept_bn_stats: bad argument");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const long items = n_rows * (C / 8);
+  const int grid = grid_for(items);
+  SEPT_CPP_DISPATCH(C, hipLaunchKernelGGL(sept_bn_stats_partial_kernel<CPP>, dim3(grid), dim3(256), 0, st,
+                                          static_cast<const bf16*>(x), items, ws));
+  hipLaunchKernelGGL(sept_bn_stats_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, ws, grid, C,
+                     double(n_rows), mean, invstd, running_mean, running_var, num_batches_tracked, momentum, eps);
+  return sept::launch_check("sept_bn_stats");
+}
+
+extern "C" int sept_bn_eval_stats(const float* running_mean, const float* running_var, int C, float eps,
+                                  float* mean, float* invstd, void* stream) {
+  SEPT_REQUIRE(running_mean && running_var && mean && invstd && C > 0, SEPT_ERR_INVALID,
+               "sept_bn_eval_stats: bad argument");
+  hipLaunchKernelGGL(sept_bn_eval_stats_kernel, dim3((C + 63) / 64), dim3(64), 0,
+                     static_cast<hipStream_t>(stream), running_mean, running_var, C, eps, mean, invstd);
+  return sept::launch_check("sept_bn_eval_stats");
+}
+
+extern "C" int sept_bn_relu_pool_forward(const void* x, const float* mean, const float* invstd,
+                                         const float* gamma, const float* beta, const float* dropscale, void* y,
+                                         int B, int H, int W, int C, int pool, void* stream) {
+  SEPT_REQUIRE(B >= 0 && H > 0 && W > 0 && (pool == 1 || pool == 2), SEPT_ERR_INVALID,
+               "sept_bn_relu_pool_forward: B=%d H=%d W=%d pool=%d", B, H, W, pool);
+  if (B == 0) return SEPT_OK;
+  SEPT_REQUIRE(x && mean && invstd && gamma && beta && y, SEPT_ERR_INVALID,
+               "sept_bn_relu_pool_forward: null argument");
+  BnFwdArgs a{static_cast<const bf16*>(x), mean, invstd, gamma, beta, dropscale, static_cast<bf16*>(y),
+              B, H, W, C, pool};
+  const long items = long(B) * (H / pool) * (W / pool) * (C / 8);
+  const int grid = int(std::min<long>((items + 255) / 256, 4096));
+  SEPT_CPP_DISPATCH(C, hipLaunchKernelGGL(sept_bn_relu_pool_fwd_kernel<CPP>, dim3(grid), dim3(256), 0,
+                                          static_cast<hipStream_t>(stream), a));
+  return sept::launch_check("sept_bn_relu_pool_fwd_kernel");
+}
+
+extern "C" int sept_bn_relu_pool_backward(const void* dy, const void* x, const float* mean, const float* invstd,
+                                          const float* gamma, const float* beta, const float* dropscale,
+                                          float* ws, void* dx, float* dgamma, float* dbeta, int B, int H, int W,
+                                          int C, int pool, void* stream) {
+  SEPT_REQUIRE(B >= 0 && H > 0 && W > 0 && (pool == 1 || pool == 2), SEPT_ERR_INVALID,
+               "sept_bn_relu_pool_backward: B=%d H=%d W=%d pool=%d", B, H, W, pool);
+  if (B == 0) return SEPT_OK;
+  SEPT_REQUIRE(dy && x && mean && invstd && gamma && beta && ws && dx, SEPT_ERR_INVALID,
+               "sept_bn_relu_pool_backward: null argument");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  BnBwdArgs a{static_cast<const bf16*>(dy), static_cast<const bf16*>(x), mean, invstd, gamma, beta, dropscale,
+              ws, static_cast<bf16*>(dx), B, H, W, C, pool};
+  const long items = long(B) * (H / pool) * (W / pool) * (C / 8);
+  const int grid = grid_for(items);
+  SEPT_CPP_DISPATCH(C, hipLaunchKernelGGL(sept_bn_bwd_reduce_kernel<CPP>, dim3(grid), dim3(256), 0, st, a));
+  hipLaunchKernelGGL(sept_bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, ws, grid, C, dgamma, dbeta);
+  const int grid2 = int(std::min<long>((items + 255) / 256, 4096));
+  SEPT_CPP_DISPATCH(C, hipLaunchKernelGGL(sept_bn_bwd_apply_kernel<CPP>, dim3(grid2), dim3(256), 0, st, a));
+  return sept::launch_check("sept_bn_relu_pool_backward");
+}

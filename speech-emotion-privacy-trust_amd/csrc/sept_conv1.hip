@@ -1,0 +1,254 @@
+// First conv layer of the stack: Conv2d(1 -> 32, k=5, pad=2) on the (noisy) mel window.
+// Reference: model/baseline_models.py:172 (conv.0), fed by cloak_models.py:165/196.
+//
+// With one input channel this layer is bandwidth/VALU work, not a dense contraction, so it
+// does not go through MFMA: forward is an fp32 direct convolution (input is the fp32
+// feature window), the data gradient (needed because the cloak parameters sit upstream,
+// cloak_models.py:45-58) is a 25x32 dot per pixel on packed-bf16 dot2, and the weight
+// gradient is a per-tile correlation reduced deterministically through a workspace.
+// Layouts: x / dx fp32 [B][H][W];  y / dy bf16 NHWC [B][H][W][32];  w fp32 OIHW [32][1][5][5].
+#include <algorithm>
+
+#include "sept_common.h"
+
+namespace {
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+
+constexpr int kC = 32, kTaps = 25, kMT = 256;
+constexpr int kDyPS = 80;  // bytes per staged dy pixel (64 + 16 pad)
+
+__host__ __device__ constexpr int nr_max(int w) { return (kMT + w - 2) / w + 5; }
+
+struct C1Args {
+  const float* x;   // [B][H][W]
+  const float* w;   // [32][25]
+  const float* bias;
+  bf16* y;          // [B][H][W][32]
+  const bf16* dy;   // [B][H][W][32]
+  float* dx;        // [B][H][W]
+  float* ws;        // wgrad partials
+  int B, H, W;
+};
+
+// stage rows [h_first-2, h_last+2] x cols [-2, W+2) of a single-channel fp32 image
+__device__ __forceinline__ void stage_x(const float* xb, float* tile, int h_first, int NR, int H, int W) {
+  const int W4 = W + 4;
+  for (int i = threadIdx.x; i < NR * W4; i += 256) {
+    const int col = i % W4, row = i / W4;
+    const int h = h_first - 2 + row, w = col - 2;
+    tile[i] = (h >= 0 && h < H && w >= 0 && w < W) ? xb[size_t(h) * W + w] : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void sept_conv1_fwd_kernel(C1Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* wl = reinterpret_cast<float*>(smem);  // [25][32] + bias[32]
+  float* tile = wl + kTaps * kC + kC;
+  const int W = a.W, H = a.H, HW = H * W, W4 = W + 4;
+  const int b = blockIdx.y, q0 = blockIdx.x * kMT;
+  const int h_first = q0 / W, h_last = min(q0 + kMT - 1, HW - 1) / W;
+  for (int i = threadIdx.x; i < kTaps * kC; i += 256) wl[i] = a.w[(i % kC) * kTaps + i / kC];
+  if (threadIdx.x < kC) wl[kTaps * kC + threadIdx.x] = a.bias ? a.bias[threadIdx.x] : 0.f;
+  stage_x(a.x + size_t(b) * HW, tile, h_first, h_last - h_first + 5, H, W);
+  __syncthreads();
+  const int q = q0 + threadIdx.x;
+  if (q >= HW) return;
+  const int h = q / W, w = q - h * W;
+  float acc[kC];
+#pragma unroll
+  for (int c = 0; c < kC; ++c) acc[c] = wl[kTaps * kC + c];
+  const float* tp = tile + (h - h_first) * W4 + w;
+#pragma unroll
+  for (int kh = 0; kh < 5; ++kh)
+#pragma unroll
+    for (int kw = 0; kw < 5; ++kw) {
+      const float xv = tp[kh * W4 + kw];
+      const float* wr = wl + (kh * 5 + kw) * kC;
+#pragma unroll
+      for (int c = 0; c < kC; ++c) acc[c] = fmaf(xv, wr[c], acc[c]);
+    }
+  bf16* yp = a.y + (size_t(b) * HW + q) * kC;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    f32x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = acc[g * 8 + e];
+    *reinterpret_cast<bf16x8*>(yp + g * 8) = __builtin_convertvector(v, bf16x8);
+  }
+}
+
+// stage rows of dy (32 bf16 channels per pixel) with halo
+__device__ __forceinline__ void stage_dy(const bf16* dyb, unsigned char* tile, int h_first, int NR, int H, int W) {
+  const int W4 = W + 4;
+  for (int i = threadIdx.x; i < NR * W4 * 4; i += 256) {
+    const int c = i & 3, px = i >> 2;
+    const int col = px % W4, row = px / W4;
+    const int h = h_first - 2 + row, w = col - 2;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (h >= 0 && h < H && w >= 0 && w < W)
+      v = *reinterpret_cast<const uint4*>(dyb + (size_t(h) * W + w) * kC + c * 8);
+    *reinterpret_cast<uint4*>(tile + size_t(px) * kDyPS + c * 16) = v;
+  }
+}
+
+// dx[h][w] = sum_{kh,kw,c} dy[h-kh+2][w-kw+2][c] * w[c][kh][kw]   (weights rounded to bf16,
+// products accumulated in fp32 by v_dot2_f32_bf16, like the MFMA layers)
+__global__ __launch_bounds__(256) void sept_conv1_dgrad_kernel(C1Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16* wl = reinterpret_cast<bf16*>(smem);  // [25 flipped taps][32] bf16
+  unsigned char* tile = smem + kTaps * kC * 2;
+  const int W = a.W, H = a.H, HW = H * W, W4 = W + 4;
+  const int b = blockIdx.y, q0 = blockIdx.x * kMT;
+  const int h_first = q0 / W, h_last = min(q0 + kMT - 1, HW - 1) / W;
+  for (int i = threadIdx.x; i < kTaps * kC; i += 256) {
+    const int c = i % kC, t = i / kC;  // t indexes the offset (dh, dw) = (t/5, t%5); tap = flipped
+    wl[i] = (bf16)a.w[c * kTaps + (4 - t / 5) * 5 + (4 - t % 5)];
+  }
+  stage_dy(a.dy + size_t(b) * HW * kC, tile, h_first, h_last - h_first + 5, H, W);
+  __syncthreads();
+  const int q = q0 + threadIdx.x;
+  if (q >= HW) return;
+  const int h = q / W, w = q - h * W;
+  const unsigned char* tp = tile + size_t((h - h_first) * W4 + w) * kDyPS;
+  float acc = 0.f;
+#pragma unroll
+  for (int dh = 0; dh < 5; ++dh)
+#pragma unroll
+    for (int dw = 0; dw < 5; ++dw) {
+      const unsigned char* pp = tp + size_t(dh * W4 + dw) * kDyPS;
+      const uint4* wr = reinterpret_cast<const uint4*>(wl + (dh * 5 + dw) * kC);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const uint4 dv = *reinterpret_cast<const uint4*>(pp + g * 16);
+        const uint4 wv = wr[g];
+        acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, dv.x), __builtin_bit_cast(bf16x2, wv.x), acc, false);
+        acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, dv.y), __builtin_bit_cast(bf16x2, wv.y), acc, false);
+        acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, dv.z), __builtin_bit_cast(bf16x2, wv.z), acc, false);
+        acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, dv.w), __builtin_bit_cast(bf16x2, wv.w), acc, false);
+      }
+    }
+  a.dx[size_t(b) * HW + q] = acc;
+}
+
+// dW[c][tap] = sum_{b,h,w} dy[b,h,w,c] * x[b,h+kh-2,w+kw-2];  db[c] = sum dy.
+// lane = (c = tid%32, tap group tg = tid/32 owning taps tg, tg+8, tg+16, tg+24).
+constexpr int kWgParts = 1024;
+__global__ __launch_bounds__(256) void sept_conv1_wgrad_partial_kernel(C1Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int W = a.W, H = a.H, HW = H * W, W4 = W + 4;
+  float* xt = reinterpret_cast<float*>(smem);                                  // [NRmax][W4]
+  bf16* dyt = reinterpret_cast<bf16*>(smem + ((sizeof(float) * nr_max(W) * W4 + 15) & ~size_t(15)));  // [kMT][32]
+  const int c = threadIdx.x % kC, tg = threadIdx.x / kC;
+  int toff[4];
+  bool tval[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int t = tg + 8 * j;
+    tval[j] = t < kTaps;
+    toff[j] = tval[j] ? (t / 5) * W4 + (t % 5) : 0;
+  }
+  float acc[4] = {0, 0, 0, 0}, accb = 0.f;
+  const int tiles_per_img = (HW + kMT - 1) / kMT;
+  const long n_tiles = long(a.B) * tiles_per_img;
+  for (long tile_id = blockIdx.x; tile_id < n_tiles; tile_id += gridDim.x) {
+    const int b = tile_id / tiles_per_img, q0 = int(tile_id % tiles_per_img) * kMT;
+    const int h_first = q0 / W, h_last = min(q0 + kMT - 1, HW - 1) / W;
+    const int npx = min(kMT, HW - q0);
+    __syncthreads();
+    stage_x(a.x + size_t(b) * HW, xt, h_first, h_last - h_first + 5, H, W);
+    const bf16* dyb = a.dy + (size_t(b) * HW + q0) * kC;
+    for (int i = threadIdx.x; i < npx * 4; i += 256)
+      *reinterpret_cast<uint4*>(dyt + i * 8) = *reinterpret_cast<const uint4*>(dyb + size_t(i) * 8);
+    __syncthreads();
+    int h = h_first, w = q0 - h_first * W;
+    for (int p = 0; p < npx; ++p) {
+      const float d = float(dyt[p * kC + c]);
+      const float* xp = xt + (h - h_first) * W4 + w;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = fmaf(d, xp[toff[j]], acc[j]);
+      accb += d;
+      if (++w == W) {
+        w = 0;
+        ++h;
+      }
+    }
+  }
+  float* out = a.ws + size_t(blockIdx.x) * (kC * kTaps + kC);
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (tval[j]) out[c * kTaps + tg + 8 * j] = acc[j];
+  if (tg == 7) out[kC * kTaps + c] = accb;
+}
+
+__global__ void sept_conv1_wgrad_finalize_kernel(const float* ws, int nparts, float* dw, float* db) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = kC * kTaps + kC;
+  if (i >= n) return;
+  double s = 0;
+  for (int p = 0; p < nparts; ++p) s += ws[size_t(p) * n + i];
+  if (i < kC * kTaps)
+    dw[i] = float(s);
+  else if (db)
+    db[i - kC * kTaps] = float(s);
+}
+
+}  // namespace
+
+extern "C" size_t sept_conv1_workspace_floats(void) { return size_t(kWgParts) * (kC * kTaps + kC); }
+
+static int conv1_check(const char* what, int B, int H, int W) {
+  SEPT_REQUIRE(B >= 0 && H > 0 && W > 0, SEPT_ERR_INVALID, "%s: B=%d H=%d W=%d", what, B, H, W);
+  SEPT_REQUIRE(B <= 65535, SEPT_ERR_UNSUPPORTED, "%s: B=%d exceeds grid.y", what, B);
+  return SEPT_OK;
+}
+
+extern "C" int sept_conv1_forward(const float* x, const float* w, const float* bias, void* y, int B, int H,
+                                  int W, void* stream) {
+  if (int e = conv1_check("sept_conv1_forward", B, H, W)) return e;
+  if (B == 0) return SEPT_OK;
+  SEPT_REQUIRE(x && w && y, SEPT_ERR_INVALID, "sept_conv1_forward: null argument");
+  C1Args a{};
+  a.x = x; a.w = w; a.bias = bias; a.y = static_cast<bf16*>(y); a.B = B; a.H = H; a.W = W;
+  const size_t smem = sizeof(float) * (kTaps * kC + kC + size_t(nr_max(W)) * (W + 4));
+  SEPT_HIP(sept::allow_max_lds(reinterpret_cast<const void*>(&sept_conv1_fwd_kernel)));
+  hipLaunchKernelGGL(sept_conv1_fwd_kernel, dim3((H * W + kMT - 1) / kMT, B), dim3(256), smem,
+                     static_cast<hipStream_t>(stream), a);
+  return sept::launch_check("sept_conv1_fwd_kernel");
+}
+
+extern "C" int sept_conv1_backward_data(const void* dy, const float* w, float* dx, int B, int H, int W,
+                                        void* stream) {
+  if (int e = conv1_check("sept_conv1_backward_data", B, H, W)) return e;
+  if (B == 0) return SEPT_OK;
+  SEPT_REQUIRE(dy && w && dx, SEPT_ERR_INVALID, "sept_conv1_backward_data: null argument");
+  C1Args a{};
+  a.dy = static_cast<const bf16*>(dy); a.w = w; a.dx = dx; a.B = B; a.H = H; a.W = W;
+  const size_t smem = kTaps * kC * 2 + size_t(nr_max(W)) * (W + 4) * kDyPS;
+  SEPT_REQUIRE(smem <= 160 * 1024, SEPT_ERR_UNSUPPORTED, "sept_conv1_backward_data: W=%d needs %zu B of LDS", W, smem);
+  SEPT_HIP(sept::allow_max_lds(reinterpret_cast<const void*>(&sept_conv1_dgrad_kernel)));
+  hipLaunchKernelGGL(sept_conv1_dgrad_kernel, dim3((H * W + kMT - 1) / kMT, B), dim3(256), smem,
+                     static_cast<hipStream_t>(stream), a);
+  return sept::launch_check("sept_conv1_dgrad_kernel");
+}
+
+extern "C" int sept_conv1_backward_weight(const float* x, const void* dy, float* ws, float* dw, float* db, int B,
+                                          int H, int W, void* stream) {
+  if (int e = conv1_check("sept_conv1_backward_weight", B, H, W)) return e;
+  SEPT_REQUIRE(x && dy && ws && dw, SEPT_ERR_INVALID, "sept_conv1_backward_weight: null argument");
+  SEPT_REQUIRE(B > 0, SEPT_ERR_INVALID, "sept_conv1_backward_weight: empty batch");
+  C1Args a{};
+  a.x = x; a.dy = static_cast<const bf16*>(dy); a.ws = ws; a.B = B; a.H = H; a.W = W;
+  const long n_tiles = long(B) * ((H * W + kMT - 1) / kMT);
+  const int grid = int(std::min<long>(n_tiles, kWgParts));
+  const size_t smem = ((sizeof(float) * size_t(nr_max(W)) * (W + 4) + 15) & ~size_t(15)) + size_t(kMT) * kC * 2;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  SEPT_HIP(sept::allow_max_lds(reinterpret_cast<const void*>(&sept_conv1_wgrad_partial_kernel)));
+  hipLaunchKernelGGL(sept_conv1_wgrad_partial_kernel, dim3(grid), dim3(256), smem, st, a);
+  const int n = kC * kTaps + kC;
+  hipLaunchKernelGGL(sept_conv1_wgrad_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ws, grid, dw, db);
+  return sept::launch_check("sept_conv1_backward_weight");
+}

@@ -2,7 +2,7 @@
 library has not been built: the product path never falls back to CPU/eager code."""
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int, c_void_p
+from ctypes import POINTER, c_char_p, c_float, c_int, c_long, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "..", "csrc", "libsept_hip.so")
@@ -36,6 +36,17 @@ SIGNATURES = {
     "sept_conv5x5_prep_weights": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "sept_conv5x5_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                      c_void_p]),
+    "sept_conv1_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "sept_conv1_backward_data": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "sept_conv1_workspace_floats": (c_size_t, []),
+    "sept_conv1_backward_weight": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                           c_void_p]),
+    "sept_bn_workspace_floats": (c_size_t, [c_int]),
+    "sept_bn_stats": (c_int, [c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                              c_float, c_float, c_void_p]),
+    "sept_bn_eval_stats": (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "sept_bn_relu_pool_forward": (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p]),
+    "sept_bn_relu_pool_backward": (c_int, [c_void_p] * 11 + [c_int] * 5 + [c_void_p]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():
