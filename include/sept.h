@@ -84,6 +84,13 @@ int sept_conv5x5_prep_weights(const float* w_oihw, int cout, int cin, int mode, 
 int sept_conv5x5_forward(const void* x_bf16, const void* wt_bf16, const float* bias, void* y_bf16,
                          int B, int H, int W, int cin, int cout, void* stream);
 
+/* dW[cout][cin][5][5] (fp32, OIHW, overwritten) = sum over batch and pixels of dy x shifted x.
+ * bf16 MFMA with transposing LDS reads; deterministic (per-workgroup slabs in `ws`, which
+ * holds sept_conv5x5_wgrad_workspace_floats(cin, cout) floats).  32->64, 64->128, 128->128. */
+size_t sept_conv5x5_wgrad_workspace_floats(int cin, int cout);
+int sept_conv5x5_backward_weight(const void* x_bf16, const void* dy_bf16, float* ws, float* dw, int B, int H,
+                                 int W, int cin, int cout, void* stream);
+
 /* First layer Conv2d(1 -> 32, k=5, pad=2) (baseline_models.py:172): x / dx fp32 [B][H][W],
  * y / dy bf16 [B][H][W][32], w fp32 [32][1][5][5].  fp32 direct forward; packed-bf16 dot2
  * data gradient (feeds the cloak parameters, cloak_models.py:45-58); deterministic weight
@@ -117,6 +124,80 @@ int sept_bn_relu_pool_backward(const void* dy_bf16, const void* x_bf16, const fl
                                const float* gamma, const float* beta, const float* dropscale, float* ws,
                                void* dx_bf16, float* dgamma, float* dbeta, int B, int H, int W, int C, int pool,
                                void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Linear layers / GRU projections: C[M][N] = alpha * A(M,K) B(K,N) (+ bias[N]) (+ beta * C)
+ * on the exact-fp32 MFMA.  A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn] (element
+ * strides), C row-major with leading dimension ldc.  A, B and C may each be bf16.
+ * Stands behind nn.Linear (baseline_models.py:208-210) and nn.GRU's x W_ih^T
+ * (baseline_models.py:191-193) and their autograd (dx = dy W, dW = dy^T x).
+ * ------------------------------------------------------------------------------------ */
+int sept_gemm(const void* A, long sam, long sak, int a_is_bf16, const void* B, long sbk, long sbn,
+              int b_is_bf16, void* C, long ldc, int c_is_bf16, const float* bias, int M, int N, int K, float alpha, float beta,
+              void* stream);
+
+/* Recurrent part of nn.GRU(.., hidden 64, bidirectional, batch_first) -- one launch per layer
+ * for both directions and all T steps (baseline_models.py:191-193; gate order r, z, n).
+ *   gi    [B][T][2][3H]  x W_ih^T + b_ih for (forward, reverse)     (from sept_gemm)
+ *   whh_fwd / whh_rev [3H][H], bhh_fwd / bhh_rev [3H]  (weight_hh_l*, weight_hh_l*_reverse, ...)
+ *   out   [B][T][2H]     hidden states (forward | reverse), h0 = 0
+ *   gates [B][T][2][4][H] saved (r, z, n, W_hn h + b_hn) for the backward pass
+ * backward: from dout[B][T][2H] produces dgi (gradient of gi), dgh (gradient of h W_hh^T + b_hh)
+ * and hprev[B][T][2][H] (the h each step consumed) so that dW_hh = dgh^T hprev, db_hh =
+ * colsum(dgh), dW_ih = dgi^T x, db_ih = colsum(dgi), dx = dgi W_ih are plain sept_gemm /
+ * sept_colsum calls.  H must be 64. */
+int sept_gru_forward(const float* gi, const float* whh_fwd, const float* whh_rev, const float* bhh_fwd,
+                     const float* bhh_rev, float* out, float* gates, int B, int T, int H, void* stream);
+int sept_gru_backward(const float* dout, const float* out, const float* gates, const float* whh_fwd,
+                      const float* whh_rev, float* dgi, float* dgh, float* hprev, int B, int T, int H,
+                      void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * cloak_noise (model/cloak_models.py:24-58).  n_per = W*F elements of locs/rhos/eps/mask.
+ *   scales = (1 + tanh(rhos)) / 2 * (max_scale - min_scale) + min_scale          (:41-43)
+ *   forward: xn[b] = x[b] (*mask) + locs + scales * eps (*mask)                   (:45-58)
+ *   backward: g = dxa + gscale_b * dxb  (dxb nullable; the second branch's input gradient goes
+ *     through GradientReversal, gscale_b = -grl_lambda, reversal_gradient.py:18-23);
+ *     dlocs = sum_b g;  drhos = sum_b g * eps (*mask) * dscales/drhos
+ *             - scale_lambda * d/drhos log(mean(scales))   (training_cloak_with_grl.py:158-160)
+ * sept_cloak_scales writes scales[n] and/or their mean (device scalar). */
+int sept_cloak_forward(const float* x, const float* locs, const float* rhos, const float* eps, const float* mask,
+                       float min_scale, float max_scale, float* xn, int B, long n_per, void* stream);
+int sept_cloak_scales(const float* rhos, float min_scale, float max_scale, float* scales, float* mean_out, long n,
+                      void* stream);
+int sept_cloak_backward(const float* dxa, const float* dxb, float gscale_b, const float* rhos, const float* eps,
+                        const float* mask, float min_scale, float max_scale, float scale_lambda,
+                        const float* scale_mean, float* dlocs, float* drhos, int B, long n_per, void* stream);
+
+/* y = a * x  (GradientReversalFunction.backward with a = -lambda, reversal_gradient.py:18-23) */
+int sept_scale(const float* x, float a, float* y, long n, void* stream);
+/* y = x * m  (GRU inter-layer dropout with a pre-scaled mask) */
+int sept_mul(const float* x, const float* m, float* y, long n, void* stream);
+/* y = relu(x) * dropscale (nullable)  -- dense_relu1 + dropout, baseline_models.py:248-249 */
+int sept_relu_dropout_forward(const float* x, const float* dropscale, float* y, long n, void* stream);
+int sept_relu_dropout_backward(const float* dy, const float* x, const float* dropscale, float* dx, long n,
+                               void* stream);
+/* z[B][D] = mean over T of x[B][T][D]  (torch.mean(x, dim=1), baseline_models.py:232) */
+int sept_mean_t_forward(const float* x, float* z, int B, int T, int D, void* stream);
+int sept_mean_t_backward(const float* dz, float* dx, int B, int T, int D, void* stream);
+/* out[N] (+)= column sums of a[M][lda]  (bias gradients) */
+int sept_colsum(const float* a, long lda, int M, int N, float* out, int accumulate, void* stream);
+/* loss (+)= scale * sum_i w_i CE(logits_i, labels_i);  dlogits = scale * w_i * (softmax - onehot)
+ * (the per-sample loop of train(), training_cloak_with_grl.py:143-154; weights nullable) */
+int sept_cross_entropy(const float* logits, const long long* labels, const float* weights, float scale, int B,
+                       int C, float* loss, float* dlogits, int accumulate, void* stream);
+/* loss -= lambda * log(*mean)  (training_cloak_with_grl.py:158-160) */
+int sept_loss_sub_log(float* loss, const float* mean, float lambda, void* stream);
+/* dst[n][w*C + c] = src[n][c*Wd + w] (inverse != 0: the other way): GRU weight_ih_l0 between
+ * the reference's (c, w) feature order (cloak_models.py:166-168) and the NHWC (w, c) order */
+int sept_permute_cols(const float* src, float* dst, int N, int C, int Wd, int inverse, void* stream);
+/* torch.optim.SGD(momentum, weight_decay) / torch.optim.Adam(betas, eps, weight_decay) on a flat
+ * parameter buffer (training_cloak_with_grl.py:416-421); grad_scale multiplies g first (1/world
+ * for averaged data-parallel gradients).  Adam `step` counts from 1. */
+int sept_sgd_step(float* p, const float* g, float* momentum_buf, long n, float lr, float momentum,
+                  float weight_decay, int first_step, float grad_scale, void* stream);
+int sept_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, int step, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

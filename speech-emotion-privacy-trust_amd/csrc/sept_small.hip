@@ -1,0 +1,323 @@
+// Small HBM-bound kernels of the training step for gfx950: the cloak noise layer, gradient
+// reversal, temporal mean, ReLU+Dropout, the weighted cross-entropy of train(), column sums
+// for bias gradients, the GRU weight column permutation, and the SGD / Adam updates.
+// Reference lines are cited per entry point in include/sept.h.  Reductions are fixed-order
+// (no float atomics), so a step is bit-reproducible.
+#include <algorithm>
+#include <cmath>
+
+#include "sept_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+inline int blocks_for(long n, int cap = 4096) { return int(std::min<long>((n + kThreads - 1) / kThreads, cap)); }
+
+#define GRID_STRIDE(i, n) for (long i = long(blockIdx.x) * blockDim.x + threadIdx.x; i < (n); i += long(gridDim.x) * blockDim.x)
+
+// ---------------- cloak_noise (cloak_models.py:41-58) ----------------
+__device__ __forceinline__ float cloak_scale(float rho, float smin, float smax) {
+  return (1.0f + tanhf(rho)) * 0.5f * (smax - smin) + smin;
+}
+
+// xn[b][i] = x[b][i] (*mask[i]) + locs[i] + scales(rhos[i]) * eps[i] (*mask[i])
+__global__ void cloak_fwd_kernel(const float* x, const float* locs, const float* rhos, const float* eps,
+                                 const float* mask, float smin, float smax, float* xn, long n_per, long total) {
+  GRID_STRIDE(i, total) {
+    const long k = i % n_per;
+    const float m = mask ? mask[k] : 1.0f;
+    xn[i] = x[i] * m + locs[k] + cloak_scale(rhos[k], smin, smax) * (eps[k] * m);
+  }
+}
+
+__global__ void cloak_scales_kernel(const float* rhos, float smin, float smax, float* scales, long n) {
+  GRID_STRIDE(i, n) scales[i] = cloak_scale(rhos[i], smin, smax);
+}
+
+// single-block fixed-order mean of scales(rhos)
+__global__ void cloak_scale_mean_kernel(const float* rhos, float smin, float smax, long n, float* mean_out) {
+  __shared__ double red[kThreads];
+  double s = 0;
+  for (long i = threadIdx.x; i < n; i += kThreads) s += cloak_scale(rhos[i], smin, smax);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = kThreads / 2; w > 0; w >>= 1) {
+    if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *mean_out = float(red[0] / double(n));
+}
+
+// dlocs[k] = sum_b g[b][k];  drhos[k] = (sum_b g[b][k]) * eps[k]*mask[k] * dscale/drho
+//            - scale_lambda * dscale/drho / (n * mean(scales))      [d/drho of -lambda*log(mean(scales))]
+// with g = dxa + gscale_b * dxb (dxb optional): the two branches' input gradients, the second
+// one through the gradient-reversal layer (gscale_b = -grl_lambda).
+__global__ void cloak_bwd_kernel(const float* dxa, const float* dxb, float gscale_b, const float* rhos,
+                                 const float* eps, const float* mask, float smin, float smax, float scale_lambda,
+                                 const float* scale_mean, int B, long n_per, float* dlocs, float* drhos) {
+  GRID_STRIDE(k, n_per) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) {
+      float g = dxa[size_t(b) * n_per + k];
+      if (dxb) g = fmaf(gscale_b, dxb[size_t(b) * n_per + k], g);
+      s += g;
+    }
+    const float th = tanhf(rhos[k]);
+    const float dsc = (1.0f - th * th) * 0.5f * (smax - smin);
+    const float m = mask ? mask[k] : 1.0f;
+    float dr = s * eps[k] * m * dsc;
+    if (scale_lambda != 0.f) dr -= scale_lambda * dsc / (float(n_per) * *scale_mean);
+    if (dlocs) dlocs[k] = s;
+    if (drhos) drhos[k] = dr;
+  }
+}
+
+// ---------------- generic elementwise ----------------
+__global__ void scale_kernel(const float* x, float a, float* y, long n) { GRID_STRIDE(i, n) y[i] = a * x[i]; }
+
+__global__ void mul_kernel(const float* x, const float* m, float* y, long n) { GRID_STRIDE(i, n) y[i] = x[i] * m[i]; }
+
+// y = relu(x) * dropscale
+__global__ void relu_drop_fwd_kernel(const float* x, const float* m, float* y, long n) {
+  GRID_STRIDE(i, n) y[i] = fmaxf(x[i], 0.f) * (m ? m[i] : 1.0f);
+}
+__global__ void relu_drop_bwd_kernel(const float* dy, const float* x, const float* m, float* dx, long n) {
+  GRID_STRIDE(i, n) dx[i] = x[i] > 0.f ? dy[i] * (m ? m[i] : 1.0f) : 0.f;
+}
+
+// z[b][d] = mean_t x[b][t][d]
+__global__ void mean_t_fwd_kernel(const float* x, float* z, int B, int T, int D) {
+  GRID_STRIDE(i, long(B) * D) {
+    const int d = i % D;
+    const long b = i / D;
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += x[(b * T + t) * D + d];
+    z[i] = s / float(T);
+  }
+}
+__global__ void mean_t_bwd_kernel(const float* dz, float* dx, int B, int T, int D) {
+  GRID_STRIDE(i, long(B) * T * D) {
+    const int d = i % D;
+    const long b = i / (long(T) * D);
+    dx[i] = dz[b * D + d] / float(T);
+  }
+}
+
+// out[n] (+)= sum_m a[m][n]   (one thread per column; rows are few thousand at most)
+__global__ void colsum_kernel(const float* a, long lda, int M, int N, float* out, int accumulate) {
+  GRID_STRIDE(n, N) {
+    float s = 0.f;
+    for (int m = 0; m < M; ++m) s += a[size_t(m) * lda + n];
+    out[n] = accumulate ? out[n] + s : s;
+  }
+}
+
+// ---------------- weighted cross-entropy (training_cloak_with_grl.py:143-154) ----------------
+// loss += scale * sum_i w_i * CE(logits_i, label_i);  dlogits_i = scale * w_i * (softmax_i - onehot)
+__global__ void ce_kernel(const float* logits, const long long* labels, const float* w, float scale, int B, int C,
+                          float* loss, float* dlogits, int accumulate) {
+  __shared__ double red[kThreads];
+  double s = 0;
+  for (int i = threadIdx.x; i < B; i += kThreads) {
+    const float* l = logits + size_t(i) * C;
+    float mx = l[0];
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, l[c]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(l[c] - mx);
+    const float lse = mx + logf(se);
+    const int y = int(labels[i]);
+    const float wi = w ? w[i] : 1.0f;
+    s += double(wi) * double(lse - l[y]);
+    if (dlogits)
+      for (int c = 0; c < C; ++c)
+        dlogits[size_t(i) * C + c] = scale * wi * (expf(l[c] - lse) - (c == y ? 1.0f : 0.0f));
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = kThreads / 2; k > 0; k >>= 1) {
+    if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float v = scale * float(red[0]);
+    *loss = accumulate ? *loss + v : v;
+  }
+}
+
+// loss -= lambda * log(mean)    (training_cloak_with_grl.py:158-160)
+__global__ void loss_sub_log_kernel(float* loss, const float* mean, float lambda) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *loss -= lambda * logf(*mean);
+}
+
+// ---------------- GRU weight_ih_l0 column permutation ----------------
+// reference feature order of the GRU input is (c, w) (transpose(1,2) of NCHW, cloak_models.py:166-168);
+// the NHWC activations deliver (w, c).  dst[n][w*C + c] = src[n][c*Wd + w]  (inverse when inv != 0)
+__global__ void permute_cols_kernel(const float* src, float* dst, int N, int C, int Wd, int inv) {
+  GRID_STRIDE(i, long(N) * C * Wd) {
+    const long n = i / (long(C) * Wd);
+    const int r = i % (C * Wd);
+    if (!inv) {
+      const int w = r / C, c = r % C;
+      dst[i] = src[n * C * Wd + c * Wd + w];
+    } else {
+      const int c = r / Wd, w = r % Wd;
+      dst[i] = src[n * C * Wd + w * C + c];
+    }
+  }
+}
+
+// ---------------- optimisers (training_cloak_with_grl.py:416-421) ----------------
+// torch.optim.SGD(momentum, weight_decay, dampening 0, nesterov False)
+__global__ void sgd_kernel(float* p, const float* g, float* buf, long n, float lr, float momentum, float wd,
+                           int first_step, float gscale) {
+  GRID_STRIDE(i, n) {
+    float d = g[i] * gscale + wd * p[i];
+    if (momentum != 0.f) {
+      const float b = first_step ? d : momentum * buf[i] + d;
+      buf[i] = b;
+      d = b;
+    }
+    p[i] -= lr * d;
+  }
+}
+// torch.optim.Adam (L2 weight decay folded into the gradient, amsgrad False)
+__global__ void adam_kernel(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
+                            float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+  GRID_STRIDE(i, n) {
+    const float d = g[i] * gscale + wd * p[i];
+    const float mi = b1 * m[i] + (1.f - b1) * d;
+    const float vi = b2 * v[i] + (1.f - b2) * d * d;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+  }
+}
+
+}  // namespace
+
+#define ST(s) static_cast<hipStream_t>(s)
+
+extern "C" int sept_cloak_forward(const float* x, const float* locs, const float* rhos, const float* eps,
+                                  const float* mask, float min_scale, float max_scale, float* xn, int B, long n_per,
+                                  void* stream) {
+  SEPT_REQUIRE(B >= 0 && n_per > 0, SEPT_ERR_INVALID, "sept_cloak_forward: B=%d n=%ld", B, n_per);
+  if (B == 0) return SEPT_OK;
+  SEPT_REQUIRE(x && locs && rhos && eps && xn, SEPT_ERR_INVALID, "sept_cloak_forward: null argument");
+  const long total = long(B) * n_per;
+  hipLaunchKernelGGL(cloak_fwd_kernel, dim3(blocks_for(total)), dim3(kThreads), 0, ST(stream), x, locs, rhos, eps,
+                     mask, min_scale, max_scale, xn, n_per, total);
+  return sept::launch_check("cloak_fwd_kernel");
+}
+
+extern "C" int sept_cloak_scales(const float* rhos, float min_scale, float max_scale, float* scales,
+                                 float* mean_out, long n, void* stream) {
+  SEPT_REQUIRE(rhos && n > 0 && (scales || mean_out), SEPT_ERR_INVALID, "sept_cloak_scales: bad argument");
+  if (scales)
+    hipLaunchKernelGGL(cloak_scales_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, ST(stream), rhos, min_scale,
+                       max_scale, scales, n);
+  if (mean_out)
+    hipLaunchKernelGGL(cloak_scale_mean_kernel, dim3(1), dim3(kThreads), 0, ST(stream), rhos, min_scale, max_scale, n,
+                       mean_out);
+  return sept::launch_check("cloak_scales_kernel");
+}
+
+extern "C" int sept_cloak_backward(const float* dxa, const float* dxb, float gscale_b, const float* rhos,
+                                   const float* eps, const float* mask, float min_scale, float max_scale,
+                                   float scale_lambda, const float* scale_mean, float* dlocs, float* drhos, int B,
+                                   long n_per, void* stream) {
+  SEPT_REQUIRE(dxa && rhos && eps && B > 0 && n_per > 0, SEPT_ERR_INVALID, "sept_cloak_backward: bad argument");
+  SEPT_REQUIRE(scale_lambda == 0.f || scale_mean, SEPT_ERR_INVALID, "sept_cloak_backward: scale_mean required");
+  hipLaunchKernelGGL(cloak_bwd_kernel, dim3(blocks_for(n_per)), dim3(kThreads), 0, ST(stream), dxa, dxb, gscale_b,
+                     rhos, eps, mask, min_scale, max_scale, scale_lambda, scale_mean, B, n_per, dlocs, drhos);
+  return sept::launch_check("cloak_bwd_kernel");
+}
+
+extern "C" int sept_scale(const float* x, float a, float* y, long n, void* stream) {
+  if (n == 0) return SEPT_OK;
+  SEPT_REQUIRE(x && y && n > 0, SEPT_ERR_INVALID, "sept_scale: bad argument");
+  hipLaunchKernelGGL(scale_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, ST(stream), x, a, y, n);
+  return sept::launch_check("scale_kernel");
+}
+
+extern "C" int sept_mul(const float* x, const float* m, float* y, long n, void* stream) {
+  if (n == 0) return SEPT_OK;
+  SEPT_REQUIRE(x && m && y && n > 0, SEPT_ERR_INVALID, "sept_mul: bad argument");
+  hipLaunchKernelGGL(mul_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, ST(stream), x, m, y, n);
+  return sept::launch_check("mul_kernel");
+}
+
+extern "C" int sept_relu_dropout_forward(const float* x, const float* dropscale, float* y, long n, void* stream) {
+  if (n == 0) return SEPT_OK;
+  SEPT_REQUIRE(x && y && n > 0, SEPT_ERR_INVALID, "sept_relu_dropout_forward: bad argument");
+  hipLaunchKernelGGL(relu_drop_fwd_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, ST(stream), x, dropscale, y, n);
+  return sept::launch_check("relu_drop_fwd_kernel");
+}
+
+extern "C" int sept_relu_dropout_backward(const float* dy, const float* x, const float* dropscale, float* dx, long n,
+                                          void* stream) {
+  if (n == 0) return SEPT_OK;
+  SEPT_REQUIRE(dy && x && dx && n > 0, SEPT_ERR_INVALID, "sept_relu_dropout_backward: bad argument");
+  hipLaunchKernelGGL(relu_drop_bwd_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, ST(stream), dy, x, dropscale, dx, n);
+  return sept::launch_check("relu_drop_bwd_kernel");
+}
+
+extern "C" int sept_mean_t_forward(const float* x, float* z, int B, int T, int D, void* stream) {
+  if (B == 0) return SEPT_OK;
+  SEPT_REQUIRE(x && z && B > 0 && T > 0 && D > 0, SEPT_ERR_INVALID, "sept_mean_t_forward: bad argument");
+  hipLaunchKernelGGL(mean_t_fwd_kernel, dim3(blocks_for(long(B) * D)), dim3(kThreads), 0, ST(stream), x, z, B, T, D);
+  return sept::launch_check("mean_t_fwd_kernel");
+}
+
+extern "C" int sept_mean_t_backward(const float* dz, float* dx, int B, int T, int D, void* stream) {
+  if (B == 0) return SEPT_OK;
+  SEPT_REQUIRE(dz && dx && B > 0 && T > 0 && D > 0, SEPT_ERR_INVALID, "sept_mean_t_backward: bad argument");
+  hipLaunchKernelGGL(mean_t_bwd_kernel, dim3(blocks_for(long(B) * T * D)), dim3(kThreads), 0, ST(stream), dz, dx, B, T, D);
+  return sept::launch_check("mean_t_bwd_kernel");
+}
+
+extern "C" int sept_colsum(const float* a, long lda, int M, int N, float* out, int accumulate, void* stream) {
+  SEPT_REQUIRE(a && out && M >= 0 && N > 0, SEPT_ERR_INVALID, "sept_colsum: bad argument");
+  hipLaunchKernelGGL(colsum_kernel, dim3(blocks_for(N)), dim3(kThreads), 0, ST(stream), a, lda, M, N, out, accumulate);
+  return sept::launch_check("colsum_kernel");
+}
+
+extern "C" int sept_cross_entropy(const float* logits, const long long* labels, const float* weights, float scale,
+                                  int B, int C, float* loss, float* dlogits, int accumulate, void* stream) {
+  SEPT_REQUIRE(logits && labels && loss && B > 0 && C > 0, SEPT_ERR_INVALID, "sept_cross_entropy: bad argument");
+  hipLaunchKernelGGL(ce_kernel, dim3(1), dim3(kThreads), 0, ST(stream), logits, labels, weights, scale, B, C, loss,
+                     dlogits, accumulate);
+  return sept::launch_check("ce_kernel");
+}
+
+extern "C" int sept_loss_sub_log(float* loss, const float* mean, float lambda, void* stream) {
+  SEPT_REQUIRE(loss && mean, SEPT_ERR_INVALID, "sept_loss_sub_log: null argument");
+  hipLaunchKernelGGL(loss_sub_log_kernel, dim3(1), dim3(64), 0, ST(stream), loss, mean, lambda);
+  return sept::launch_check("loss_sub_log_kernel");
+}
+
+extern "C" int sept_permute_cols(const float* src, float* dst, int N, int C, int Wd, int inverse, void* stream) {
+  SEPT_REQUIRE(src && dst && N > 0 && C > 0 && Wd > 0, SEPT_ERR_INVALID, "sept_permute_cols: bad argument");
+  hipLaunchKernelGGL(permute_cols_kernel, dim3(blocks_for(long(N) * C * Wd)), dim3(kThreads), 0, ST(stream), src, dst,
+                     N, C, Wd, inverse);
+  return sept::launch_check("permute_cols_kernel");
+}
+
+extern "C" int sept_sgd_step(float* p, const float* g, float* momentum_buf, long n, float lr, float momentum,
+                             float weight_decay, int first_step, float grad_scale, void* stream) {
+  if (n == 0) return SEPT_OK;
+  SEPT_REQUIRE(p && g && n > 0 && (momentum == 0.f || momentum_buf), SEPT_ERR_INVALID, "sept_sgd_step: bad argument");
+  hipLaunchKernelGGL(sgd_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, ST(stream), p, g, momentum_buf, n, lr,
+                     momentum, weight_decay, first_step, grad_scale);
+  return sept::launch_check("sgd_kernel");
+}
+
+extern "C" int sept_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
+                              float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream) {
+  if (n == 0) return SEPT_OK;
+  SEPT_REQUIRE(p && g && m && v && n > 0 && step >= 1, SEPT_ERR_INVALID, "sept_adam_step: bad argument");
+  const float bc1 = 1.0f - std::pow(beta1, float(step));
+  const float bc2_sqrt = std::sqrt(1.0f - std::pow(beta2, float(step)));
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, ST(stream), p, g, m, v, n, lr, beta1, beta2,
+                     eps, weight_decay, bc1, bc2_sqrt, grad_scale);
+  return sept::launch_check("adam_kernel");
+}

@@ -1,0 +1,166 @@
+"""Drop-in for the reference's model/baseline_models.py classifier classes.
+
+Same class names, constructor signatures, attribute names and state-dict keys as the
+reference (two_d_cnn_lstm :143-260, deep_two_d_cnn_lstm :264-385, one_d_cnn_lstm :19-140),
+so checkpoints and the cloak wrappers interoperate; `forward` runs the hand-written HIP
+kernels of libsept_hip (NHWC bf16 MFMA convs, fused BatchNorm/ReLU/pool/dropout, HIP GRU).
+The torch sub-modules held here (`conv`, `rnn`, `dense1`, ...) are parameter containers:
+their own forward is never called and there is no eager/CPU fallback.
+
+Scope: att=None, rnn_cell='gru', hidden 64, global_feature concat
+not supported on the HIP path; `one_d_cnn_lstm` keeps its constructor/state-dict surface but
+its forward is not implemented yet (it raises).
+"""
+try:
+    from . import _paths  # noqa: F401
+except ImportError:
+    import _paths  # noqa: F401
+
+import torch
+import torch.nn as nn
+
+from sept_amd import functional as SF
+
+
+def _rnn_cls(name):
+    name = name.lower()
+    if name == "gru":
+        return nn.GRU
+    if name == "lstm":
+        return nn.LSTM
+    raise ValueError("Unsupported RNN Cell: {0}".format(name))
+
+
+def _block(cin, cout, p, pool):
+    mods = [nn.Conv2d(cin, cout, kernel_size=5, padding=2), nn.BatchNorm2d(cout), nn.ReLU()]
+    if pool:
+        mods.append(nn.MaxPool2d(kernel_size=(2, 2), stride=(2, 2)))
+    mods.append(nn.Dropout2d(p))
+    return mods
+
+
+class _TwoD(nn.Module):
+    _deep = False
+
+    def __init__(self, input_channel, input_spec_size, cnn_filter_size, lstm_hidden_size=128, num_layers_lstm=2,
+                 pred='emotion', bidirectional=True, rnn_cell='gru', attention_size=256, variable_lengths=False,
+                 global_feature=1, att=None):
+        super().__init__()
+        self.input_channel = input_channel
+        self.input_spec_size = input_spec_size
+        self.lstm_hidden_size = lstm_hidden_size
+        self.bidirectional = bidirectional
+        self.num_layers_lstm = num_layers_lstm
+        self.dropout_p = 0.2
+        self.variable_lengths = variable_lengths
+        self.num_emo_classes = 4
+        self.num_gender_class = 2
+        self.cnn_filter_size = cnn_filter_size
+        self.attention_size = attention_size
+        self.pred = pred
+        self.att = att
+        self.rnn_input_size = int(128 * input_spec_size / 8)
+        self.rnn_cell = _rnn_cls(rnn_cell)
+
+        p = self.dropout_p
+        self.dropout = nn.Dropout(p=p)
+        mods = _block(1, 32, p, True) + _block(32, 64, p, True) + _block(64, 128, p, True)
+        if self._deep:
+            mods += _block(128, 128, p, False)
+        self.conv = nn.Sequential(*mods)
+        self.rnn = self.rnn_cell(input_size=self.rnn_input_size, hidden_size=lstm_hidden_size,
+                                 num_layers=num_layers_lstm, batch_first=True, dropout=p,
+                                 bidirectional=bidirectional)
+        d_att, n_att = attention_size, 16
+        self.att_linear1 = nn.Linear(lstm_hidden_size * 2, d_att, bias=False)
+        self.att_pool = nn.Tanh()
+        self.att_linear2 = nn.Linear(d_att, n_att, bias=False)
+        self.att_mat1 = nn.Parameter(torch.rand(d_att, lstm_hidden_size * 2), requires_grad=True)
+        self.att_mat2 = nn.Parameter(torch.rand(n_att, d_att), requires_grad=True)
+        self.dense_relu1 = nn.ReLU()
+        self.dense_relu2 = nn.ReLU()
+        self.dense2 = nn.Linear(128, 64)
+        flat = 25 if self._deep else 1
+        self.dense1 = nn.Linear(lstm_hidden_size * 2 + 88, 128) if global_feature == 1 \
+            else nn.Linear(lstm_hidden_size * 2 * flat, 128)
+        self.pred_emotion_layer = nn.Linear(128, self.num_emo_classes)
+        self.pred_gender_layer = nn.Linear(128, self.num_gender_class)
+        self.init_weight()
+
+    def init_weight(self):
+        # The reference's init_weight() (baseline_models.py:213-220) loops over the *names* in
+        # self._modules, so no layer ever matches and default torch init is what checkpoints
+        # carry.  Kept as a no-op for the same effect.
+        return None
+
+    def hip_logits(self, x, head, pooling, injected=None):
+        """Run the HIP trunk on x (B, 1, T, F) / (B, T, F) and apply `head`'s prediction layer."""
+        x = x.float()
+        if x.dim() == 4:
+            if x.shape[1] != 1:
+                raise ValueError("the conv stack takes one input channel")
+            x = x[:, 0]
+        return SF.run_trunk(self, x, head, pooling, injected)
+
+    def forward(self, input_var, global_feature=None):
+        if global_feature is not None:
+            raise NotImplementedError("global_feature concat (openSMILE functionals) is outside the HIP path")
+        pooling = "flatten" if self._deep else "mean"
+        if self.pred == 'multitask':
+            raise NotImplementedError("pred='multitask' is not used by any trainer and is not on the HIP path")
+        return self.hip_logits(input_var, 'emotion' if self.pred == 'emotion' else 'gender', pooling)
+
+
+class two_d_cnn_lstm(_TwoD):
+    _deep = False
+
+
+class deep_two_d_cnn_lstm(_TwoD):
+    _deep = True
+
+
+class one_d_cnn_lstm(nn.Module):
+    """Constructor / attribute / state-dict surface of baseline_models.py:19-99.  The forward
+    (a Conv1d stack, used only by the baseline trainer) has no HIP kernels yet."""
+
+    def __init__(self, input_channel, input_spec_size, cnn_filter_size, lstm_hidden_size=128, num_layers_lstm=2,
+                 pred='emotion', bidirectional=True, rnn_cell='gru', attention_size=256, variable_lengths=False,
+                 global_feature=1, att=None):
+        super().__init__()
+        self.input_channel, self.input_spec_size = input_channel, input_spec_size
+        self.lstm_hidden_size, self.bidirectional = lstm_hidden_size, bidirectional
+        self.num_layers_lstm, self.dropout_p = num_layers_lstm, 0.2
+        self.variable_lengths = variable_lengths
+        self.num_emo_classes, self.num_gender_class = 4, 2
+        self.cnn_filter_size, self.rnn_input_size = cnn_filter_size, 512
+        self.attention_size, self.pred, self.att = attention_size, pred, att
+        self.rnn_cell = _rnn_cls(rnn_cell)
+        p = self.dropout_p
+        self.dropout = nn.Dropout(p=p)
+        self.conv = nn.Sequential(
+            nn.Conv1d(input_spec_size, 128, kernel_size=5, padding=2), nn.ReLU(),
+            nn.MaxPool1d(kernel_size=2, stride=2), nn.Dropout(p),
+            nn.Conv1d(128, 256, kernel_size=5, padding=2), nn.ReLU(),
+            nn.MaxPool1d(kernel_size=5, stride=5), nn.Dropout(p),
+            nn.Conv1d(256, 512, kernel_size=5, padding=2), nn.ReLU(),
+            nn.MaxPool1d(kernel_size=5, stride=5), nn.Dropout(p))
+        self.rnn = self.rnn_cell(input_size=512, hidden_size=lstm_hidden_size, num_layers=num_layers_lstm,
+                                 batch_first=True, dropout=p, bidirectional=bidirectional)
+        d_att, n_att = attention_size, 8
+        self.att_linear1 = nn.Linear(lstm_hidden_size * 2, d_att)
+        self.att_pool = nn.Tanh()
+        self.att_linear2 = nn.Linear(d_att, n_att)
+        self.att_mat1 = nn.Parameter(torch.rand(d_att, lstm_hidden_size * 2), requires_grad=True)
+        self.att_mat2 = nn.Parameter(torch.rand(n_att, d_att), requires_grad=True)
+        self.dense_relu1, self.dense_relu2 = nn.ReLU(), nn.ReLU()
+        self.classifier = nn.Sequential(nn.Linear(512 * 4, 128), nn.ReLU(), nn.Dropout(p))
+        self.dense2 = nn.Linear(128, 64)
+        self.dense1 = nn.Linear(lstm_hidden_size * 2 + 88, 128) if global_feature == 1 else nn.Linear(512 * 4, 128)
+        self.pred_emotion_layer = nn.Linear(128, self.num_emo_classes)
+        self.pred_gender_layer = nn.Linear(128, self.num_gender_class)
+
+    def init_weight(self):
+        return None
+
+    def forward(self, input_var, global_feature=None):
+        raise NotImplementedError("one_d_cnn_lstm.forward: Conv1d stack has no HIP kernels yet (SURVEY.md a8)")

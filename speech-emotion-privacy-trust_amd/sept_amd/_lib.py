@@ -36,6 +36,9 @@ SIGNATURES = {
     "sept_conv5x5_prep_weights": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "sept_conv5x5_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                      c_void_p]),
+    "sept_conv5x5_wgrad_workspace_floats": (c_size_t, [c_int, c_int]),
+    "sept_conv5x5_backward_weight": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                             c_void_p]),
     "sept_conv1_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "sept_conv1_backward_data": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "sept_conv1_workspace_floats": (c_size_t, []),
@@ -47,6 +50,29 @@ SIGNATURES = {
     "sept_bn_eval_stats": (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "sept_bn_relu_pool_forward": (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p]),
     "sept_bn_relu_pool_backward": (c_int, [c_void_p] * 11 + [c_int] * 5 + [c_void_p]),
+    "sept_gemm": (c_int, [c_void_p, c_long, c_long, c_int, c_void_p, c_long, c_long, c_int, c_void_p, c_long, c_int,
+                          c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p]),
+    "sept_gru_forward": (c_int, [c_void_p] * 7 + [c_int] * 3 + [c_void_p]),
+    "sept_gru_backward": (c_int, [c_void_p] * 8 + [c_int] * 3 + [c_void_p]),
+    "sept_cloak_forward": (c_int, [c_void_p] * 5 + [c_float, c_float, c_void_p, c_int, c_long, c_void_p]),
+    "sept_cloak_scales": (c_int, [c_void_p, c_float, c_float, c_void_p, c_void_p, c_long, c_void_p]),
+    "sept_cloak_backward": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_float, c_float,
+                                    c_float, c_void_p, c_void_p, c_void_p, c_int, c_long, c_void_p]),
+    "sept_scale": (c_int, [c_void_p, c_float, c_void_p, c_long, c_void_p]),
+    "sept_mul": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
+    "sept_relu_dropout_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
+    "sept_relu_dropout_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
+    "sept_mean_t_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "sept_mean_t_backward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "sept_colsum": (c_int, [c_void_p, c_long, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "sept_cross_entropy": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_void_p, c_int,
+                                   c_void_p]),
+    "sept_loss_sub_log": (c_int, [c_void_p, c_void_p, c_float, c_void_p]),
+    "sept_permute_cols": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "sept_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float, c_int, c_float,
+                              c_void_p]),
+    "sept_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float, c_float,
+                               c_float, c_int, c_float, c_void_p]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

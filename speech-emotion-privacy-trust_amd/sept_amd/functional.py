@@ -1,0 +1,377 @@
+"""The model half of the hot path as compositions of libsept_hip kernels.
+
+`trunk_forward` / `trunk_backward` run one two_d_cnn_lstm-style network (conv stack ->
+bi-GRU -> pooling -> dense1 -> head; reference model/baseline_models.py:222-260 and the
+re-statements of it inside the cloak wrappers, model/cloak_models.py:165-224) on NHWC bf16
+activations; the autograd Functions below glue them into torch's autograd graph so the
+product modules (model/*.py) keep the reference's call surface.  Nothing here computes on the
+CPU or through eager torch math: torch supplies storage, views, RNG draws and the autograd
+tape only.
+"""
+from types import SimpleNamespace
+
+import torch
+
+from . import ops
+from ._lib import SeptError, require_cuda
+
+DROP_P = 0.2  # every Dropout / Dropout2d / GRU dropout in the reference uses 0.2 (baseline_models.py:153)
+
+# ---------------------------------------------------------------------------------------------
+# derived-operand cache (bf16 conv operands, permuted GRU weights).  Keyed on storage + version;
+# the HIP optimiser updates parameters through raw pointers, so it bumps EPOCH explicitly.
+# ---------------------------------------------------------------------------------------------
+_EPOCH = [0]
+
+
+def invalidate_weight_cache():
+    _EPOCH[0] += 1
+
+
+def _cached(tag, t, fn):
+    """Derived operand of parameter `t`, stored ON the parameter object (so it can never be
+    served to another tensor that happens to reuse the address) and refreshed whenever torch
+    bumps the tensor version or the HIP optimiser bumps the epoch."""
+    store = t.__dict__.setdefault("_sept_derived", {})
+    stamp = (t.data_ptr(), t._version, _EPOCH[0])
+    hit = store.get(tag)
+    if hit is None or hit[0] != stamp:
+        hit = store[tag] = (stamp, fn())
+    return hit[1]
+
+
+# ---------------------------------------------------------------------------------------------
+# parameter view of a two_d_cnn_lstm / deep_two_d_cnn_lstm module
+# ---------------------------------------------------------------------------------------------
+def trunk_params(model, head: str):
+    """Collect the tensors the HIP trunk reads from a (reference-layout) module.  `head` is
+    'emotion' or 'gender' (which prediction layer the caller applies)."""
+    conv = model.conv
+    if len(conv) == 2 and not isinstance(conv[0], torch.nn.Conv2d):  # Sequential(GradientReversal, conv)
+        conv = conv[1]
+    convs = [m for m in conv if isinstance(m, torch.nn.Conv2d)]
+    bns = [m for m in conv if isinstance(m, torch.nn.BatchNorm2d)]
+    pools, drop_ps = [], []
+    mods = list(conv)
+    for i, m in enumerate(mods):
+        if isinstance(m, torch.nn.Conv2d):
+            nxt = []
+            for n in mods[i + 1:]:
+                if isinstance(n, torch.nn.Conv2d):
+                    break
+                nxt.append(n)
+            pools.append(2 if any(isinstance(n, torch.nn.MaxPool2d) for n in nxt) else 1)
+            dps = [n.p for n in nxt if isinstance(n, torch.nn.Dropout2d)]
+            drop_ps.append(dps[0] if dps else 0.0)
+    rnn = model.rnn
+    if not isinstance(rnn, torch.nn.GRU):
+        raise NotImplementedError("only rnn_cell='gru' is implemented on the HIP path")
+    if rnn.hidden_size != 64 or rnn.num_layers != 2 or not rnn.bidirectional:
+        raise NotImplementedError("HIP GRU supports hidden 64, 2 layers, bidirectional (the trainer's config)")
+    if model.att is not None:
+        raise NotImplementedError("att='self_att' is outside the HIP path (SURVEY.md section 8f)")
+    return SimpleNamespace(convs=convs, bns=bns, pools=pools, drop_ps=drop_ps, dense_p=model.dropout.p, rnn=rnn,
+                           dense1=model.dense1,
+                           head=model.pred_emotion_layer if head == "emotion" else model.pred_gender_layer,
+                           training=model.training)
+
+
+def _drop_mask(shape, device, p=DROP_P):
+    return (torch.rand(shape, device=device) >= p).float().mul_(1.0 / (1.0 - p))
+
+
+def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None):
+    """x (B, H, W) fp32 CUDA -> logits (B, C).  Returns (logits, saved) where `saved` holds
+    what trunk_backward needs.  BatchNorm uses batch statistics (and updates the running
+    buffers) when the module is in train mode -- also for a frozen model;
+    Dropout / Dropout2d / GRU dropout are active in train mode.  `injected` may carry
+    explicit dropout masks {'drop2d': [...], 'rnn': t, 'dense': t} for reproducible tests."""
+    require_cuda(x)
+    B, H, W = x.shape
+    dev = x.device
+    train = P.training
+    inj = injected or {}
+    S = SimpleNamespace(x=x, blocks=[], train=train, pooling=pooling, B=B)
+    act = None
+    h, w = H, W
+    for li, (cv, bn, pool) in enumerate(zip(P.convs, P.bns, P.pools)):
+        cout = cv.weight.shape[0]
+        if li == 0:
+            pre = ops.conv1_forward(x, cv.weight, cv.bias)
+        else:
+            wt = _cached("convfwd", cv.weight, lambda: ops.conv5x5_prep_weights(cv.weight, 0))
+            pre = ops.conv5x5(act, wt, cv.bias)
+        if bn.training:
+            mean, invstd = ops.bn_stats(pre, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                        bn.momentum if bn.momentum is not None else 0.1, bn.eps)
+        else:
+            mean, invstd = ops.bn_eval_stats(bn.running_mean, bn.running_var, bn.eps)
+        drop = None
+        if train and (P.drop_ps[li] > 0 or "drop2d" in inj):
+            d2 = inj.get("drop2d")
+            drop = d2[li] if d2 is not None else _drop_mask((B, cout), dev, P.drop_ps[li])
+        out = ops.bn_relu_pool_forward(pre, mean, invstd, bn.weight, bn.bias, drop, pool)
+        S.blocks.append(SimpleNamespace(inp=act, pre=pre, mean=mean, invstd=invstd, drop=drop, pool=pool, h=h, w=w,
+                                        bn_train=bn.training))
+        act = out
+        h, w = h // pool, w // pool
+    # ---- GRU: (B, T=h, D = w*C) with NHWC feature order (w, c) ----
+    C = act.shape[-1]
+    T, D = h, w * C
+    seq = act.view(B * T, D)
+    r = P.rnn
+    S.seq, S.T, S.D, S.C, S.Wd = seq, T, D, C, w
+    layer_in = seq
+    S.gru = []
+    for layer in range(2):
+        names = [f"weight_ih_l{layer}", f"weight_ih_l{layer}_reverse", f"weight_hh_l{layer}",
+                 f"weight_hh_l{layer}_reverse", f"bias_ih_l{layer}", f"bias_ih_l{layer}_reverse",
+                 f"bias_hh_l{layer}", f"bias_hh_l{layer}_reverse"]
+        wif, wir, whf, whr, bif, bir, bhf, bhr = [getattr(r, n) for n in names]
+        if layer == 0:
+            wif_k = _cached("wih_perm", wif, lambda: ops.permute_cols(wif, C, w))
+            wir_k = _cached("wih_perm", wir, lambda: ops.permute_cols(wir, C, w))
+        else:
+            wif_k, wir_k = wif, wir
+        K = layer_in.shape[1]
+        gi = torch.empty((B * T, 2 * 192), dtype=torch.float32, device=dev)
+        ops.gemm_raw(layer_in, K, 1, wif_k, 1, K, gi, 384, B * T, 192, K, bif)
+        ops.gemm_raw(layer_in, K, 1, wir_k, 1, K, gi[:, 192:], 384, B * T, 192, K, bir)
+        out, gates = ops.gru_forward(gi.view(B, T, 2, 192), whf, whr, bhf, bhr)
+        G = SimpleNamespace(inp=layer_in, out=out, gates=gates, wif_k=wif_k, wir_k=wir_k, whf=whf, whr=whr, mask=None)
+        if layer == 0:
+            nxt = out.view(B * T, 128)
+            if train and (r.dropout > 0 or "rnn" in inj):
+                m = inj.get("rnn")
+                G.mask = m if m is not None else _drop_mask((B, T, 128), dev, r.dropout)
+                nxt = ops.mul(out, G.mask).view(B * T, 128)
+            layer_in = nxt
+        S.gru.append(G)
+    out1 = S.gru[1].out
+    z = ops.mean_t_forward(out1) if pooling == "mean" else out1.view(B, T * 128)
+    d1 = ops.linear_forward(z, P.dense1.weight, P.dense1.bias)
+    dmask = None
+    if train and (P.dense_p > 0 or "dense" in inj):
+        m = inj.get("dense")
+        dmask = m if m is not None else _drop_mask((B, d1.shape[1]), dev, P.dense_p)
+    d1a = ops.relu_dropout_forward(d1, dmask)
+    logits = ops.linear_forward(d1a, P.head.weight, P.head.bias)
+    S.z, S.d1, S.dmask, S.d1a = z, d1, dmask, d1a
+    return logits, (S if need_grad else None)
+
+
+def trunk_backward(S, P, dlogits, need_wgrad=True, need_dx=True):
+    """Returns (dx (B,H,W) fp32 or None, grads: dict parameter-tensor-id -> gradient) for one
+    network.  With need_wgrad False (frozen model) only the data path is evaluated."""
+    B, T = S.B, S.T
+    grads = {}
+
+    def put(param, g):
+        if need_wgrad and param is not None and param.requires_grad:
+            grads[param] = g
+
+    dlogits = dlogits.contiguous()
+    d_d1a = ops.linear_backward_input(dlogits, P.head.weight)
+    if need_wgrad:
+        put(P.head.weight, ops.linear_backward_weight(dlogits, S.d1a))
+        put(P.head.bias, ops.colsum(dlogits))
+    d_d1 = ops.relu_dropout_backward(d_d1a, S.d1, S.dmask)
+    dz = ops.linear_backward_input(d_d1, P.dense1.weight)
+    if need_wgrad:
+        put(P.dense1.weight, ops.linear_backward_weight(d_d1, S.z))
+        put(P.dense1.bias, ops.colsum(d_d1))
+    dout = ops.mean_t_backward(dz, T) if S.pooling == "mean" else dz.view(B, T, 128)
+    r = P.rnn
+    dseq = None
+    for layer in (1, 0):
+        G = S.gru[layer]
+        sfx = f"_l{layer}"
+        dgi, dgh, hprev = ops.gru_backward(dout.contiguous(), G.out, G.gates, G.whf, G.whr)
+        dgi2, dgh2, hp2 = dgi.view(B * T, 384), dgh.view(B * T, 384), hprev.view(B * T, 128)
+        K = G.inp.shape[1]
+        if need_wgrad:
+            for d, tag in ((0, ""), (1, "_reverse")):
+                gs = dgi2[:, d * 192:(d + 1) * 192]
+                gh = dgh2[:, d * 192:(d + 1) * 192]
+                dwih = ops.linear_backward_weight(gs, G.inp)
+                if layer == 0:
+                    dwih = ops.permute_cols(dwih, S.C, S.Wd, inverse=True)
+                put(getattr(r, "weight_ih" + sfx + tag), dwih)
+                put(getattr(r, "weight_hh" + sfx + tag), ops.linear_backward_weight(gh, hp2[:, d * 64:(d + 1) * 64]))
+                put(getattr(r, "bias_ih" + sfx + tag), ops.colsum(gs))
+                put(getattr(r, "bias_hh" + sfx + tag), ops.colsum(gh))
+        # gradient wrt the layer input: dgi_f W_if + dgi_r W_ir
+        if layer == 1:
+            din = torch.empty((B * T, K), dtype=torch.float32, device=dgi.device)
+        else:
+            din = torch.empty((B * T, K), dtype=torch.bfloat16, device=dgi.device)
+        ops.gemm_raw(dgi2, 384, 1, G.wif_k, K, 1, din, K, B * T, K, 192)
+        ops.gemm_raw(dgi2[:, 192:], 384, 1, G.wir_k, K, 1, din, K, B * T, K, 192, beta=1.0)
+        if layer == 1:
+            dout = din.view(B, T, 128)
+            if S.gru[0].mask is not None:
+                dout = ops.mul(dout, S.gru[0].mask)
+        else:
+            dseq = din
+    # ---- conv stack ----
+    dact = dseq.view(B, T, S.Wd, S.C)
+    dx = None
+    for li in range(len(S.blocks) - 1, -1, -1):
+        blk, cv, bn = S.blocks[li], P.convs[li], P.bns[li]
+        if not blk.bn_train:
+            raise SeptError("backward through an eval-mode BatchNorm is not implemented on the HIP path")
+        want_bn = need_wgrad and bn.weight.requires_grad
+        dpre, dgamma, dbeta = ops.bn_relu_pool_backward(dact, blk.pre, blk.mean, blk.invstd, bn.weight, bn.bias,
+                                                        blk.drop, blk.pool, need_param_grads=want_bn)
+        if want_bn:
+            put(bn.weight, dgamma)
+            put(bn.bias, dbeta)
+        if li == 0:
+            if need_wgrad and cv.weight.requires_grad:
+                dw, db = ops.conv1_backward_weight(S.x, dpre)
+                put(cv.weight, dw)
+                put(cv.bias, db)
+            if need_dx:
+                dx = ops.conv1_backward_data(dpre, cv.weight)
+        else:
+            if need_wgrad and cv.weight.requires_grad:
+                put(cv.weight, ops.conv5x5_backward_weight(blk.inp, dpre))
+                # the conv bias feeds straight into a training-mode BatchNorm, whose backward has
+                # zero channel sum by construction: d(bias) == 0 (the reference gets rounding noise)
+                put(cv.bias, torch.zeros_like(cv.bias))
+            wtd = _cached("convdgrad", cv.weight, lambda: ops.conv5x5_prep_weights(cv.weight, 1))
+            dact = ops.conv5x5(dpre, wtd)
+    return dx, grads
+
+
+# ---------------------------------------------------------------------------------------------
+# autograd glue
+# ---------------------------------------------------------------------------------------------
+def _param_list(P):
+    ps = []
+    for cv, bn in zip(P.convs, P.bns):
+        ps += [cv.weight, cv.bias, bn.weight, bn.bias]
+    ps += list(P.rnn.parameters())
+    ps += [P.dense1.weight, P.dense1.bias, P.head.weight, P.head.bias]
+    return ps
+
+
+class TrunkFn(torch.autograd.Function):
+    """logits = trunk(x; params).  forward(ctx, x, P, pooling, injected, *params)."""
+
+    @staticmethod
+    def forward(ctx, x, P, pooling, injected, *params):
+        need = any(ctx.needs_input_grad)
+        logits, S = trunk_forward(x.detach().contiguous().view(x.shape[0], x.shape[-2], x.shape[-1]), P, pooling,
+                                  need_grad=need, injected=injected)
+        ctx.S, ctx.P, ctx.params, ctx.xshape = S, P, params, x.shape
+        ctx.need_dx = x.requires_grad
+        ctx.need_w = any(p.requires_grad for p in params)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        dx, grads = trunk_backward(ctx.S, ctx.P, dlogits, need_wgrad=ctx.need_w, need_dx=ctx.need_dx)
+        ctx.S = None
+        gp = tuple(grads.get(p) if p.requires_grad else None for p in ctx.params)
+        return (dx.view(ctx.xshape) if dx is not None else None, None, None, None) + gp
+
+
+def run_trunk(model, x, head, pooling="mean", injected=None):
+    P = trunk_params(model, head)
+    return TrunkFn.apply(x, P, pooling, injected, *_param_list(P))
+
+
+class GradientReversalFunction(torch.autograd.Function):
+    """reversal_gradient.py:5-23: identity forward, -lambda * grad backward (HIP scale kernel)."""
+
+    @staticmethod
+    def forward(ctx, x, lambda_):
+        ctx.lambda_ = lambda_
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, grads):
+        require_cuda(grads)
+        return ops.scale(grads.contiguous().float(), -float(ctx.lambda_)), None
+
+
+class CloakFn(torch.autograd.Function):
+    """cloak_noise.forward (cloak_models.py:52-58) with an explicit epsilon."""
+
+    @staticmethod
+    def forward(ctx, x, locs, rhos, eps, mask, min_scale, max_scale):
+        xn = ops.cloak_forward(x.detach().float().contiguous(), locs.detach(), rhos.detach(), eps, mask,
+                               min_scale, max_scale)
+        ctx.save_for_backward(rhos.detach(), eps, mask if mask is not None else torch.empty(0))
+        ctx.has_mask = mask is not None
+        ctx.cfg = (float(min_scale), float(max_scale))
+        ctx.need = (locs.requires_grad, rhos.requires_grad)
+        return xn
+
+    @staticmethod
+    def backward(ctx, dxn):
+        rhos, eps, mask = ctx.saved_tensors
+        dlocs, drhos = ops.cloak_backward(dxn.contiguous(), None, 0.0, rhos, eps, mask if ctx.has_mask else None,
+                                          ctx.cfg[0], ctx.cfg[1], need_locs=ctx.need[0], need_rhos=ctx.need[1])
+        return None, dlocs, drhos, None, None, None, None
+
+
+class ScalesFn(torch.autograd.Function):
+    """cloak_noise.scales() (cloak_models.py:41-43)."""
+
+    @staticmethod
+    def forward(ctx, rhos, min_scale, max_scale):
+        s, _ = ops.cloak_scales(rhos.detach(), min_scale, max_scale)
+        ctx.save_for_backward(rhos.detach())
+        ctx.cfg = (float(min_scale), float(max_scale))
+        return s
+
+    @staticmethod
+    def backward(ctx, ds):
+        (rhos,) = ctx.saved_tensors
+        # d scales / d rho = (1 - tanh^2) / 2 * (max - min): reuse the cloak backward with eps = ds, B = 1
+        ones = ds.contiguous().view(1, -1)
+        _, dr = ops.cloak_backward(torch.ones_like(ones), None, 0.0, rhos, ds.contiguous(), None, ctx.cfg[0],
+                                   ctx.cfg[1], need_locs=False)
+        return dr, None, None
+
+
+class GrlStepLossFn(torch.autograd.Function):
+    """The loss of train() (training_cloak_with_grl.py:141-160) in two CE launches:
+    sum_i w_i CE(emo_i)/B + gender_lambda * sum_i w_i CE(gen_i)/B - scale_lamda*log(mean(scales))."""
+
+    @staticmethod
+    def forward(ctx, preds, preds_grl, labels_emo, labels_gen, weights, gender_lambda, scale_lamda, rhos,
+                min_scale, max_scale):
+        B = preds.shape[0]
+        loss = torch.zeros((), dtype=torch.float32, device=preds.device)
+        d1 = ops.cross_entropy(preds.detach().contiguous(), labels_emo, weights, 1.0 / B, loss)
+        d2 = None
+        if preds_grl is not None:
+            d2 = ops.cross_entropy(preds_grl.detach().contiguous(), labels_gen, weights, float(gender_lambda) / B,
+                                   loss, accumulate=True)
+        ctx.scale_cfg = None
+        if rhos is not None and float(scale_lamda) != 0.0:
+            _, mean = ops.cloak_scales(rhos.detach(), min_scale, max_scale, want_scales=False, want_mean=True)
+            ops.loss_sub_log(loss, mean, float(scale_lamda))
+            ctx.scale_cfg = (float(scale_lamda), float(min_scale), float(max_scale), mean)
+            ctx.rhos = rhos.detach()
+        ctx.d = (d1, d2)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        d1, d2 = ctx.d
+        # g is the upstream scalar (1.0 for loss.backward()); keep it on-device
+        gd1 = ops.mul(d1, g.expand_as(d1).contiguous())
+        gd2 = ops.mul(d2, g.expand_as(d2).contiguous()) if d2 is not None else None
+        drhos = None
+        if ctx.scale_cfg is not None:
+            lam, mn, mx, mean = ctx.scale_cfg
+            rh = ctx.rhos
+            zero = torch.zeros((1, rh.numel()), dtype=torch.float32, device=rh.device)
+            _, drhos = ops.cloak_backward(zero, None, 0.0, rh, zero.view_as(rh), None, mn, mx, scale_lambda=lam,
+                                          scale_mean=mean, need_locs=False)
+            drhos = ops.mul(drhos, g.expand_as(drhos).contiguous())
+        return gd1, gd2, None, None, None, None, None, drhos, None, None

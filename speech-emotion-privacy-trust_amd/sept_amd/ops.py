@@ -131,3 +131,193 @@ def bn_relu_pool_backward(dy, x, mean, invstd, gamma, beta, dropscale=None, pool
                                          dx.data_ptr(), _p(dgamma), _p(dbeta), B, H, W, C, pool, _s(x)),
           "sept_bn_relu_pool_backward")
     return dx, dgamma, dbeta
+
+
+def conv5x5_backward_weight(x, dy):
+    """x (B,H,W,cin) bf16, dy (B,H,W,cout) bf16 -> dW (cout,cin,5,5) fp32."""
+    require_cuda(x, dy)
+    B, H, W, cin = x.shape
+    cout = dy.shape[-1]
+    ws = workspace("conv_wgrad", lib.sept_conv5x5_wgrad_workspace_floats(cin, cout), x.device)
+    dw = torch.empty((cout, cin, 5, 5), dtype=torch.float32, device=x.device)
+    check(lib.sept_conv5x5_backward_weight(x.data_ptr(), dy.data_ptr(), ws.data_ptr(), dw.data_ptr(), B, H, W, cin,
+                                           cout, _s(x)), "sept_conv5x5_backward_weight")
+    return dw
+
+
+# ---------------------------------------------------------------------------------------------
+# linear algebra / recurrent / small ops
+# ---------------------------------------------------------------------------------------------
+def _is_bf16(t):
+    return 1 if t.dtype == torch.bfloat16 else 0
+
+
+def gemm_raw(A, sam, sak, Bm, sbk, sbn, C, ldc, M, N, K, bias=None, alpha=1.0, beta=0.0):
+    """C[M][N] = alpha * A(M,K) B(K,N) (+bias) (+beta*C) with explicit element strides; A/B/C may
+    be views (data_ptr carries the offset)."""
+    check(lib.sept_gemm(A.data_ptr(), sam, sak, _is_bf16(A), Bm.data_ptr(), sbk, sbn, _is_bf16(Bm), C.data_ptr(), ldc,
+                        _is_bf16(C), _p(bias), M, N, K, float(alpha), float(beta), _s(C)), "sept_gemm")
+    return C
+
+
+def linear_forward(x, W, bias=None, out=None, out_dtype=torch.float32):
+    """y[M][N] = x[M][K] W[N][K]^T + bias."""
+    M, K = x.shape
+    N = W.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=x.device)
+    return gemm_raw(x, K, 1, W, 1, K, out, out.stride(0), M, N, K, bias)
+
+
+def linear_backward_input(dy, W, out=None, out_dtype=torch.float32):
+    """dx[M][K] = dy[M][N] W[N][K]."""
+    M, N = dy.shape
+    K = W.shape[1]
+    if out is None:
+        out = torch.empty((M, K), dtype=out_dtype, device=dy.device)
+    return gemm_raw(dy, dy.stride(0), 1, W, K, 1, out, out.stride(0), M, K, N)
+
+
+def linear_backward_weight(dy, x, out=None):
+    """dW[N][K] = dy[M][N]^T x[M][K]  (dy / x may be row-strided views)."""
+    M, N = dy.shape
+    K = x.shape[1]
+    if out is None:
+        out = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+    return gemm_raw(dy, 1, dy.stride(0), x, x.stride(0), 1, out, out.stride(0), N, K, M)
+
+
+def colsum(a, out=None, accumulate=False):
+    M, N = a.shape
+    if out is None:
+        out = torch.empty(N, dtype=torch.float32, device=a.device)
+    check(lib.sept_colsum(a.data_ptr(), a.stride(0), M, N, out.data_ptr(), int(accumulate), _s(a)), "sept_colsum")
+    return out
+
+
+def gru_forward(gi, whh_f, whh_r, bhh_f, bhh_r):
+    """gi (B,T,2,3H), whh_* (3H,H), bhh_* (3H) -> out (B,T,2H), gates (B,T,2,4,H)."""
+    B, T = gi.shape[0], gi.shape[1]
+    H = whh_f.shape[1]
+    out = torch.empty((B, T, 2 * H), dtype=torch.float32, device=gi.device)
+    gates = torch.empty((B, T, 2, 4, H), dtype=torch.float32, device=gi.device)
+    check(lib.sept_gru_forward(gi.data_ptr(), whh_f.data_ptr(), whh_r.data_ptr(), bhh_f.data_ptr(), bhh_r.data_ptr(),
+                               out.data_ptr(), gates.data_ptr(), B, T, H, _s(gi)), "sept_gru_forward")
+    return out, gates
+
+
+def gru_backward(dout, out, gates, whh_f, whh_r):
+    B, T = dout.shape[0], dout.shape[1]
+    H = whh_f.shape[1]
+    dgi = torch.empty((B, T, 2, 3 * H), dtype=torch.float32, device=dout.device)
+    dgh = torch.empty_like(dgi)
+    hprev = torch.empty((B, T, 2, H), dtype=torch.float32, device=dout.device)
+    check(lib.sept_gru_backward(dout.data_ptr(), out.data_ptr(), gates.data_ptr(), whh_f.data_ptr(), whh_r.data_ptr(),
+                                dgi.data_ptr(), dgh.data_ptr(), hprev.data_ptr(), B, T, H, _s(dout)),
+          "sept_gru_backward")
+    return dgi, dgh, hprev
+
+
+def cloak_forward(x, locs, rhos, eps, mask, min_scale, max_scale):
+    B = x.shape[0]
+    n_per = locs.numel()
+    xn = torch.empty_like(x)
+    check(lib.sept_cloak_forward(x.data_ptr(), locs.data_ptr(), rhos.data_ptr(), eps.data_ptr(), _p(mask),
+                                 float(min_scale), float(max_scale), xn.data_ptr(), B, n_per, _s(x)),
+          "sept_cloak_forward")
+    return xn
+
+
+def cloak_scales(rhos, min_scale, max_scale, want_scales=True, want_mean=False):
+    n = rhos.numel()
+    scales = torch.empty_like(rhos) if want_scales else None
+    mean = torch.empty((), dtype=torch.float32, device=rhos.device) if want_mean else None
+    check(lib.sept_cloak_scales(rhos.data_ptr(), float(min_scale), float(max_scale), _p(scales), _p(mean), n,
+                                _s(rhos)), "sept_cloak_scales")
+    return scales, mean
+
+
+def cloak_backward(dxa, dxb, gscale_b, rhos, eps, mask, min_scale, max_scale, scale_lambda=0.0, scale_mean=None,
+                   need_locs=True, need_rhos=True):
+    B = dxa.shape[0]
+    n_per = rhos.numel()
+    dlocs = torch.empty_like(rhos) if need_locs else None
+    drhos = torch.empty_like(rhos) if need_rhos else None
+    check(lib.sept_cloak_backward(dxa.data_ptr(), _p(dxb), float(gscale_b), rhos.data_ptr(), eps.data_ptr(), _p(mask),
+                                  float(min_scale), float(max_scale), float(scale_lambda), _p(scale_mean), _p(dlocs),
+                                  _p(drhos), B, n_per, _s(dxa)), "sept_cloak_backward")
+    return dlocs, drhos
+
+
+def scale(x, a):
+    y = torch.empty_like(x)
+    check(lib.sept_scale(x.data_ptr(), float(a), y.data_ptr(), x.numel(), _s(x)), "sept_scale")
+    return y
+
+
+def mul(x, m):
+    y = torch.empty_like(x)
+    check(lib.sept_mul(x.data_ptr(), m.data_ptr(), y.data_ptr(), x.numel(), _s(x)), "sept_mul")
+    return y
+
+
+def relu_dropout_forward(x, dropscale=None):
+    y = torch.empty_like(x)
+    check(lib.sept_relu_dropout_forward(x.data_ptr(), _p(dropscale), y.data_ptr(), x.numel(), _s(x)),
+          "sept_relu_dropout_forward")
+    return y
+
+
+def relu_dropout_backward(dy, x, dropscale=None):
+    dx = torch.empty_like(x)
+    check(lib.sept_relu_dropout_backward(dy.data_ptr(), x.data_ptr(), _p(dropscale), dx.data_ptr(), x.numel(),
+                                         _s(x)), "sept_relu_dropout_backward")
+    return dx
+
+
+def mean_t_forward(x):
+    B, T, D = x.shape
+    z = torch.empty((B, D), dtype=torch.float32, device=x.device)
+    check(lib.sept_mean_t_forward(x.data_ptr(), z.data_ptr(), B, T, D, _s(x)), "sept_mean_t_forward")
+    return z
+
+
+def mean_t_backward(dz, T):
+    B, D = dz.shape
+    dx = torch.empty((B, T, D), dtype=torch.float32, device=dz.device)
+    check(lib.sept_mean_t_backward(dz.data_ptr(), dx.data_ptr(), B, T, D, _s(dz)), "sept_mean_t_backward")
+    return dx
+
+
+def cross_entropy(logits, labels, weights, scale_, loss, want_grad=True, accumulate=False):
+    """loss (0-dim fp32 tensor, updated in place) (+)= scale * sum_i w_i CE_i; returns dlogits."""
+    B, C = logits.shape
+    labels = labels.reshape(-1)
+    assert labels.dtype == torch.int64 and labels.numel() == B
+    d = torch.empty_like(logits) if want_grad else None
+    check(lib.sept_cross_entropy(logits.data_ptr(), labels.data_ptr(), _p(weights), float(scale_), B, C,
+                                 loss.data_ptr(), _p(d), int(accumulate), _s(logits)), "sept_cross_entropy")
+    return d
+
+
+def loss_sub_log(loss, mean, lam):
+    check(lib.sept_loss_sub_log(loss.data_ptr(), mean.data_ptr(), float(lam), _s(loss)), "sept_loss_sub_log")
+
+
+def permute_cols(src, C, Wd, inverse=False):
+    N = src.shape[0]
+    dst = torch.empty_like(src)
+    check(lib.sept_permute_cols(src.data_ptr(), dst.data_ptr(), N, C, Wd, int(inverse), _s(src)),
+          "sept_permute_cols")
+    return dst
+
+
+def sgd_step(p, g, buf, lr, momentum, weight_decay, first_step, grad_scale=1.0):
+    check(lib.sept_sgd_step(p.data_ptr(), g.data_ptr(), _p(buf), p.numel(), float(lr), float(momentum),
+                            float(weight_decay), int(first_step), float(grad_scale), _s(p)), "sept_sgd_step")
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    check(lib.sept_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr),
+                             float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
+                             float(grad_scale), _s(p)), "sept_adam_step")

@@ -27,3 +27,19 @@ for (H, W, ci, co, mode) in [(100, 40, 32, 64, 0), (50, 20, 64, 128, 0), (100, 4
     ms = s.elapsed_time(e) / n
     fl = 2.0 * B * H * W * ci * co * 25
     print(f"conv {ci}->{co} {H}x{W} B={B} mode={mode}: {ms*1e3:.1f} us  {fl/ms/1e9:.1f} TFLOP/s")
+
+for (H, W, ci, co) in [(100, 40, 32, 64), (50, 20, 64, 128), (100, 64, 32, 64), (50, 32, 64, 128)]:
+    x = torch.randn(B, H, W, ci, device="cuda").bfloat16()
+    dy = torch.randn(B, H, W, co, device="cuda").bfloat16()
+    for _ in range(3):
+        ops.conv5x5_backward_weight(x, dy)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(20):
+        ops.conv5x5_backward_weight(x, dy)
+    e.record()
+    torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / 20
+    fl = 2.0 * B * H * W * ci * co * 25
+    print(f"wgrad {ci}->{co} {H}x{W} B={B}: {ms*1e3:.1f} us  {fl/ms/1e9:.1f} TFLOP/s")
