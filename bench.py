@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""bench.py -- utterances/sec of the fused hot path (BASELINE.json metric) on N MI355X.
+
+One step = one pass of the whole path over one batch of synthetic clips per GPU:
+  waveforms (clips_per_gpu x 5 s @ 16 kHz, already in HBM) -> STFT/mel/dB (n_fft 800, F mels)
+  -> 7 windows/clip (200 frames every 50) + z-norm -> cloak noise -> emotion CNN+GRU (frozen,
+  fwd + data-grad) + GRL + gender adversary (fwd + bwd) -> weighted CE loss -> backward ->
+  gradient all-reduce (RCCL, N > 1) -> SGD step.   (BASELINE.json config 5 / 4)
+value = clips processed by all ranks / max-over-ranks wall time of the K timed steps.
+
+Also printed on the same JSON line:
+  roofline     -- the dominant kernel of the step (by device time), its algorithmic FLOPs per
+                  launch / its mean launch duration measured with HIP events on the launch
+                  stream inside the timed region, against the dense bf16 MFMA peak (2.5 PF);
+                  plus the STFT->mel kernel's HBM figure under "mel" (north-star target)
+  cpu_baseline -- the oracle port (oracle/: torch fp32 CPU restatement of the reference) on a
+                  bounded sample of the same workload, rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "speech-emotion-privacy-trust_amd"))
+
+SR, CLIP_L, HOP, WIN, SHIFT = 16000, 80000, 160, 200, 50
+MFMA_PEAK, HBM_PEAK = 2.5e15, 8.0e12
+
+
+def build(F, device, seed=8):
+    from model import baseline_models as bm, cloak_models as cm
+    torch.manual_seed(seed)  # default torch init, same on every rank
+    kw = dict(lstm_hidden_size=64, num_layers_lstm=2, attention_size=128, att=None, global_feature=0)
+    emo = bm.two_d_cnn_lstm(1, F, 64, pred="emotion", **kw).to(device)
+    gen = bm.two_d_cnn_lstm(1, F, 64, pred="gender", **kw).to(device)
+    noise = cm.cloak_noise(torch.zeros(1, WIN, F), torch.ones(1, WIN, F), torch.tensor(0.01), torch.tensor(10.0),
+                           device).to(device)
+    return cm.two_d_cnn_lstm_syn_with_grl(emo, gen, noise, 0.1).to(device)
+
+
+def synth(clips, F, device, rank):
+    g = torch.Generator().manual_seed(8 + rank)
+    wav = (torch.randn(clips, CLIP_L, generator=g) * 0.1)
+    t = torch.arange(CLIP_L) / SR
+    f0 = torch.randint(3, 390, (clips, 1), generator=g) * (SR / 800.0)   # one bin-centred tone per clip
+    wav = (wav + 0.2 * torch.sin(2 * torch.pi * f0 * t)).clamp(-1, 1)
+    nwin = (1 + CLIP_L // HOP - WIN) // SHIFT + 1
+    le = torch.randint(0, 4, (clips,), generator=g).repeat_interleave(nwin)
+    lg = torch.randint(0, 2, (clips,), generator=g).repeat_interleave(nwin)
+    return wav.to(device), le.to(device), lg.to(device), nwin
+
+
+def conv_flops(tag, Bw, F):
+    """algorithmic FLOPs of one launch of the tagged conv kernel at Bw windows."""
+    name, dims = tag.split("<")
+    a, b = [int(v) for v in dims.rstrip(">").split(",")]
+    cin, cout = a, b
+    lo = min(cin, cout)                      # 32<->64 live at 100 x F/2, 64<->128 at 50 x F/4
+    H, W = (100, F // 2) if lo == 32 else (50, F // 4)
+    return 2.0 * Bw * H * W * cin * cout * 25
+
+
+def cpu_baseline(F, seconds_budget=25.0):
+    """oracle port on the host cores: mel one clip at a time (as the reference loops) + GRL
+    steps at the reference batch size of 32 windows; utterances/s over the same per-clip work."""
+    from oracle import mel_oracle, model_oracle as mo
+    # threads actually used: the box's CPU share for one GPU (16), never more than what the
+    # scheduler lets this process run on -- 256 oversubscribed threads only slow torch down
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    ncores = max(1, min(avail, 16))
+    torch.set_num_threads(ncores)
+    torch.manual_seed(8)
+    kw = dict(lstm_hidden_size=64, num_layers_lstm=2, attention_size=128, att=None, global_feature=0)
+    emo, gen = mo.two_d_cnn_lstm(1, F, 64, pred="emotion", **kw), mo.two_d_cnn_lstm(1, F, 64, pred="gender", **kw)
+    noise = mo.cloak_noise(torch.zeros(1, WIN, F), torch.ones(1, WIN, F), torch.tensor(0.01), torch.tensor(10.0), "cpu")
+    model = mo.two_d_cnn_lstm_syn_with_grl(emo, gen, noise, 0.1).train()
+    opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    fb = mel_oracle.melscale_fbanks_htk(401, F)
+    wav = torch.randn(8, CLIP_L) * 0.1
+    Bw = 32
+    le, lg, w = torch.randint(0, 4, (Bw, 1)), torch.randint(0, 2, (Bw, 1)), torch.ones(Bw)
+    t0 = time.perf_counter()
+    for i in range(8):
+        mel_oracle.mel_spectrogram_torch(wav[i:i + 1], 800, F, fb=fb)
+    t_mel = (time.perf_counter() - t0) / 8
+    x = torch.randn(Bw, 1, WIN, F)
+    steps, t_step = 0, 0.0
+    while steps < 1 or (t_step < seconds_budget and steps < 6):
+        t0 = time.perf_counter()
+        p1, p2, _ = model(x, mask=None, grl=False, pooling="mean")
+        loss = mo.grl_step_loss(p1, p2, le, lg, w, 0.1, 0.0, model)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        dt = time.perf_counter() - t0
+        if steps > 0 or dt > seconds_budget / 2:   # first step is warm-up unless it is already long
+            t_step += dt
+        steps += 1
+    n_timed = max(steps - 1, 1)
+    per_clip = t_mel + (t_step / n_timed) * 7.0 / Bw
+    return {"value": 1.0 / per_clip, "unit": "utterances/s", "cores": ncores, "kind": "port",
+            "sample": f"oracle (torch fp32 CPU): 8 clips mel one at a time + {n_timed} GRL step(s) of 32 windows "
+                      f"(fwd+bwd+SGD), {ncores} threads; mel {t_mel*1e3:.2f} ms/clip, step {t_step/n_timed:.2f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--clips-per-gpu", type=int, default=32)
+    ap.add_argument("--mels", type=int, default=80)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import sept_amd
+    from sept_amd import ops
+    from sept_amd.trainer import FusedPipeline, GrlTrainer
+    sept_amd.check(sept_amd.lib.sept_device_check(), "sept_device_check")
+
+    F, clips = a.mels, a.clips_per_gpu
+    model = build(F, dev)
+    trainer = GrlTrainer(model, optimizer="sgd", gender_lambda=0.1, scale_lamda=0.0)
+    mean = torch.full((F,), -20.0, device=dev)    # fixed per-mel statistics of the synthetic set
+    std = torch.full((F,), 12.0, device=dev)
+    pipe = FusedPipeline(trainer, n_mels=F, n_fft=800, mean=mean, std=std)
+    wav, le, lg, nwin = synth(clips, F, dev, rank)
+    Bw = clips * nwin
+    weights = torch.ones(Bw, device=dev)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warm-up (also finds the dominant conv kernel with per-launch events) ----
+    ops.TIMER = ops.KernelTimer()
+    for _ in range(max(a.warmup, 1)):
+        loss, _, _ = pipe.train_step(wav, le, lg, weights)
+    torch.cuda.synchronize()
+    warm = ops.TIMER.summary()
+    per_step = {t: n * ms / max(a.warmup, 1) for t, (n, ms) in warm.items()}
+    dominant = max(per_step, key=per_step.get)
+    ops.TIMER = ops.KernelTimer(tags={dominant})
+    mel_ev = []
+
+    # ---- timed region ----
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        x = pipe.features(wav)
+        e1.record()
+        mel_ev.append((e0, e1))
+        loss, _, _ = trainer.train_step(x.view(Bw, 1, WIN, F), le, lg, weights)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_val = float(loss.item())
+
+    n_launch, k_ms = ops.TIMER.summary()[dominant]
+    flops = conv_flops(dominant, Bw, F)
+    achieved = flops / (k_ms * 1e-3)
+    feat_ms = sum(a_.elapsed_time(b_) for a_, b_ in mel_ev) / len(mel_ev)
+    ops.TIMER = None
+
+    # kernel-only mel figure (config 2: batch 256, F mels) for the north-star HBM target
+    mel = {}
+    if rank == 0:
+        from sept_amd.mel import get_mel_plan
+        plan = get_mel_plan(800, F)
+        wb = torch.randn(256, CLIP_L, device=dev) * 0.1
+        out = plan.forward(wb)
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(10):
+            plan.forward(wb, out=out)
+        e.record()
+        torch.cuda.synchronize()
+        us = s.elapsed_time(e) * 100.0
+        byts = 256 * (4 * CLIP_L + 4 * F * (1 + CLIP_L // HOP))
+        mel = {"kernel": plan.kernel_name, "batch": 256, "us_per_launch": round(us, 1), "bound": "hbm",
+               "achieved_GBps": round(byts / us / 1e3, 1), "peak_GBps": HBM_PEAK / 1e9,
+               "frac": round(byts / (us * 1e-6) / HBM_PEAK, 4), "algorithmic_bytes_per_clip": byts // 256}
+
+    if rank != 0:
+        return
+    total_clips = clips * world * a.steps
+    res = {
+        "metric": "utterances/sec (feat-extract + fwd + bwd), 5 s @ 16 kHz",
+        "value": round(total_clips / dt, 2), "unit": "utterances/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"fused waveform->STFT/mel(n_fft 800, {F} mels)->7 windows/clip->cloak+emotion CNN/GRU"
+                               f"+GRL gender adversary fwd+bwd+SGD (BASELINE config 5); {clips} clips "
+                               f"({Bw} windows) per GPU per step",
+                   "clips_per_gpu": clips, "windows_per_gpu": Bw, "n_mels": F, "n_fft": 800,
+                   "parallelism": f"dp{world}", "optimizer": "sgd", "loss": round(loss_val, 5),
+                   "feature_stage_ms": round(feat_ms, 3)},
+        "roofline": {"bound": "mfma", "kernel": dominant, "launches_timed": n_launch,
+                     "ms_per_launch": round(k_ms, 4), "flops_per_launch": flops,
+                     "achieved": round(achieved / 1e12, 2), "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s",
+                     "frac": round(achieved / MFMA_PEAK, 4), "traffic": None,
+                     "per_step_ms_by_kernel": {t: round(v, 3) for t, v in sorted(per_step.items())}},
+        "mel": mel,
+    }
+    if world == 1 and not a.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(F)
+        res["vs_cpu_baseline"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

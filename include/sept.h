@@ -130,11 +130,12 @@ int sept_bn_relu_pool_backward(const void* dy_bf16, const void* x_bf16, const fl
  * on the exact-fp32 MFMA.  A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn] (element
  * strides), C row-major with leading dimension ldc.  A, B and C may each be bf16.
  * Stands behind nn.Linear (baseline_models.py:208-210) and nn.GRU's x W_ih^T
- * (baseline_models.py:191-193) and their autograd (dx = dy W, dW = dy^T x).
+ * (baseline_models.py:191-193) and their autograd (dx = dy W, dW = dy^T x).  `ws` (nullable,
+ * ws_floats floats) lets weight-gradient shapes (few tiles, long K) split K deterministically.
  * ------------------------------------------------------------------------------------ */
 int sept_gemm(const void* A, long sam, long sak, int a_is_bf16, const void* B, long sbk, long sbn,
-              int b_is_bf16, void* C, long ldc, int c_is_bf16, const float* bias, int M, int N, int K, float alpha, float beta,
-              void* stream);
+              int b_is_bf16, void* C, long ldc, int c_is_bf16, const float* bias, int M, int N, int K,
+              float alpha, float beta, float* ws, long ws_floats, void* stream);
 
 /* Recurrent part of nn.GRU(.., hidden 64, bidirectional, batch_first) -- one launch per layer
  * for both directions and all T steps (baseline_models.py:191-193; gate order r, z, n).
@@ -191,6 +192,12 @@ int sept_loss_sub_log(float* loss, const float* mean, float lambda, void* stream
 /* dst[n][w*C + c] = src[n][c*Wd + w] (inverse != 0: the other way): GRU weight_ih_l0 between
  * the reference's (c, w) feature order (cloak_models.py:166-168) and the NHWC (w, c) order */
 int sept_permute_cols(const float* src, float* dst, int N, int C, int Wd, int inverse, void* stream);
+/* Windowing + per-speaker z-normalisation between the two halves of the path: mel (B, T, F)
+ * time-major -> out (B*nwin, win, F), window i = frames [shift*i, shift*i + win) (zero padded
+ * past T), each value (x - mean[f]) / (std[f] + 1e-5) when mean/std are given
+ * (preprocess_adversary_data.py:30-35,131,377-378; training_cloak_with_grl.py:71). */
+int sept_window_norm(const float* mel_btf, const float* mean, const float* stdv, float* out, int B, int T, int F,
+                     int win, int shift, int nwin, void* stream);
 /* torch.optim.SGD(momentum, weight_decay) / torch.optim.Adam(betas, eps, weight_decay) on a flat
  * parameter buffer (training_cloak_with_grl.py:416-421); grad_scale multiplies g first (1/world
  * for averaged data-parallel gradients).  Adam `step` counts from 1. */

@@ -72,14 +72,11 @@ __global__ __launch_bounds__(256) void sept_bn_stats_partial_kernel(const bf16* 
 __global__ void sept_bn_stats_finalize_kernel(const float* ws, int nparts, int C, double n, float* mean,
                                               float* invstd, float* running_mean, float* running_var,
                                               long long* nbt, float momentum, float eps) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.x;  // one wave per channel
+  const double s = sept::wave_sum_partials(ws, nparts, size_t(2) * C, c);
+  const double ss = sept::wave_sum_partials(ws, nparts, size_t(2) * C, size_t(C) + c);
+  if (threadIdx.x != 0) return;
   if (c == 0 && nbt) *nbt += 1;
-  if (c >= C) return;
-  double s = 0, ss = 0;
-  for (int p = 0; p < nparts; ++p) {
-    s += ws[size_t(p) * 2 * C + c];
-    ss += ws[size_t(p) * 2 * C + C + c];
-  }
   const double m = s / n;
   double var = ss / n - m * m;
   var = var < 0 ? 0 : var;
@@ -206,13 +203,10 @@ __global__ __launch_bounds__(256) void sept_bn_bwd_reduce_kernel(BnBwdArgs a) {
 }
 
 __global__ void sept_bn_bwd_finalize_kernel(float* ws, int nparts, int C, float* dgamma, float* dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0, s2 = 0;
-  for (int p = 0; p < nparts; ++p) {
-    s1 += ws[size_t(p) * 2 * C + c];
-    s2 += ws[size_t(p) * 2 * C + C + c];
-  }
+  const int c = blockIdx.x;  // one wave per channel
+  const double s1 = sept::wave_sum_partials(ws, nparts, size_t(2) * C, c);
+  const double s2 = sept::wave_sum_partials(ws, nparts, size_t(2) * C, size_t(C) + c);
+  if (threadIdx.x != 0) return;
   float* sums = ws + size_t(kParts) * 2 * C;
   sums[c] = float(s1);      // sum dy      (= dbeta)
   sums[C + c] = float(s2);  // sum dy*xhat (= dgamma)
@@ -289,7 +283,7 @@ extern "C" int sept_bn_stats(const void* x, long n_rows, int C, float* ws, float
   const int grid = grid_for(items);
   SEPT_CPP_DISPATCH(C, hipLaunchKernelGGL(sept_bn_stats_partial_kernel<CPP>, dim3(grid), dim3(256), 0, st,
                                           static_cast<const bf16*>(x), items, ws));
-  hipLaunchKernelGGL(sept_bn_stats_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, ws, grid, C,
+  hipLaunchKernelGGL(sept_bn_stats_finalize_kernel, dim3(C), dim3(64), 0, st, ws, grid, C,
                      double(n_rows), mean, invstd, running_mean, running_var, num_batches_tracked, momentum, eps);
   return sept::launch_check("sept_bn_stats");
 }
@@ -335,7 +329,7 @@ extern "C" int sept_bn_relu_pool_backward(const void* dy, const void* x, const f
   const long items = long(B) * (H / pool) * (W / pool) * (C / 8);
   const int grid = grid_for(items);
   SEPT_CPP_DISPATCH(C, hipLaunchKernelGGL(sept_bn_bwd_reduce_kernel<CPP>, dim3(grid), dim3(256), 0, st, a));
-  hipLaunchKernelGGL(sept_bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, ws, grid, C, dgamma, dbeta);
+  hipLaunchKernelGGL(sept_bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, ws, grid, C, dgamma, dbeta);
   const int grid2 = int(std::min<long>((items + 255) / 256, 4096));
   SEPT_CPP_DISPATCH(C, hipLaunchKernelGGL(sept_bn_bwd_apply_kernel<CPP>, dim3(grid2), dim3(256), 0, st, a));
   return sept::launch_check("sept_bn_relu_pool_backward");

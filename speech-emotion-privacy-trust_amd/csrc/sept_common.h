@@ -52,4 +52,16 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Fixed-order sum over `nparts` partial slabs: returns sum_p ws[p * stride + idx] to lane 0 of
+// the calling wave (all 64 lanes must call with the same idx).  Lanes take every 64th slab in
+// double precision, then a shuffle tree combines them -- deterministic for a given nparts.
+__device__ __forceinline__ double wave_sum_partials(const float* ws, int nparts, size_t stride, size_t idx) {
+  const int lane = threadIdx.x & 63;
+  double s = 0.0;
+  for (int p = lane; p < nparts; p += 64) s += double(ws[size_t(p) * stride + idx]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  return s;
+}
+
 }  // namespace sept

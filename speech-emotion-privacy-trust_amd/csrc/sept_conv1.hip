@@ -185,11 +185,11 @@ __global__ __launch_bounds__(256) void sept_conv1_wgrad_partial_kernel(C1Args a)
 }
 
 __global__ void sept_conv1_wgrad_finalize_kernel(const float* ws, int nparts, float* dw, float* db) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = kC * kTaps + kC;
+  const int i = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;  // one wave per output element
   if (i >= n) return;
-  double s = 0;
-  for (int p = 0; p < nparts; ++p) s += ws[size_t(p) * n + i];
+  const double s = sept::wave_sum_partials(ws, nparts, size_t(n), i);
+  if (threadIdx.x & 63) return;
   if (i < kC * kTaps)
     dw[i] = float(s);
   else if (db)
@@ -249,6 +249,6 @@ extern "C" int sept_conv1_backward_weight(const float* x, const void* dy, float*
   SEPT_HIP(sept::allow_max_lds(reinterpret_cast<const void*>(&sept_conv1_wgrad_partial_kernel)));
   hipLaunchKernelGGL(sept_conv1_wgrad_partial_kernel, dim3(grid), dim3(256), smem, st, a);
   const int n = kC * kTaps + kC;
-  hipLaunchKernelGGL(sept_conv1_wgrad_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ws, grid, dw, db);
+  hipLaunchKernelGGL(sept_conv1_wgrad_finalize_kernel, dim3((n + 3) / 4), dim3(256), 0, st, ws, grid, dw, db);
   return sept::launch_check("sept_conv1_backward_weight");
 }

@@ -103,12 +103,23 @@ __global__ void mean_t_bwd_kernel(const float* dz, float* dx, int B, int T, int 
   }
 }
 
-// out[n] (+)= sum_m a[m][n]   (one thread per column; rows are few thousand at most)
-__global__ void colsum_kernel(const float* a, long lda, int M, int N, float* out, int accumulate) {
-  GRID_STRIDE(n, N) {
-    float s = 0.f;
-    for (int m = 0; m < M; ++m) s += a[size_t(m) * lda + n];
-    out[n] = accumulate ? out[n] + s : s;
+// out[n] (+)= sum_m a[m][n]: a block owns 32 columns; 8 row-lanes stride the rows (128-byte
+// row segments), then a fixed-order LDS tree over the row-lanes.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* a, long lda, int M, int N, float* out,
+                                                     int accumulate) {
+  __shared__ float red[8][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int n = blockIdx.x * 32 + tx;
+  float s = 0.f;
+  if (n < N)
+    for (int m = ty; m < M; m += 8) s += a[size_t(m) * lda + n];
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && n < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][tx];
+    out[n] = accumulate ? out[n] + t : t;
   }
 }
 
@@ -163,6 +174,26 @@ __global__ void permute_cols_kernel(const float* src, float* dst, int N, int C, 
       const int c = r / Wd, w = r % Wd;
       dst[i] = src[n * C * Wd + w * C + c];
     }
+  }
+}
+
+// ---------------- windowing + per-speaker z-normalisation ----------------
+// preprocess_adversary_data.py:131 (windows of win frames every shift frames, :71 of the trainer)
+// and :377-378 (x - mean) / (std + 1e-5) per mel bin.  mel (B, T, F) time-major ->
+// out (B * nwin, win, F); window i of clip b starts at frame shift * i.
+__global__ void window_norm_kernel(const float* mel, const float* mean, const float* stdv, float* out, int B, int T,
+                                   int F, int win, int shift, int nwin) {
+  const long total = long(B) * nwin * win * F;
+  GRID_STRIDE(i, total) {
+    const int f = i % F;
+    const int t = (i / F) % win;
+    const long bw = i / (long(F) * win);
+    const int wi = bw % nwin;
+    const long b = bw / nwin;
+    const int src_t = wi * shift + t;
+    float v = src_t < T ? mel[(b * T + src_t) * F + f] : 0.f;  // short clips are zero-padded (:30-35)
+    if (mean) v = (v - mean[f]) / (stdv[f] + 1e-5f);
+    out[i] = v;
   }
 }
 
@@ -277,7 +308,7 @@ extern "C" int sept_mean_t_backward(const float* dz, float* dx, int B, int T, in
 
 extern "C" int sept_colsum(const float* a, long lda, int M, int N, float* out, int accumulate, void* stream) {
   SEPT_REQUIRE(a && out && M >= 0 && N > 0, SEPT_ERR_INVALID, "sept_colsum: bad argument");
-  hipLaunchKernelGGL(colsum_kernel, dim3(blocks_for(N)), dim3(kThreads), 0, ST(stream), a, lda, M, N, out, accumulate);
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 31) / 32), dim3(256), 0, ST(stream), a, lda, M, N, out, accumulate);
   return sept::launch_check("colsum_kernel");
 }
 
@@ -300,6 +331,18 @@ extern "C" int sept_permute_cols(const float* src, float* dst, int N, int C, int
   hipLaunchKernelGGL(permute_cols_kernel, dim3(blocks_for(long(N) * C * Wd)), dim3(kThreads), 0, ST(stream), src, dst,
                      N, C, Wd, inverse);
   return sept::launch_check("permute_cols_kernel");
+}
+
+extern "C" int sept_window_norm(const float* mel_btf, const float* mean, const float* stdv, float* out, int B, int T,
+                                int F, int win, int shift, int nwin, void* stream) {
+  if (B == 0) return SEPT_OK;
+  SEPT_REQUIRE(mel_btf && out && B > 0 && T > 0 && F > 0 && win > 0 && shift > 0 && nwin > 0, SEPT_ERR_INVALID,
+               "sept_window_norm: bad argument");
+  SEPT_REQUIRE((mean == nullptr) == (stdv == nullptr), SEPT_ERR_INVALID, "sept_window_norm: mean/std must come together");
+  const long total = long(B) * nwin * win * F;
+  hipLaunchKernelGGL(window_norm_kernel, dim3(blocks_for(total)), dim3(kThreads), 0, ST(stream), mel_btf, mean, stdv, out,
+                     B, T, F, win, shift, nwin);
+  return sept::launch_check("window_norm_kernel");
 }
 
 extern "C" int sept_sgd_step(float* p, const float* g, float* momentum_buf, long n, float lr, float momentum,

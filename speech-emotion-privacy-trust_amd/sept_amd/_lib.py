@@ -51,7 +51,7 @@ SIGNATURES = {
     "sept_bn_relu_pool_forward": (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p]),
     "sept_bn_relu_pool_backward": (c_int, [c_void_p] * 11 + [c_int] * 5 + [c_void_p]),
     "sept_gemm": (c_int, [c_void_p, c_long, c_long, c_int, c_void_p, c_long, c_long, c_int, c_void_p, c_long, c_int,
-                          c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p]),
+                          c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_long, c_void_p]),
     "sept_gru_forward": (c_int, [c_void_p] * 7 + [c_int] * 3 + [c_void_p]),
     "sept_gru_backward": (c_int, [c_void_p] * 8 + [c_int] * 3 + [c_void_p]),
     "sept_cloak_forward": (c_int, [c_void_p] * 5 + [c_float, c_float, c_void_p, c_int, c_long, c_void_p]),
@@ -69,6 +69,8 @@ SIGNATURES = {
                                    c_void_p]),
     "sept_loss_sub_log": (c_int, [c_void_p, c_void_p, c_float, c_void_p]),
     "sept_permute_cols": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "sept_window_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                 c_void_p]),
     "sept_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float, c_int, c_float,
                               c_void_p]),
     "sept_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float, c_float,

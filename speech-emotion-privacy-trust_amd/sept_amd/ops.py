@@ -9,6 +9,35 @@ def _s(t):
     return current_stream_ptr(t.device)
 
 
+class KernelTimer:
+    """Per-launch HIP-event timing of selected entry points ON the launch stream (torch's
+    current stream is the stream every kernel here is enqueued on).  Used by bench.py for the
+    roofline figure of the dominant kernel; off by default (two event records per launch)."""
+
+    def __init__(self, tags=None):
+        self.tags = tags  # None = time everything that is instrumented
+        self.events = {}
+
+    def start(self, tag):
+        if self.tags is not None and tag not in self.tags:
+            return None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return (tag, e0, e1)
+
+    def stop(self, h):
+        if h is not None:
+            h[2].record()
+            self.events.setdefault(h[0], []).append((h[1], h[2]))
+
+    def summary(self):
+        """tag -> (launches, mean ms); call after torch.cuda.synchronize()."""
+        return {t: (len(ev), sum(a.elapsed_time(b) for a, b in ev) / len(ev)) for t, ev in self.events.items()}
+
+
+TIMER = None  # set to a KernelTimer to collect
+
+
 def conv5x5_prep_weights(w_oihw: torch.Tensor, mode: int = 0, out: torch.Tensor = None) -> torch.Tensor:
     """(cout, cin, 5, 5) fp32 -> bf16 [25][o'][i'] operand (mode 0 forward, 1 data-gradient)."""
     require_cuda(w_oihw)
@@ -35,8 +64,11 @@ def conv5x5(x: torch.Tensor, wt: torch.Tensor, bias: torch.Tensor = None, out: t
         require_cuda(bias)
         assert bias.dtype == torch.float32 and bias.numel() == cout and bias.is_contiguous()
         bp = bias.data_ptr()
+    h = TIMER.start(f"conv5x5_mfma<{cin},{cout}>") if TIMER is not None else None
     check(lib.sept_conv5x5_forward(x.data_ptr(), wt.data_ptr(), bp, out.data_ptr(), B, H, W, cin, cout, _s(x)),
           "sept_conv5x5_forward")
+    if h is not None:
+        TIMER.stop(h)
     return out
 
 
@@ -140,8 +172,11 @@ def conv5x5_backward_weight(x, dy):
     cout = dy.shape[-1]
     ws = workspace("conv_wgrad", lib.sept_conv5x5_wgrad_workspace_floats(cin, cout), x.device)
     dw = torch.empty((cout, cin, 5, 5), dtype=torch.float32, device=x.device)
+    h = TIMER.start(f"conv5x5_wgrad<{cin},{cout}>") if TIMER is not None else None
     check(lib.sept_conv5x5_backward_weight(x.data_ptr(), dy.data_ptr(), ws.data_ptr(), dw.data_ptr(), B, H, W, cin,
                                            cout, _s(x)), "sept_conv5x5_backward_weight")
+    if h is not None:
+        TIMER.stop(h)
     return dw
 
 
@@ -155,8 +190,12 @@ def _is_bf16(t):
 def gemm_raw(A, sam, sak, Bm, sbk, sbn, C, ldc, M, N, K, bias=None, alpha=1.0, beta=0.0):
     """C[M][N] = alpha * A(M,K) B(K,N) (+bias) (+beta*C) with explicit element strides; A/B/C may
     be views (data_ptr carries the offset)."""
+    wsp, wsn = 0, 0
+    if K >= 1024 and ((M + 63) // 64) * ((N + 63) // 64) < 256:   # weight-gradient shape: allow split-K
+        wsn = 16 * M * N
+        wsp = workspace("gemm_splitk", wsn, C.device).data_ptr()
     check(lib.sept_gemm(A.data_ptr(), sam, sak, _is_bf16(A), Bm.data_ptr(), sbk, sbn, _is_bf16(Bm), C.data_ptr(), ldc,
-                        _is_bf16(C), _p(bias), M, N, K, float(alpha), float(beta), _s(C)), "sept_gemm")
+                        _is_bf16(C), _p(bias), M, N, K, float(alpha), float(beta), wsp, wsn, _s(C)), "sept_gemm")
     return C
 
 
@@ -321,3 +360,15 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=
     check(lib.sept_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr),
                              float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
                              float(grad_scale), _s(p)), "sept_adam_step")
+
+
+def window_norm(mel_btf, mean=None, std=None, win=200, shift=50):
+    """mel (B, T, F) fp32 -> (B*nwin, win, F) normalised windows; nwin = int((T - win)/shift) + 1
+    (training_cloak_with_grl.py:71), 1 zero-padded window when T < win."""
+    require_cuda(mel_btf)
+    B, T, F = mel_btf.shape
+    nwin = 1 if T < win else (T - win) // shift + 1
+    out = torch.empty((B * nwin, win, F), dtype=torch.float32, device=mel_btf.device)
+    check(lib.sept_window_norm(mel_btf.data_ptr(), _p(mean), _p(std), out.data_ptr(), B, T, F, win, shift, nwin,
+                               _s(out)), "sept_window_norm")
+    return out

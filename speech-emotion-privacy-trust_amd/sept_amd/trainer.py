@@ -1,0 +1,135 @@
+"""The GRL training step of the reference (training/training_cloak_with_grl.py:122-169) as a
+reusable object: forward through two_d_cnn_lstm_syn_with_grl, the weighted CE + gender CE -
+scale_lamda*log(mean(scales)) loss, backward, and the SGD / Adam update of the trainable set
+(gender adversary + cloak locs/rhos, :416-421) -- all on libsept_hip kernels, sharded by batch
+over ranks with ONE gradient all-reduce (RCCL) per step when a process group is given.
+
+`FusedPipeline` prepends the feature half: waveforms -> mel (time-major) -> 200-frame windows
+every 50 frames, z-normalised -> the step (BASELINE.json config 5).
+"""
+import torch
+
+from . import functional as SF
+from . import ops
+from .mel import LAYOUT_BTF, get_mel_plan
+
+
+class FlatParams:
+    """Packs the trainable parameters into one flat fp32 buffer (parameters become views), so
+    the optimiser is one kernel launch and data-parallel needs one all-reduce over one buffer."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev = self.params[0].device
+        self.numel = sum(p.numel() for p in self.params)
+        self.flat = torch.empty(self.numel, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        off = 0
+        self.views = []
+        for p in self.params:
+            n = p.numel()
+            v = self.flat[off:off + n].view_as(p)
+            v.copy_(p.data)
+            p.data = v
+            self.views.append((off, n))
+            off += n
+
+    def gather_grads(self):
+        """Pack the autograd-produced gradients into the flat gradient buffer (one launch) and
+        expose them as views."""
+        torch.cat([p.grad.reshape(-1) if p.grad is not None else torch.zeros(p.numel(), device=self.flat.device)
+                   for p in self.params], out=self.grad)
+        for p, (off, n) in zip(self.params, self.views):
+            p.grad = self.grad[off:off + n].view_as(p)
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+
+class GrlTrainer:
+    def __init__(self, cloak_model, optimizer="sgd", lr=None, momentum=0.9, weight_decay=1e-4, betas=(0.9, 0.98),
+                 eps=1e-9, gender_lambda=0.1, scale_lamda=0.0, suppression=False, process_group=None):
+        self.model = cloak_model
+        self.flat = FlatParams(cloak_model.parameters())  # filter(requires_grad), as :417/:420
+        self.kind = optimizer
+        if optimizer == "sgd":       # :417  SGD(lr=0.001, momentum=0.9, weight_decay=1e-4)
+            self.lr = 1e-3 if lr is None else lr
+            self.buf = torch.zeros_like(self.flat.flat)
+        elif optimizer == "adam":    # :420  Adam(lr=0.0005, weight_decay=1e-4, betas=(0.9, 0.98), eps=1e-9)
+            self.lr = 5e-4 if lr is None else lr
+            self.m, self.v = torch.zeros_like(self.flat.flat), torch.zeros_like(self.flat.flat)
+        else:
+            raise ValueError(f"unknown optimizer {optimizer}")
+        self.momentum, self.weight_decay, self.betas, self.eps = momentum, weight_decay, betas, eps
+        self.gender_lambda, self.scale_lamda, self.suppression = gender_lambda, scale_lamda, suppression
+        self.steps = 0
+        self.pg = process_group
+        self.world = 1
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self.world = torch.distributed.get_world_size(process_group)
+
+    def loss(self, preds, preds_grl, labels_emo, labels_gen, weights, training=True):
+        noise = self.model.intermed
+        rhos = None if self.suppression else noise.rhos
+        w = weights if training else None  # validate mode drops the speaker weights (:153-154)
+        return SF.GrlStepLossFn.apply(preds, preds_grl, labels_emo, labels_gen, w, self.gender_lambda,
+                                      self.scale_lamda, rhos, float(noise.min_scale), float(noise.max_scale))
+
+    def optimizer_step(self):
+        f = self.flat
+        gscale = 1.0 / self.world
+        self.steps += 1
+        if self.kind == "sgd":
+            ops.sgd_step(f.flat, f.grad, self.buf, self.lr, self.momentum, self.weight_decay, self.steps == 1, gscale)
+        else:
+            ops.adam_step(f.flat, f.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps,
+                          self.weight_decay, self.steps, gscale)
+        SF.invalidate_weight_cache()  # parameters changed through raw pointers
+
+    def train_step(self, features, labels_emo, labels_gen, weights=None, mask=None, pooling="mean"):
+        """One iteration of the batch loop (:122-169) on this rank's shard.  Returns
+        (loss, preds, preds_grl); loss is a 0-dim device tensor (no host sync here)."""
+        self.model.train()
+        self.flat.zero_grad()
+        preds, preds_grl, _ = self.model(features, mask=mask, grl=False, pooling=pooling)
+        loss = self.loss(preds, preds_grl, labels_emo, labels_gen, weights, training=True)
+        loss.backward()
+        self.flat.gather_grads()
+        if self.world > 1:
+            # the loss is a mean over the local shard (:150-151), so averaging equal shards gives
+            # the global-batch gradient; the scale term is batch independent and survives averaging
+            torch.distributed.all_reduce(self.flat.grad, group=self.pg)
+        self.optimizer_step()
+        return loss.detach(), preds.detach(), preds_grl.detach()
+
+    @torch.no_grad()
+    def eval_step(self, features, labels_emo, labels_gen, mask=None, pooling="mean"):
+        self.model.eval()
+        preds, preds_grl, _ = self.model(features, mask=mask, grl=False, pooling=pooling)
+        return self.loss(preds, preds_grl, labels_emo, labels_gen, None, training=False), preds, preds_grl
+
+
+class FusedPipeline:
+    """waveforms (B, L) on the device -> mel(n_fft 800, F) -> windows -> z-norm -> GRL step."""
+
+    def __init__(self, trainer: GrlTrainer, n_mels=80, n_fft=800, win=200, shift=50, mean=None, std=None):
+        self.trainer, self.n_mels, self.n_fft, self.win, self.shift = trainer, n_mels, n_fft, win, shift
+        self.plan = get_mel_plan(n_fft, n_mels)
+        self.mean, self.std = mean, std
+
+    def features(self, wav):
+        mel = self.plan.forward(wav, LAYOUT_BTF)                       # (B, T, F)
+        return ops.window_norm(mel, self.mean, self.std, self.win, self.shift)  # (B*nwin, win, F)
+
+    def windows_per_clip(self, length):
+        T = 1 + length // 160
+        return 1 if T < self.win else (T - self.win) // self.shift + 1
+
+    def train_step(self, wav, labels_emo_w, labels_gen_w, weights_w=None):
+        """labels/weights are per WINDOW (clip label repeated for each of its windows)."""
+        x = self.features(wav)
+        return self.trainer.train_step(x.view(x.shape[0], 1, self.win, self.n_mels), labels_emo_w, labels_gen_w,
+                                       weights_w)

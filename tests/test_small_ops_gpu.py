@@ -1,0 +1,155 @@
+"""GPU parity of the GEMM / GRU / small kernels against fp32 torch on the CPU.
+Reference layers: nn.Linear / nn.GRU of two_d_cnn_lstm (model/baseline_models.py:191-210),
+cloak_noise (cloak_models.py:24-58), train() loss (training_cloak_with_grl.py:143-160),
+optimisers (:416-421)."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("M,N,K", [(5600, 192, 1280), (224, 128, 128), (224, 4, 128), (200, 192, 2048), (37, 53, 71),
+                                   (64, 64, 32), (1, 2, 3)])
+@pytest.mark.parametrize("abf16", [False, True])
+def test_linear_three_products(M, N, K, abf16):
+    from sept_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g)
+    if abf16:
+        x = x.bfloat16()
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    dy = torch.randn(M, N, generator=g)
+    xf = x.float()
+    y = ops.linear_forward(x.cuda(), W.cuda(), b.cuda()).cpu()
+    assert torch.allclose(y, xf @ W.t() + b, rtol=1e-4, atol=1e-4)
+    dx = ops.linear_backward_input(dy.cuda(), W.cuda()).cpu()
+    assert torch.allclose(dx, dy @ W, rtol=1e-4, atol=1e-4)
+    dW = ops.linear_backward_weight(dy.cuda(), x.cuda()).cpu()      # split-K path when K(=M) is long
+    want = dy.t() @ xf
+    assert torch.allclose(dW, want, rtol=1e-4, atol=1e-4 * want.abs().max())
+    assert torch.equal(dW, ops.linear_backward_weight(dy.cuda(), x.cuda()).cpu())   # deterministic
+    assert torch.allclose(ops.colsum(dy.cuda()).cpu(), dy.sum(0), rtol=1e-4, atol=1e-4)
+    # strided views + bf16 output + beta accumulate (the GRU dx path)
+    out = torch.zeros(M, K, dtype=torch.bfloat16, device="cuda")
+    ops.gemm_raw(dy.cuda(), N, 1, W.cuda(), K, 1, out, K, M, K, N)
+    ops.gemm_raw(dy.cuda(), N, 1, W.cuda(), K, 1, out, K, M, K, N, beta=1.0)
+    assert torch.allclose(out.float().cpu(), 2 * (dy @ W), rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("B,T", [(7, 25), (4, 3), (1, 1)])
+def test_gru_layer_forward_backward(B, T):
+    """One bidirectional GRU layer (input projections by sept_gemm + recurrent kernel) vs nn.GRU."""
+    from sept_amd import ops
+    torch.manual_seed(B)
+    K, H = 48, 64
+    ref = nn.GRU(K, H, num_layers=1, batch_first=True, bidirectional=True)
+    x = torch.randn(B, T, K, requires_grad=True)
+    want, _ = ref(x)
+    dout = torch.randn(B, T, 2 * H)
+    want.backward(dout)
+    P = {n: p.detach().cuda() for n, p in ref.named_parameters()}
+    xc = x.detach().cuda().view(B * T, K)
+    gi = torch.empty(B * T, 384, device="cuda")
+    ops.gemm_raw(xc, K, 1, P["weight_ih_l0"], 1, K, gi, 384, B * T, 192, K, P["bias_ih_l0"])
+    ops.gemm_raw(xc, K, 1, P["weight_ih_l0_reverse"], 1, K, gi[:, 192:], 384, B * T, 192, K, P["bias_ih_l0_reverse"])
+    out, gates = ops.gru_forward(gi.view(B, T, 2, 192), P["weight_hh_l0"], P["weight_hh_l0_reverse"],
+                                 P["bias_hh_l0"], P["bias_hh_l0_reverse"])
+    assert torch.allclose(out.cpu(), want.detach(), rtol=1e-4, atol=1e-5)
+    dgi, dgh, hprev = ops.gru_backward(dout.cuda(), out, gates, P["weight_hh_l0"], P["weight_hh_l0_reverse"])
+    dgi2, dgh2, hp2 = dgi.view(B * T, 384), dgh.view(B * T, 384), hprev.view(B * T, 128)
+    for d, tag in ((0, ""), (1, "_reverse")):
+        gs, gh = dgi2[:, d * 192:(d + 1) * 192], dgh2[:, d * 192:(d + 1) * 192]
+        grads = dict(ref.named_parameters())
+        chk = [("weight_ih_l0" + tag, ops.linear_backward_weight(gs, xc)),
+               ("weight_hh_l0" + tag, ops.linear_backward_weight(gh, hp2[:, d * 64:(d + 1) * 64])),
+               ("bias_ih_l0" + tag, ops.colsum(gs)), ("bias_hh_l0" + tag, ops.colsum(gh))]
+        for name, got in chk:
+            w = grads[name].grad
+            assert torch.allclose(got.cpu(), w, rtol=1e-3, atol=1e-5 + 1e-4 * w.abs().max()), name
+    dx = torch.empty(B * T, K, device="cuda")
+    ops.gemm_raw(dgi2, 384, 1, P["weight_ih_l0"], K, 1, dx, K, B * T, K, 192)
+    ops.gemm_raw(dgi2[:, 192:], 384, 1, P["weight_ih_l0_reverse"], K, 1, dx, K, B * T, K, 192, beta=1.0)
+    assert torch.allclose(dx.cpu().view(B, T, K), x.grad, rtol=1e-3, atol=1e-5)
+
+
+def test_cloak_and_loss_and_small_ops():
+    from sept_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, Wn, Fm = 5, 20, 16
+    x = torch.randn(B, Wn * Fm, generator=g)
+    locs = (0.1 * torch.randn(1, Wn, Fm, generator=g)).requires_grad_()
+    rhos = (-2 + 0.5 * torch.randn(1, Wn, Fm, generator=g)).requires_grad_()
+    eps = 0.1 * torch.randn(1, Wn, Fm, generator=g)
+    mask = (torch.rand(1, Wn, Fm, generator=g) > 0.3).float()
+    for m in (None, mask):
+        locs.grad = rhos.grad = None
+        scales = (1 + torch.tanh(rhos)) / 2 * (10 - 0.01) + 0.01
+        e = eps if m is None else eps * m
+        want = (x.view(B, 1, Wn, Fm) if m is None else x.view(B, 1, Wn, Fm) * m) + locs + scales * e
+        dxa, dxb = torch.randn(B, Wn * Fm, generator=g), torch.randn(B, Wn * Fm, generator=g)
+        (want.view(B, -1) * (dxa - 0.1 * dxb)).sum().backward(retain_graph=True)
+        (-0.05 * torch.log(scales.mean())).backward()
+        mc = None if m is None else m.cuda()
+        xn = ops.cloak_forward(x.cuda(), locs.detach().cuda(), rhos.detach().cuda(), eps.cuda(), mc, 0.01, 10.0)
+        assert torch.allclose(xn.cpu(), want.detach().view(B, -1), rtol=1e-5, atol=1e-6)
+        _, mean = ops.cloak_scales(rhos.detach().cuda(), 0.01, 10.0, want_scales=False, want_mean=True)
+        assert float(mean) == pytest.approx(float(scales.mean()), rel=1e-5)
+        dl, dr = ops.cloak_backward(dxa.cuda(), dxb.cuda(), -0.1, rhos.detach().cuda(), eps.cuda(), mc, 0.01, 10.0,
+                                    scale_lambda=0.05, scale_mean=mean)
+        assert torch.allclose(dl.cpu(), locs.grad, rtol=1e-4, atol=1e-6)
+        assert torch.allclose(dr.cpu(), rhos.grad, rtol=1e-4, atol=1e-7)
+    # weighted CE
+    logits = torch.randn(9, 4, generator=g, requires_grad=True)
+    lab = torch.randint(0, 4, (9,), generator=g)
+    w = 1 + torch.rand(9, generator=g)
+    want = (F.cross_entropy(logits, lab, reduction="none") * w).sum() * (0.1 / 9)
+    want.backward()
+    loss = torch.zeros((), device="cuda")
+    d = ops.cross_entropy(logits.detach().cuda(), lab.cuda(), w.cuda(), 0.1 / 9, loss)
+    assert float(loss) == pytest.approx(float(want), rel=1e-5)
+    assert torch.allclose(d.cpu(), logits.grad, rtol=1e-4, atol=1e-7)
+    # mean over time, relu+dropout, permutation round trip, window/norm
+    x3 = torch.randn(4, 25, 128, generator=g)
+    assert torch.allclose(ops.mean_t_forward(x3.cuda()).cpu(), x3.mean(1), atol=1e-6)
+    dz = torch.randn(4, 128, generator=g)
+    assert torch.allclose(ops.mean_t_backward(dz.cuda(), 25).cpu(), (dz / 25)[:, None].expand(4, 25, 128), atol=1e-7)
+    m2 = (torch.rand(4, 128, generator=g) > 0.2).float() / 0.8
+    y = ops.relu_dropout_forward(dz.cuda(), m2.cuda()).cpu()
+    assert torch.allclose(y, F.relu(dz) * m2)
+    assert torch.allclose(ops.relu_dropout_backward(dz.cuda(), dz.cuda(), m2.cuda()).cpu(), (dz > 0) * dz * m2)
+    Wm = torch.randn(6, 5 * 7, generator=g)
+    pw = ops.permute_cols(Wm.cuda(), 5, 7)
+    assert torch.equal(pw.cpu().view(6, 7, 5), Wm.view(6, 5, 7).transpose(1, 2))
+    assert torch.equal(ops.permute_cols(pw, 5, 7, inverse=True).cpu(), Wm)
+    mel = torch.randn(3, 501, 8, generator=g)
+    mu, sd = torch.randn(8, generator=g), torch.rand(8, generator=g) + 0.5
+    wn = ops.window_norm(mel.cuda(), mu.cuda(), sd.cuda()).cpu()
+    assert wn.shape == (21, 200, 8)
+    want = torch.stack([(mel[b, 50 * i:50 * i + 200] - mu) / (sd + 1e-5) for b in range(3) for i in range(7)])
+    assert torch.allclose(wn, want, rtol=1e-5, atol=1e-6)
+    short = ops.window_norm(mel[:, :120].cuda()).cpu()       # T < win: one zero-padded window
+    assert short.shape == (3, 200, 8) and torch.equal(short[:, :120], mel[:, :120]) and (short[:, 120:] == 0).all()
+
+
+@pytest.mark.parametrize("kind", ["sgd", "adam"])
+def test_optimizer_steps_match_torch(kind):
+    from sept_amd import ops
+    g = torch.Generator().manual_seed(1)
+    p0 = torch.randn(1000, generator=g)
+    ref = p0.clone().requires_grad_()
+    opt = torch.optim.SGD([ref], lr=1e-3, momentum=0.9, weight_decay=1e-4) if kind == "sgd" else \
+        torch.optim.Adam([ref], lr=5e-4, weight_decay=1e-4, betas=(0.9, 0.98), eps=1e-9)
+    p = p0.clone().cuda()
+    b1, b2 = torch.zeros_like(p), torch.zeros_like(p)
+    for step in range(1, 4):
+        gr = torch.randn(1000, generator=g)
+        ref.grad = gr.clone()
+        opt.step()
+        if kind == "sgd":
+            ops.sgd_step(p, (2 * gr).cuda(), b1, 1e-3, 0.9, 1e-4, step == 1, grad_scale=0.5)
+        else:
+            ops.adam_step(p, (2 * gr).cuda(), b1, b2, 5e-4, 0.9, 0.98, 1e-9, 1e-4, step, grad_scale=0.5)
+        assert torch.allclose(p.cpu(), ref.detach(), rtol=1e-5, atol=1e-7), step
