@@ -181,8 +181,9 @@ int sept_relu_dropout_backward(const float* dy, const float* x, const float* dro
 /* z[B][D] = mean over T of x[B][T][D]  (torch.mean(x, dim=1), baseline_models.py:232) */
 int sept_mean_t_forward(const float* x, float* z, int B, int T, int D, void* stream);
 int sept_mean_t_backward(const float* dz, float* dx, int B, int T, int D, void* stream);
-/* out[N] (+)= column sums of a[M][lda]  (bias gradients) */
-int sept_colsum(const float* a, long lda, int M, int N, float* out, int accumulate, void* stream);
+/* out[N] (+)= column sums of a[M][lda]  (bias gradients); ws holds sept_colsum_workspace_floats(N) */
+size_t sept_colsum_workspace_floats(int N);
+int sept_colsum(const float* a, long lda, int M, int N, float* ws, float* out, int accumulate, void* stream);
 /* loss (+)= scale * sum_i w_i CE(logits_i, labels_i);  dlogits = scale * w_i * (softmax - onehot)
  * (the per-sample loop of train(), training_cloak_with_grl.py:143-154; weights nullable) */
 int sept_cross_entropy(const float* logits, const long long* labels, const float* weights, float scale, int B,

@@ -11,10 +11,12 @@
 // (4 pixels x 16 channels per 16-lane group, delivered column-major), so no transposed copy
 // of either tensor is ever written.
 //
-// grid = (G workgroups, 1, Z): z selects the kernel row kh (5 taps), a slice of MBZ*32 output
-// channels and a slice of NBZ*32 input channels; every wave keeps all 5*MBZ*NBZ accumulator
-// blocks of its slice in registers across ALL tiles the workgroup walks (128 pixels per
-// tile, 32 per wave), so the only cross-workgroup traffic is one partial slab per workgroup,
+// grid = (G workgroups, 1, Z): z selects a slice of MBZ*32 output channels and NBZ*32 input
+// channels.  A workgroup walks many 128-pixel tiles; per tile the input rows (+halo) and the dY
+// rows are staged ONCE in LDS (double-buffered, next tile prefetched into registers under the
+// MFMAs) and reused by all 25 taps: wave w owns taps {w, w+4, ...} for every pixel of the tile,
+// so its 7*MBZ*NBZ accumulator blocks persist in registers across ALL tiles and no cross-wave
+// reduction is needed.  The only cross-workgroup traffic is one partial slab per workgroup,
 // summed in fixed order by a finalize kernel (deterministic, no float atomics).
 #include <algorithm>
 
@@ -28,14 +30,14 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int kMT = 128;
-constexpr int kTotalWG = 768;  // ~3 workgroups per CU over all z-slices
+constexpr int kXCH = 13;  // max 16-byte input chunks a lane prefetches per tile
 
 __host__ __device__ constexpr int wg_nr_max(int w) { return (kMT + w - 2) / w + 5; }
 
 struct WgArgs {
   const bf16* x;   // [B][H][W][CIN]
   const bf16* dy;  // [B][H][W][COUT]
-  float* ws;       // partial slabs [Z][G][5*MBZ*NBZ*1024]
+  float* ws;       // partial slabs [Z][G][25*MBZ*NBZ*1024]
   int B, H, W, nr_max;
 };
 
@@ -47,69 +49,112 @@ __device__ __forceinline__ bf16x4 lds_tr(const unsigned char* p) {
 template <int CIN, int COUT, int MBZ, int NBZ>
 __global__ __launch_bounds__(256) void sept_conv5x5_wgrad_kernel(WgArgs a) {
   constexpr int MSL = COUT / 32 / MBZ;  // output-channel slices
-  constexpr int NSL = CIN / 32 / NBZ;   // input-channel slices
   constexpr int CX = NBZ * 32, CY = MBZ * 32;
   constexpr int PSX = CX * 2 + 16, PSY = CY * 2 + 16;
-  constexpr int NBLK = 5 * MBZ * NBZ;
+  constexpr int CPP = CX / 8, CPY = CY / 8;
+  constexpr int YCH = (kMT * CPY) / 256;
+  constexpr int NT = 7;  // taps per wave (wave 0: 7, others: 6)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int W = a.W, H = a.H, HW = H * W, W4 = W + 4;
-  unsigned char* xt = smem;
-  unsigned char* yt = smem + size_t(a.nr_max) * W4 * PSX;
+  const size_t xbytes = size_t(a.nr_max) * W4 * PSX;
+  const size_t bufbytes = xbytes + size_t(kMT) * PSY;
 
   const int z = blockIdx.z;
-  const int kh = z % 5, msl = (z / 5) % MSL, nsl = z / (5 * MSL);
+  const int msl = z % MSL, nsl = z / MSL;
   const int cout0 = msl * CY, cin0 = nsl * CX;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // transposing-read lane roles: row q of the 4-pixel block, 4-channel column chunk p
   const int tr_q = (lane & 15) >> 2;
   const int tr_ch = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
   const int k_hi = lane >> 5;
 
-  f32x16 acc[5][MBZ][NBZ];
+  f32x16 acc[NT][MBZ][NBZ];
 #pragma unroll
-  for (int t = 0; t < 5; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int mb = 0; mb < MBZ; ++mb)
 #pragma unroll
       for (int nb = 0; nb < NBZ; ++nb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][mb][nb][r] = 0.f;
+  int tapoff[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int tap = min(wave + 4 * j, 24);
+    tapoff[j] = ((tap / 5) * W4 + (tap % 5)) * PSX;
+  }
 
   const int tiles_per_img = (HW + kMT - 1) / kMT;
   const long n_tiles = long(a.B) * tiles_per_img;
-  for (long tile_id = blockIdx.x; tile_id < n_tiles; tile_id += gridDim.x) {
-    const int b = tile_id / tiles_per_img;
-    const int q0 = int(tile_id % tiles_per_img) * kMT;
-    const int h_first = q0 / W;
-    const int h_last = min(q0 + kMT - 1, HW - 1) / W;
-    const int NR = h_last - h_first + 5;
-    __syncthreads();  // previous tile's reads are done
-    {
-      const bf16* xb = a.x + size_t(b) * HW * CIN + cin0;
-      constexpr int CPP = CX / 8;
-      const int total = NR * W4 * CPP;
-      for (int i = tid; i < total; i += 256) {
+
+  uint4 xr[kXCH], yr[YCH];
+  auto tile_geom = [&](long tile_id, int& b, int& q0, int& h_first, int& NR) {
+    b = tile_id / tiles_per_img;
+    q0 = int(tile_id % tiles_per_img) * kMT;
+    h_first = q0 / W;
+    NR = min(q0 + kMT - 1, HW - 1) / W - h_first + 5;
+  };
+  auto gload = [&](long tile_id) {
+    int b, q0, h_first, NR;
+    tile_geom(tile_id, b, q0, h_first, NR);
+    const bf16* xb = a.x + size_t(b) * HW * CIN + cin0;
+    const int total = NR * W4 * CPP;
+#pragma unroll
+    for (int j = 0; j < kXCH; ++j) {
+      const int i = tid + 256 * j;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (i < total) {
         const int c = i % CPP, px = i / CPP;
         const int col = px % W4, row = px / W4;
         const int h = h_first - 2 + row, w = col - 2;
-        uint4 v = make_uint4(0, 0, 0, 0);
         if (h >= 0 && h < H && w >= 0 && w < W)
           v = *reinterpret_cast<const uint4*>(xb + (size_t(h) * W + w) * CIN + c * 8);
-        *reinterpret_cast<uint4*>(xt + size_t(px) * PSX + c * 16) = v;
       }
-      const bf16* yb = a.dy + size_t(b) * HW * COUT + cout0;
-      constexpr int CPY = CY / 8;
-      for (int i = tid; i < kMT * CPY; i += 256) {
-        const int c = i % CPY, t = i / CPY;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (q0 + t < HW) v = *reinterpret_cast<const uint4*>(yb + size_t(q0 + t) * COUT + c * 8);
-        *reinterpret_cast<uint4*>(yt + size_t(t) * PSY + c * 16) = v;
-      }
+      xr[j] = v;
     }
-    __syncthreads();
+    const bf16* yb = a.dy + size_t(b) * HW * COUT + cout0;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int kb = wave * 32 + ks * 16 + 8 * k_hi + tr_q;  // this lane's block row, first half
+    for (int j = 0; j < YCH; ++j) {
+      const int i = tid + 256 * j;
+      const int c = i % CPY, t = i / CPY;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (q0 + t < HW) v = *reinterpret_cast<const uint4*>(yb + size_t(q0 + t) * COUT + c * 8);
+      yr[j] = v;
+    }
+  };
+  auto lstore = [&](long tile_id, unsigned char* buf) {
+    int b, q0, h_first, NR;
+    tile_geom(tile_id, b, q0, h_first, NR);
+    const int total = NR * W4 * CPP;
+#pragma unroll
+    for (int j = 0; j < kXCH; ++j) {
+      const int i = tid + 256 * j;
+      if (i < total) *reinterpret_cast<uint4*>(buf + size_t(i / CPP) * PSX + (i % CPP) * 16) = xr[j];
+    }
+    unsigned char* yt = buf + xbytes;
+#pragma unroll
+    for (int j = 0; j < YCH; ++j) {
+      const int i = tid + 256 * j;
+      *reinterpret_cast<uint4*>(yt + size_t(i / CPY) * PSY + (i % CPY) * 16) = yr[j];
+    }
+  };
+
+  long tile_id = blockIdx.x;
+  if (tile_id < n_tiles) {
+    gload(tile_id);
+    lstore(tile_id, smem);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (; tile_id < n_tiles; tile_id += gridDim.x, cur ^= 1) {
+    const long next = tile_id + gridDim.x;
+    if (next < n_tiles) gload(next);  // in flight under the MFMAs below
+    int b, q0, h_first, NR;
+    tile_geom(tile_id, b, q0, h_first, NR);
+    const unsigned char* xt = smem + size_t(cur) * bufbytes;
+    const unsigned char* yt = xt + xbytes;
+#pragma unroll 2
+    for (int ks = 0; ks < kMT / 16; ++ks) {
+      const int kb = ks * 16 + 8 * k_hi + tr_q;
       const unsigned char* ya[2];
       const unsigned char* xa[2];
 #pragma unroll
@@ -118,7 +163,7 @@ __global__ __launch_bounds__(256) void sept_conv5x5_wgrad_kernel(WgArgs a) {
         ya[half] = yt + size_t(t) * PSY + tr_ch * 2;
         const int q = min(q0 + t, HW - 1);
         const int h = q / W, w = q - h * W;
-        xa[half] = xt + size_t((h - h_first + kh) * W4 + w) * PSX + tr_ch * 2;
+        xa[half] = xt + size_t((h - h_first) * W4 + w) * PSX + tr_ch * 2;
       }
       bf16x8 afrag[MBZ];
 #pragma unroll
@@ -127,71 +172,70 @@ __global__ __launch_bounds__(256) void sept_conv5x5_wgrad_kernel(WgArgs a) {
         afrag[mb] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
       }
 #pragma unroll
-      for (int kw = 0; kw < 5; ++kw) {
+      for (int j = 0; j < NT; ++j) {
+        if (j == NT - 1 && wave != 0) break;  // taps 24.. only exist for wave 0 (wave-uniform)
 #pragma unroll
         for (int nb = 0; nb < NBZ; ++nb) {
-          const bf16x4 lo = lds_tr(xa[0] + kw * PSX + nb * 64), hi = lds_tr(xa[1] + kw * PSX + nb * 64);
+          const bf16x4 lo = lds_tr(xa[0] + tapoff[j] + nb * 64), hi = lds_tr(xa[1] + tapoff[j] + nb * 64);
           const bf16x8 bfrag = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
           for (int mb = 0; mb < MBZ; ++mb)
-            acc[kw][mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[mb], bfrag, acc[kw][mb][nb], 0, 0, 0);
+            acc[j][mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[mb], bfrag, acc[j][mb][nb], 0, 0, 0);
         }
       }
     }
+    if (next < n_tiles) lstore(next, smem + size_t(cur ^ 1) * bufbytes);
+    __syncthreads();
   }
 
-  // ---- fixed-order sum of the four waves through LDS, then one slab per workgroup ----
-  float* red = reinterpret_cast<float*>(smem);  // [NBLK][16][64]
-  for (int wv = 0; wv < 4; ++wv) {
-    __syncthreads();
-    if (wave == wv) {
+  // ---- one slab per workgroup: [tap 25][MBZ][NBZ][16][64] ----
+  float* slab = a.ws + (size_t(z) * gridDim.x + blockIdx.x) * (25 * MBZ * NBZ * 1024);
 #pragma unroll
-      for (int t = 0; t < 5; ++t)
+  for (int j = 0; j < NT; ++j) {
+    const int tap = wave + 4 * j;
+    if (tap >= 25) break;
 #pragma unroll
-        for (int mb = 0; mb < MBZ; ++mb)
+    for (int mb = 0; mb < MBZ; ++mb)
 #pragma unroll
-          for (int nb = 0; nb < NBZ; ++nb)
+      for (int nb = 0; nb < NBZ; ++nb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              float* p = red + (((t * MBZ + mb) * NBZ + nb) * 16 + r) * 64 + lane;
-              *p = (wv == 0 ? 0.f : *p) + acc[t][mb][nb][r];
-            }
-    }
+        for (int r = 0; r < 16; ++r)
+          slab[(((size_t(tap) * MBZ + mb) * NBZ + nb) * 16 + r) * 64 + lane] = acc[j][mb][nb][r];
   }
-  __syncthreads();
-  float* slab = a.ws + (size_t(z) * gridDim.x + blockIdx.x) * (NBLK * 1024);
-  for (int i = tid; i < NBLK * 1024; i += 256) slab[i] = red[i];
 }
 
 // sums the G slabs of each z-slice in fixed order and scatters into OIHW fp32
 template <int CIN, int COUT, int MBZ, int NBZ>
 __global__ void sept_conv5x5_wgrad_finalize_kernel(const float* ws, int G, float* dw) {
   constexpr int MSL = COUT / 32 / MBZ;
-  constexpr int NBLK = 5 * MBZ * NBZ;
+  constexpr int NBLK = 25 * MBZ * NBZ;
   const int z = blockIdx.y;
-  const int kh = z % 5, msl = (z / 5) % MSL, nsl = z / (5 * MSL);
+  const int msl = z % MSL, nsl = z / MSL;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= NBLK * 1024) return;
   float s = 0.f;
   for (int g = 0; g < G; ++g) s += ws[(size_t(z) * G + g) * (NBLK * 1024) + e];
   const int lane = e & 63, r = (e >> 6) & 15, blk = e >> 10;
-  const int nb = blk % NBZ, mb = (blk / NBZ) % MBZ, kw = blk / (NBZ * MBZ);
+  const int nb = blk % NBZ, mb = (blk / NBZ) % MBZ, tap = blk / (NBZ * MBZ);
   const int cout = msl * MBZ * 32 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
   const int cin = nsl * NBZ * 32 + nb * 32 + (lane & 31);
-  dw[((size_t(cout) * CIN + cin) * 5 + kh) * 5 + kw] = s;
+  dw[(size_t(cout) * CIN + cin) * 25 + tap] = s;
 }
+
+constexpr int kSlabFloats = 25 * 2 * 1024;  // every supported shape has MBZ * NBZ = 2
+constexpr int kTotalWG = 256;               // one 4-wave workgroup per CU (accumulators fill the VGPR file)
 
 template <int CIN, int COUT, int MBZ, int NBZ>
 int launch_wgrad(const WgArgs& a0, float* dw, hipStream_t st) {
+  static_assert(MBZ * NBZ == 2, "slab size");
   WgArgs a = a0;
-  constexpr int Z = 5 * (COUT / 32 / MBZ) * (CIN / 32 / NBZ);
-  constexpr int NBLK = 5 * MBZ * NBZ;
+  constexpr int Z = (COUT / 32 / MBZ) * (CIN / 32 / NBZ);
+  constexpr int NBLK = 25 * MBZ * NBZ;
   constexpr int PSX = NBZ * 64 + 16, PSY = MBZ * 64 + 16;
   a.nr_max = wg_nr_max(a.W);
-  const size_t tile_bytes = size_t(a.nr_max) * (a.W + 4) * PSX + size_t(kMT) * PSY;
-  const size_t smem = std::max(tile_bytes, size_t(NBLK) * 4096);
-  SEPT_REQUIRE(smem <= 160 * 1024, SEPT_ERR_UNSUPPORTED, "sept_conv5x5_backward_weight: W=%d needs %zu B of LDS",
-               a.W, smem);
+  const size_t smem = 2 * (size_t(a.nr_max) * (a.W + 4) * PSX + size_t(kMT) * PSY);
+  SEPT_REQUIRE(smem <= 160 * 1024 && a.nr_max * (a.W + 4) * (NBZ * 4) <= kXCH * 256, SEPT_ERR_UNSUPPORTED,
+               "sept_conv5x5_backward_weight: W=%d is too wide for the LDS tile (%zu B)", a.W, smem);
   const long n_tiles = long(a.B) * ((a.H * a.W + kMT - 1) / kMT);
   const int G = int(std::min<long>(n_tiles, std::max(1, kTotalWG / Z)));
   const void* fn = reinterpret_cast<const void*>(&sept_conv5x5_wgrad_kernel<CIN, COUT, MBZ, NBZ>);
@@ -205,10 +249,10 @@ int launch_wgrad(const WgArgs& a0, float* dw, hipStream_t st) {
 }  // namespace
 
 extern "C" size_t sept_conv5x5_wgrad_workspace_floats(int cin, int cout) {
-  // Z * G * NBLK * 1024 floats with NBLK = 10 and Z * G <= kTotalWG for every supported shape
+  // Z * G slabs of kSlabFloats with Z * G <= kTotalWG for every supported shape
   (void)cin;
   (void)cout;
-  return size_t(kTotalWG) * 10 * 1024;
+  return size_t(kTotalWG) * kSlabFloats;
 }
 
 extern "C" int sept_conv5x5_backward_weight(const void* x, const void* dy, float* ws, float* dw, int B, int H,

@@ -103,23 +103,31 @@ __global__ void mean_t_bwd_kernel(const float* dz, float* dx, int B, int T, int 
   }
 }
 
-// out[n] (+)= sum_m a[m][n]: a block owns 32 columns; 8 row-lanes stride the rows (128-byte
-// row segments), then a fixed-order LDS tree over the row-lanes.
-__global__ __launch_bounds__(256) void colsum_kernel(const float* a, long lda, int M, int N, float* out,
-                                                     int accumulate) {
+// out[n] (+)= sum_m a[m][n]: block (x, y) owns 32 columns and every gridDim.y-th group of 8
+// rows; row-lane partials meet in LDS, row-block partials in a small workspace that the last
+// pass sums in fixed order (deterministic; no atomics).
+constexpr int kColsumRows = 32;  // max row blocks (workspace rows)
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* a, long lda, int M, int N, float* part) {
   __shared__ float red[8][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int n = blockIdx.x * 32 + tx;
   float s = 0.f;
   if (n < N)
-    for (int m = ty; m < M; m += 8) s += a[size_t(m) * lda + n];
+    for (int m = blockIdx.y * 8 + ty; m < M; m += 8 * gridDim.y) s += a[size_t(m) * lda + n];
   red[ty][tx] = s;
   __syncthreads();
   if (ty == 0 && n < N) {
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) t += red[k][tx];
-    out[n] = accumulate ? out[n] + t : t;
+    part[size_t(blockIdx.y) * N + n] = t;
+  }
+}
+__global__ void colsum_final_kernel(const float* part, int R, int N, float* out, int accumulate) {
+  GRID_STRIDE(n, N) {
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += part[size_t(r) * N + n];
+    out[n] = accumulate ? out[n] + s : s;
   }
 }
 
@@ -306,9 +314,14 @@ extern "C" int sept_mean_t_backward(const float* dz, float* dx, int B, int T, in
   return sept::launch_check("mean_t_bwd_kernel");
 }
 
-extern "C" int sept_colsum(const float* a, long lda, int M, int N, float* out, int accumulate, void* stream) {
-  SEPT_REQUIRE(a && out && M >= 0 && N > 0, SEPT_ERR_INVALID, "sept_colsum: bad argument");
-  hipLaunchKernelGGL(colsum_kernel, dim3((N + 31) / 32), dim3(256), 0, ST(stream), a, lda, M, N, out, accumulate);
+extern "C" size_t sept_colsum_workspace_floats(int N) { return size_t(kColsumRows) * size_t(N); }
+
+extern "C" int sept_colsum(const float* a, long lda, int M, int N, float* ws, float* out, int accumulate,
+                           void* stream) {
+  SEPT_REQUIRE(a && out && ws && M >= 0 && N > 0, SEPT_ERR_INVALID, "sept_colsum: bad argument");
+  const int R = std::max(1, std::min(kColsumRows, M / 64));
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 31) / 32, R), dim3(256), 0, ST(stream), a, lda, M, N, ws);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(blocks_for(N)), dim3(kThreads), 0, ST(stream), ws, R, N, out, accumulate);
   return sept::launch_check("colsum_kernel");
 }
 

@@ -64,7 +64,8 @@ SIGNATURES = {
     "sept_relu_dropout_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
     "sept_mean_t_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "sept_mean_t_backward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
-    "sept_colsum": (c_int, [c_void_p, c_long, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "sept_colsum_workspace_floats": (c_size_t, [c_int]),
+    "sept_colsum": (c_int, [c_void_p, c_long, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "sept_cross_entropy": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_void_p, c_int,
                                    c_void_p]),
     "sept_loss_sub_log": (c_int, [c_void_p, c_void_p, c_float, c_void_p]),

@@ -230,7 +230,9 @@ def colsum(a, out=None, accumulate=False):
     M, N = a.shape
     if out is None:
         out = torch.empty(N, dtype=torch.float32, device=a.device)
-    check(lib.sept_colsum(a.data_ptr(), a.stride(0), M, N, out.data_ptr(), int(accumulate), _s(a)), "sept_colsum")
+    ws = workspace("colsum", lib.sept_colsum_workspace_floats(N), a.device)
+    check(lib.sept_colsum(a.data_ptr(), a.stride(0), M, N, ws.data_ptr(), out.data_ptr(), int(accumulate), _s(a)),
+          "sept_colsum")
     return out
 
 
