@@ -16,6 +16,8 @@
 // output channels; weights stream through a double-buffered per-tap LDS tile (prefetched
 // into registers under the MFMAs, one barrier per tap).  Pixel stride in LDS is padded by
 // 16 B so the 16-lane groups of ds_read_b128 hit distinct banks.
+#include <cstdlib>
+
 #include "sept_common.h"
 
 namespace {
@@ -38,21 +40,26 @@ struct ConvArgs {
 
 __host__ __device__ constexpr int conv_nr_max(int mt, int w) { return (mt + w - 2) / w + 5; }
 
-template <int CIN, int COUT, int PB>
-__global__ __launch_bounds__(256) void sept_conv5x5_mfma_kernel(ConvArgs a) {
-  constexpr int MT = 128 * PB;
-  constexpr int NB = COUT / 32;
+// The workgroup is a WP x WN grid of waves: WP pixel groups (PB blocks of 32 pixels each) times
+// WN slices of the output channels.  8-wave shapes put two waves on every SIMD, so the LDS /
+// global-load latency of one hides under the other's MFMAs (measured 1.3-1.9x over 4 waves).
+template <int CIN, int COUT, int PB, int WP, int WN>
+__global__ __launch_bounds__(64 * WP * WN) void sept_conv5x5_mfma_kernel(ConvArgs a) {
+  constexpr int MT = 32 * PB * WP;
+  constexpr int NTHR = 64 * WP * WN;
+  constexpr int NB = COUT / 32 / WN;  // output-channel blocks per wave
   constexpr int KS = CIN / 16;
   constexpr int PS = CIN * 2 + 16;   // bytes per staged pixel (padded)
   constexpr int PSW = CIN * 2 + 16;  // bytes per staged weight row (padded)
   constexpr int CPP = CIN / 8;       // 16-B chunks per pixel
-  constexpr int WCH = (COUT * CPP + 255) / 256;
+  constexpr int WCH = (COUT * CPP + NTHR - 1) / NTHR;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int W = a.W, H = a.H, HW = H * W, W4 = W + 4;
   unsigned char* tile = smem;
   unsigned char* wbuf = smem + size_t(a.nr_max) * W4 * PS;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = (tid >> 6) % WP, nhalf = (tid >> 6) / WP;  // pixel group, output-channel slice
   const int b = blockIdx.y;
   const int q0 = blockIdx.x * MT;
   const int h_first = q0 / W;
@@ -63,7 +70,7 @@ __global__ __launch_bounds__(256) void sept_conv5x5_mfma_kernel(ConvArgs a) {
   {
     const bf16* xb = a.x + size_t(b) * HW * CIN;
     const int total = NR * W4 * CPP;
-    for (int i = tid; i < total; i += 256) {
+    for (int i = tid; i < total; i += NTHR) {
       const int c = i % CPP, px = i / CPP;
       const int col = px % W4, row = px / W4;
       const int h = h_first - 2 + row, w = col - 2;
@@ -77,7 +84,7 @@ __global__ __launch_bounds__(256) void sept_conv5x5_mfma_kernel(ConvArgs a) {
     const bf16* wsrc = a.wt + size_t(tap) * COUT * CIN;
 #pragma unroll
     for (int j = 0; j < WCH; ++j) {
-      const int i = tid + 256 * j;
+      const int i = tid + NTHR * j;
       if (i < COUT * CPP) r[j] = *reinterpret_cast<const uint4*>(wsrc + size_t(i) * 8);
     }
   };
@@ -85,7 +92,7 @@ __global__ __launch_bounds__(256) void sept_conv5x5_mfma_kernel(ConvArgs a) {
     unsigned char* dst = wbuf + size_t(buf) * COUT * PSW;
 #pragma unroll
     for (int j = 0; j < WCH; ++j) {
-      const int i = tid + 256 * j;
+      const int i = tid + NTHR * j;
       if (i < COUT * CPP) *reinterpret_cast<uint4*>(dst + (i / CPP) * PSW + (i % CPP) * 16) = r[j];
     }
   };
@@ -103,7 +110,7 @@ __global__ __launch_bounds__(256) void sept_conv5x5_mfma_kernel(ConvArgs a) {
     const int h = q / W, w = q - h * W;
     lane_base[pb] = ((h - h_first) * W4 + w) * PS + (lane >> 5) * 16;
   }
-  const int a_base = (lane & 31) * PSW + (lane >> 5) * 16;
+  const int a_base = (nhalf * NB * 32 + (lane & 31)) * PSW + (lane >> 5) * 16;
 
   f32x16 acc[PB][NB];
 #pragma unroll
@@ -148,7 +155,7 @@ __global__ __launch_bounds__(256) void sept_conv5x5_mfma_kernel(ConvArgs a) {
     for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int co = nb * 32 + 8 * g + 4 * (lane >> 5);
+        const int co = (nhalf * NB + nb) * 32 + 8 * g + 4 * (lane >> 5);
         f32x4 v = {acc[pb][nb][4 * g + 0], acc[pb][nb][4 * g + 1], acc[pb][nb][4 * g + 2],
                    acc[pb][nb][4 * g + 3]};
         if (a.bias) {
@@ -180,14 +187,19 @@ __global__ void sept_conv5x5_prep_kernel(const float* w, bf16* wt, int cout, int
 }
 
 struct ConvVariant {
-  int cin, cout, pb;
+  int cin, cout, pb, wp, wn;
   const void* fn;
 };
-#define SEPT_CONV_VARIANT(ci, co, pb) \
-  { ci, co, pb, reinterpret_cast<const void*>(&sept_conv5x5_mfma_kernel<ci, co, pb>) }
+#define SEPT_CONV_VARIANT(ci, co, pb, wp, wn) \
+  { ci, co, pb, wp, wn, reinterpret_cast<const void*>(&sept_conv5x5_mfma_kernel<ci, co, pb, wp, wn>) }
+// first entry that fits the LDS wins; order = measured preference at the training shapes
+// (tools/sweep_conv.py): the 8-wave 256-pixel tiles first, 4-wave fallbacks for wide images.
 const ConvVariant kConvVariants[] = {
-    SEPT_CONV_VARIANT(32, 64, 2),  SEPT_CONV_VARIANT(64, 128, 2), SEPT_CONV_VARIANT(64, 128, 1),
-    SEPT_CONV_VARIANT(64, 32, 2),  SEPT_CONV_VARIANT(128, 64, 1), SEPT_CONV_VARIANT(128, 128, 1),
+    SEPT_CONV_VARIANT(32, 64, 2, 4, 2),   SEPT_CONV_VARIANT(32, 64, 2, 4, 1),   SEPT_CONV_VARIANT(32, 64, 1, 4, 1),
+    SEPT_CONV_VARIANT(64, 128, 2, 4, 2),  SEPT_CONV_VARIANT(64, 128, 1, 4, 2),  SEPT_CONV_VARIANT(64, 128, 1, 4, 1),
+    SEPT_CONV_VARIANT(64, 32, 1, 8, 1),   SEPT_CONV_VARIANT(64, 32, 1, 4, 1),   SEPT_CONV_VARIANT(64, 32, 2, 4, 1),
+    SEPT_CONV_VARIANT(128, 64, 2, 4, 2),  SEPT_CONV_VARIANT(128, 64, 1, 4, 2),  SEPT_CONV_VARIANT(128, 64, 1, 4, 1),
+    SEPT_CONV_VARIANT(128, 128, 2, 4, 2), SEPT_CONV_VARIANT(128, 128, 1, 4, 2), SEPT_CONV_VARIANT(128, 128, 1, 4, 1),
 };
 
 }  // namespace
@@ -211,9 +223,13 @@ extern "C" int sept_conv5x5_forward(const void* x, const void* wt, const float* 
   SEPT_REQUIRE(B <= 65535, SEPT_ERR_UNSUPPORTED, "sept_conv5x5_forward: B=%d exceeds grid.y", B);
   const ConvVariant* best = nullptr;
   size_t best_smem = 0;
+  const int force_pb = getenv("SEPT_CONV_PB") ? atoi(getenv("SEPT_CONV_PB")) : 0;  // tuning aids
+  const int force_ns = getenv("SEPT_CONV_NS") ? atoi(getenv("SEPT_CONV_NS")) : 0;
   for (const ConvVariant& v : kConvVariants) {
     if (v.cin != cin || v.cout != cout) continue;
-    const int mt = 128 * v.pb;
+    if (force_pb && v.pb != force_pb) continue;
+    if (force_ns && v.wp * v.wn != 4 * force_ns) continue;
+    const int mt = 32 * v.pb * v.wp;
     const size_t ps = size_t(cin) * 2 + 16;
     const size_t smem = size_t(conv_nr_max(mt, W)) * (W + 4) * ps + 2 * size_t(cout) * ps;
     if (smem > 160 * 1024) continue;
@@ -233,10 +249,10 @@ extern "C" int sept_conv5x5_forward(const void* x, const void* wt, const float* 
   a.B = B;
   a.H = H;
   a.W = W;
-  const int mt = 128 * best->pb;
+  const int mt = 32 * best->pb * best->wp;
   a.nr_max = conv_nr_max(mt, W);
   SEPT_HIP(sept::allow_max_lds(best->fn));
-  dim3 grid((H * W + mt - 1) / mt, B), block(256);
+  dim3 grid((H * W + mt - 1) / mt, B), block(64 * best->wp * best->wn);
   void* args[] = {&a};
   SEPT_HIP(hipLaunchKernel(best->fn, grid, block, args, best_smem, static_cast<hipStream_t>(stream)));
   return SEPT_OK;
