@@ -94,10 +94,14 @@ int sept_conv5x5_backward_weight(const void* x_bf16, const void* dy_bf16, float*
 /* First layer Conv2d(1 -> 32, k=5, pad=2) (baseline_models.py:172): x / dx fp32 [B][H][W],
  * y / dy bf16 [B][H][W][32], w fp32 [32][1][5][5].  fp32 direct forward; packed-bf16 dot2
  * data gradient (feeds the cloak parameters, cloak_models.py:45-58); deterministic weight
- * gradient through a workspace of sept_conv1_workspace_floats() floats. */
-int sept_conv1_forward(const float* x, const float* w, const float* bias, void* y_bf16, int B, int H, int W,
-                       void* stream);
-int sept_conv1_backward_data(const void* dy_bf16, const float* w, float* dx, int B, int H, int W, void* stream);
+ * gradient through a workspace of sept_conv1_workspace_floats() floats.
+ * `wprep` is a scratch buffer of sept_conv1_prep_floats() floats (re-laid weights, read with
+ * scalar loads by the kernels). */
+size_t sept_conv1_prep_floats(void);
+int sept_conv1_forward(const float* x, const float* w, const float* bias, float* wprep, void* y_bf16, int B,
+                       int H, int W, void* stream);
+int sept_conv1_backward_data(const void* dy_bf16, const float* w, float* wprep, float* dx, int B, int H, int W,
+                             void* stream);
 size_t sept_conv1_workspace_floats(void);
 int sept_conv1_backward_weight(const float* x, const void* dy_bf16, float* ws, float* dw, float* db /*nullable*/,
                                int B, int H, int W, void* stream);

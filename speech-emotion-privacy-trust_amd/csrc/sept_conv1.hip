@@ -44,34 +44,47 @@ __device__ __forceinline__ void stage_x(const float* xb, float* tile, int h_firs
   }
 }
 
-__global__ __launch_bounds__(256) void sept_conv1_fwd_kernel(C1Args a) {
+// Weight operands in the form the kernels read them with SCALAR loads (uniform addresses, so
+// they ride in SGPRs and cost no LDS or VGPR traffic): wprep = { wt[25][32] fp32 (tap-major),
+// bias[32] fp32, wflip[25][32] bf16 (taps flipped, for the data gradient) }.
+constexpr int kPrepFloats = kTaps * kC + kC + kTaps * kC / 2;
+__global__ void sept_conv1_prep_kernel(const float* w, const float* bias, float* wprep) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < kTaps * kC) {
+    const int c = i % kC, t = i / kC;
+    wprep[i] = w[c * kTaps + t];
+    reinterpret_cast<bf16*>(wprep + kTaps * kC + kC)[i] = (bf16)w[c * kTaps + (4 - t / 5) * 5 + (4 - t % 5)];
+  }
+  if (i < kC) wprep[kTaps * kC + i] = bias ? bias[i] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void sept_conv1_fwd_kernel(const float* __restrict__ x,
+                                                             const float* __restrict__ wprep,
+                                                             bf16* __restrict__ y, int B, int H, int W) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* wl = reinterpret_cast<float*>(smem);  // [25][32] + bias[32]
-  float* tile = wl + kTaps * kC + kC;
-  const int W = a.W, H = a.H, HW = H * W, W4 = W + 4;
+  float* tile = reinterpret_cast<float*>(smem);
+  const int HW = H * W, W4 = W + 4;
   const int b = blockIdx.y, q0 = blockIdx.x * kMT;
   const int h_first = q0 / W, h_last = min(q0 + kMT - 1, HW - 1) / W;
-  for (int i = threadIdx.x; i < kTaps * kC; i += 256) wl[i] = a.w[(i % kC) * kTaps + i / kC];
-  if (threadIdx.x < kC) wl[kTaps * kC + threadIdx.x] = a.bias ? a.bias[threadIdx.x] : 0.f;
-  stage_x(a.x + size_t(b) * HW, tile, h_first, h_last - h_first + 5, H, W);
+  stage_x(x + size_t(b) * HW, tile, h_first, h_last - h_first + 5, H, W);
   __syncthreads();
   const int q = q0 + threadIdx.x;
   if (q >= HW) return;
   const int h = q / W, w = q - h * W;
   float acc[kC];
 #pragma unroll
-  for (int c = 0; c < kC; ++c) acc[c] = wl[kTaps * kC + c];
+  for (int c = 0; c < kC; ++c) acc[c] = wprep[kTaps * kC + c];
   const float* tp = tile + (h - h_first) * W4 + w;
 #pragma unroll
   for (int kh = 0; kh < 5; ++kh)
 #pragma unroll
     for (int kw = 0; kw < 5; ++kw) {
       const float xv = tp[kh * W4 + kw];
-      const float* wr = wl + (kh * 5 + kw) * kC;
+      const float* wr = wprep + (kh * 5 + kw) * kC;  // uniform -> s_load
 #pragma unroll
       for (int c = 0; c < kC; ++c) acc[c] = fmaf(xv, wr[c], acc[c]);
     }
-  bf16* yp = a.y + (size_t(b) * HW + q) * kC;
+  bf16* yp = y + (size_t(b) * HW + q) * kC;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     f32x8 v;
@@ -97,18 +110,16 @@ __device__ __forceinline__ void stage_dy(const bf16* dyb, unsigned char* tile, i
 
 // dx[h][w] = sum_{kh,kw,c} dy[h-kh+2][w-kw+2][c] * w[c][kh][kw]   (weights rounded to bf16,
 // products accumulated in fp32 by v_dot2_f32_bf16, like the MFMA layers)
-__global__ __launch_bounds__(256) void sept_conv1_dgrad_kernel(C1Args a) {
+__global__ __launch_bounds__(256) void sept_conv1_dgrad_kernel(const bf16* __restrict__ dy,
+                                                               const float* __restrict__ wprep,
+                                                               float* __restrict__ dx, int B, int H, int W) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  bf16* wl = reinterpret_cast<bf16*>(smem);  // [25 flipped taps][32] bf16
-  unsigned char* tile = smem + kTaps * kC * 2;
-  const int W = a.W, H = a.H, HW = H * W, W4 = W + 4;
+  unsigned char* tile = smem;
+  const uint4* wflip = reinterpret_cast<const uint4*>(wprep + kTaps * kC + kC);  // [25][4] x 8 bf16
+  const int HW = H * W, W4 = W + 4;
   const int b = blockIdx.y, q0 = blockIdx.x * kMT;
   const int h_first = q0 / W, h_last = min(q0 + kMT - 1, HW - 1) / W;
-  for (int i = threadIdx.x; i < kTaps * kC; i += 256) {
-    const int c = i % kC, t = i / kC;  // t indexes the offset (dh, dw) = (t/5, t%5); tap = flipped
-    wl[i] = (bf16)a.w[c * kTaps + (4 - t / 5) * 5 + (4 - t % 5)];
-  }
-  stage_dy(a.dy + size_t(b) * HW * kC, tile, h_first, h_last - h_first + 5, H, W);
+  stage_dy(dy + size_t(b) * HW * kC, tile, h_first, h_last - h_first + 5, H, W);
   __syncthreads();
   const int q = q0 + threadIdx.x;
   if (q >= HW) return;
@@ -120,18 +131,17 @@ __global__ __launch_bounds__(256) void sept_conv1_dgrad_kernel(C1Args a) {
 #pragma unroll
     for (int dw = 0; dw < 5; ++dw) {
       const unsigned char* pp = tp + size_t(dh * W4 + dw) * kDyPS;
-      const uint4* wr = reinterpret_cast<const uint4*>(wl + (dh * 5 + dw) * kC);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const uint4 dv = *reinterpret_cast<const uint4*>(pp + g * 16);
-        const uint4 wv = wr[g];
+        const uint4 wv = wflip[(dh * 5 + dw) * 4 + g];  // uniform -> s_load
         acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, dv.x), __builtin_bit_cast(bf16x2, wv.x), acc, false);
         acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, dv.y), __builtin_bit_cast(bf16x2, wv.y), acc, false);
         acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, dv.z), __builtin_bit_cast(bf16x2, wv.z), acc, false);
         acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, dv.w), __builtin_bit_cast(bf16x2, wv.w), acc, false);
       }
     }
-  a.dx[size_t(b) * HW + q] = acc;
+  dx[size_t(b) * HW + q] = acc;
 }
 
 // dW[c][tap] = sum_{b,h,w} dy[b,h,w,c] * x[b,h+kh-2,w+kw-2];  db[c] = sum dy.
@@ -196,9 +206,96 @@ __global__ void sept_conv1_wgrad_finalize_kernel(const float* ws, int nparts, fl
     db[i - kC * kTaps] = float(s);
 }
 
+// ---- weight gradient on MFMA (image width a multiple of 8) -------------------------------
+// D[c][tap] += sum_pixels dy[pixel][c] * x[pixel + tap]:  A[c][pixel] comes from the NHWC dy tile by
+// the transposing LDS read (as in sept_conv_wgrad.hip); B[pixel][tap] is built on the fly -- lane
+// (tap = l & 31) reads the 8 consecutive fp32 inputs its tap sees for pixels 8*(l>>5)..+7 and
+// rounds them to bf16.  Column 25 of B is the constant 1, so D[c][25] is the bias gradient.
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__global__ __launch_bounds__(256) void sept_conv1_wgrad_mfma_kernel(const float* __restrict__ x,
+                                                                    const bf16* __restrict__ dy,
+                                                                    float* __restrict__ ws, int B, int H, int W) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int HW = H * W, W4 = W + 4;
+  float* xt = reinterpret_cast<float*>(smem);
+  unsigned char* yt = smem + ((sizeof(float) * nr_max(W) * W4 + 15) & ~size_t(15));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tap = lane & 31, k_hi = lane >> 5;
+  const int tapoff = tap < kTaps ? (tap / 5) * W4 + (tap % 5) : 0;
+  const int tr_q = (lane & 15) >> 2;
+  const int tr_ch = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int tiles_per_img = (HW + kMT - 1) / kMT;
+  const long n_tiles = long(B) * tiles_per_img;
+  for (long tile_id = blockIdx.x; tile_id < n_tiles; tile_id += gridDim.x) {
+    const int b = tile_id / tiles_per_img, q0 = int(tile_id % tiles_per_img) * kMT;
+    const int h_first = q0 / W, h_last = min(q0 + kMT - 1, HW - 1) / W;
+    __syncthreads();
+    stage_x(x + size_t(b) * HW, xt, h_first, h_last - h_first + 5, H, W);
+    const bf16* dyb = dy + (size_t(b) * HW + q0) * kC;
+    for (int i = tid; i < kMT * 4; i += 256) {
+      const int t = i >> 2, c = i & 3;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (q0 + t < HW) v = *reinterpret_cast<const uint4*>(dyb + size_t(t) * kC + c * 8);
+      *reinterpret_cast<uint4*>(yt + size_t(t) * kDyPS + c * 16) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < kMT / 64; ++ks) {
+      const int kb = wave * (kMT / 4) + ks * 16;  // first pixel of this 16-pixel step
+      // A: dy^T fragment (two transposing reads of 4 pixels x 16 channels)
+      const int ta = kb + 8 * k_hi + tr_q;
+      const bf16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+          (__attribute__((address_space(3))) bf16x4*)(reinterpret_cast<uintptr_t>(yt + size_t(ta) * kDyPS + tr_ch * 2)));
+      const bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+          (__attribute__((address_space(3))) bf16x4*)(reinterpret_cast<uintptr_t>(yt + size_t(ta + 4) * kDyPS + tr_ch * 2)));
+      const bf16x8 afrag = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
+      // B: 8 consecutive pixels (same image row: W % 8 == 0 and the group start is 8-aligned)
+      const int q = min(q0 + kb + 8 * k_hi, HW - 8);
+      const int h = q / W, w = q - h * W;
+      const float* xp = xt + (h - h_first) * W4 + w + tapoff;
+      f32x8 xv;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xv[e] = tap < kTaps ? xp[e] : (tap == kTaps ? 1.0f : 0.0f);
+      const bf16x8 bfrag = __builtin_convertvector(xv, bf16x8);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc, 0, 0, 0);
+    }
+  }
+  // fixed-order sum of the four waves, one [16][64] slab per workgroup
+  float* red = reinterpret_cast<float*>(smem);
+  for (int wv = 0; wv < 4; ++wv) {
+    __syncthreads();
+    if (wave == wv) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[r * 64 + lane] = (wv == 0 ? 0.f : red[r * 64 + lane]) + acc[r];
+    }
+  }
+  __syncthreads();
+  float* slab = ws + size_t(blockIdx.x) * 1024;
+  for (int i = tid; i < 1024; i += 256) slab[i] = red[i];
+}
+
+__global__ void sept_conv1_wgrad_mfma_finalize_kernel(const float* ws, int nparts, float* dw, float* db) {
+  const int e = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;  // one wave per slab element
+  if (e >= 1024) return;
+  const double s = sept::wave_sum_partials(ws, nparts, size_t(1024), e);
+  if (threadIdx.x & 63) return;
+  const int lane = e & 63, r = e >> 6;
+  const int c = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), tap = lane & 31;
+  if (tap < kTaps)
+    dw[c * kTaps + tap] = float(s);
+  else if (tap == kTaps && db)
+    db[c] = float(s);
+}
+
 }  // namespace
 
-extern "C" size_t sept_conv1_workspace_floats(void) { return size_t(kWgParts) * (kC * kTaps + kC); }
+// the MFMA path writes one raw [16][64] accumulator slab (1024 floats) per workgroup
+extern "C" size_t sept_conv1_workspace_floats(void) { return size_t(kWgParts) * 1024; }
 
 static int conv1_check(const char* what, int B, int H, int W) {
   SEPT_REQUIRE(B >= 0 && H > 0 && W > 0, SEPT_ERR_INVALID, "%s: B=%d H=%d W=%d", what, B, H, W);
@@ -206,32 +303,35 @@ static int conv1_check(const char* what, int B, int H, int W) {
   return SEPT_OK;
 }
 
-extern "C" int sept_conv1_forward(const float* x, const float* w, const float* bias, void* y, int B, int H,
-                                  int W, void* stream) {
+extern "C" size_t sept_conv1_prep_floats(void) { return kPrepFloats; }
+
+extern "C" int sept_conv1_forward(const float* x, const float* w, const float* bias, float* wprep, void* y, int B,
+                                  int H, int W, void* stream) {
   if (int e = conv1_check("sept_conv1_forward", B, H, W)) return e;
   if (B == 0) return SEPT_OK;
-  SEPT_REQUIRE(x && w && y, SEPT_ERR_INVALID, "sept_conv1_forward: null argument");
-  C1Args a{};
-  a.x = x; a.w = w; a.bias = bias; a.y = static_cast<bf16*>(y); a.B = B; a.H = H; a.W = W;
-  const size_t smem = sizeof(float) * (kTaps * kC + kC + size_t(nr_max(W)) * (W + 4));
+  SEPT_REQUIRE(x && w && y && wprep, SEPT_ERR_INVALID, "sept_conv1_forward: null argument");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(sept_conv1_prep_kernel, dim3((kTaps * kC + 255) / 256), dim3(256), 0, st, w, bias, wprep);
+  const size_t smem = sizeof(float) * size_t(nr_max(W)) * (W + 4);
   SEPT_HIP(sept::allow_max_lds(reinterpret_cast<const void*>(&sept_conv1_fwd_kernel)));
-  hipLaunchKernelGGL(sept_conv1_fwd_kernel, dim3((H * W + kMT - 1) / kMT, B), dim3(256), smem,
-                     static_cast<hipStream_t>(stream), a);
+  hipLaunchKernelGGL(sept_conv1_fwd_kernel, dim3((H * W + kMT - 1) / kMT, B), dim3(256), smem, st, x,
+                     static_cast<const float*>(wprep), static_cast<bf16*>(y), B, H, W);
   return sept::launch_check("sept_conv1_fwd_kernel");
 }
 
-extern "C" int sept_conv1_backward_data(const void* dy, const float* w, float* dx, int B, int H, int W,
-                                        void* stream) {
+extern "C" int sept_conv1_backward_data(const void* dy, const float* w, float* wprep, float* dx, int B, int H,
+                                        int W, void* stream) {
   if (int e = conv1_check("sept_conv1_backward_data", B, H, W)) return e;
   if (B == 0) return SEPT_OK;
-  SEPT_REQUIRE(dy && w && dx, SEPT_ERR_INVALID, "sept_conv1_backward_data: null argument");
-  C1Args a{};
-  a.dy = static_cast<const bf16*>(dy); a.w = w; a.dx = dx; a.B = B; a.H = H; a.W = W;
-  const size_t smem = kTaps * kC * 2 + size_t(nr_max(W)) * (W + 4) * kDyPS;
+  SEPT_REQUIRE(dy && w && dx && wprep, SEPT_ERR_INVALID, "sept_conv1_backward_data: null argument");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(sept_conv1_prep_kernel, dim3((kTaps * kC + 255) / 256), dim3(256), 0, st, w,
+                     static_cast<const float*>(nullptr), wprep);
+  const size_t smem = size_t(nr_max(W)) * (W + 4) * kDyPS;
   SEPT_REQUIRE(smem <= 160 * 1024, SEPT_ERR_UNSUPPORTED, "sept_conv1_backward_data: W=%d needs %zu B of LDS", W, smem);
   SEPT_HIP(sept::allow_max_lds(reinterpret_cast<const void*>(&sept_conv1_dgrad_kernel)));
-  hipLaunchKernelGGL(sept_conv1_dgrad_kernel, dim3((H * W + kMT - 1) / kMT, B), dim3(256), smem,
-                     static_cast<hipStream_t>(stream), a);
+  hipLaunchKernelGGL(sept_conv1_dgrad_kernel, dim3((H * W + kMT - 1) / kMT, B), dim3(256), smem, st,
+                     static_cast<const bf16*>(dy), static_cast<const float*>(wprep), dx, B, H, W);
   return sept::launch_check("sept_conv1_dgrad_kernel");
 }
 
@@ -244,8 +344,16 @@ extern "C" int sept_conv1_backward_weight(const float* x, const void* dy, float*
   a.x = x; a.dy = static_cast<const bf16*>(dy); a.ws = ws; a.B = B; a.H = H; a.W = W;
   const long n_tiles = long(B) * ((H * W + kMT - 1) / kMT);
   const int grid = int(std::min<long>(n_tiles, kWgParts));
-  const size_t smem = ((sizeof(float) * size_t(nr_max(W)) * (W + 4) + 15) & ~size_t(15)) + size_t(kMT) * kC * 2;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (W % 8 == 0 && H * W >= 8) {  // MFMA path
+    const size_t smem2 = ((sizeof(float) * size_t(nr_max(W)) * (W + 4) + 15) & ~size_t(15)) + size_t(kMT) * kDyPS;
+    SEPT_HIP(sept::allow_max_lds(reinterpret_cast<const void*>(&sept_conv1_wgrad_mfma_kernel)));
+    hipLaunchKernelGGL(sept_conv1_wgrad_mfma_kernel, dim3(grid), dim3(256), std::max(smem2, size_t(4096)), st, x,
+                       static_cast<const bf16*>(dy), ws, B, H, W);
+    hipLaunchKernelGGL(sept_conv1_wgrad_mfma_finalize_kernel, dim3(256), dim3(256), 0, st, ws, grid, dw, db);
+    return sept::launch_check("sept_conv1_wgrad_mfma_kernel");
+  }
+  const size_t smem = ((sizeof(float) * size_t(nr_max(W)) * (W + 4) + 15) & ~size_t(15)) + size_t(kMT) * kC * 2;
   SEPT_HIP(sept::allow_max_lds(reinterpret_cast<const void*>(&sept_conv1_wgrad_partial_kernel)));
   hipLaunchKernelGGL(sept_conv1_wgrad_partial_kernel, dim3(grid), dim3(256), smem, st, a);
   const int n = kC * kTaps + kC;

@@ -39,8 +39,9 @@ SIGNATURES = {
     "sept_conv5x5_wgrad_workspace_floats": (c_size_t, [c_int, c_int]),
     "sept_conv5x5_backward_weight": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                              c_void_p]),
-    "sept_conv1_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
-    "sept_conv1_backward_data": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "sept_conv1_prep_floats": (c_size_t, []),
+    "sept_conv1_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "sept_conv1_backward_data": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "sept_conv1_workspace_floats": (c_size_t, []),
     "sept_conv1_backward_weight": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                            c_void_p]),

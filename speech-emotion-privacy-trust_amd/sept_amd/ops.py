@@ -93,7 +93,8 @@ def conv1_forward(x, w, bias=None):
     require_cuda(x, w)
     B, H, W = x.shape
     y = torch.empty((B, H, W, 32), dtype=torch.bfloat16, device=x.device)
-    check(lib.sept_conv1_forward(x.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), B, H, W, _s(x)),
+    wp = workspace("conv1_prep_fwd", lib.sept_conv1_prep_floats(), x.device)
+    check(lib.sept_conv1_forward(x.data_ptr(), w.data_ptr(), _p(bias), wp.data_ptr(), y.data_ptr(), B, H, W, _s(x)),
           "sept_conv1_forward")
     return y
 
@@ -102,7 +103,8 @@ def conv1_backward_data(dy, w):
     require_cuda(dy, w)
     B, H, W, _ = dy.shape
     dx = torch.empty((B, H, W), dtype=torch.float32, device=dy.device)
-    check(lib.sept_conv1_backward_data(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), B, H, W, _s(dy)),
+    wp = workspace("conv1_prep_bwd", lib.sept_conv1_prep_floats(), dy.device)
+    check(lib.sept_conv1_backward_data(dy.data_ptr(), w.data_ptr(), wp.data_ptr(), dx.data_ptr(), B, H, W, _s(dy)),
           "sept_conv1_backward_data")
     return dx
 
