@@ -209,8 +209,10 @@ extern "C" int sept_gemm(const void* A, long sam, long sak, int a_is_bf16, const
   GemmArgs g{A, B, C, bias, ws, sam, sak, sbk, sbn, ldc, M, N, K, 0, alpha, beta, a_is_bf16, c_is_bf16, b_is_bf16, 1};
   const int tiles = ((N + TN - 1) / TN) * ((M + TM - 1) / TM);
   int splits = 1;
-  if (ws && tiles < 256 && K >= 1024) {
-    splits = std::min({16, (512 + tiles - 1) / tiles, K / 256});
+  // a 64x64 tile keeps one workgroup busy for K/32 barrier-separated chunks; with fewer than ~4
+  // workgroups per CU nothing overlaps its staging, so long-K products are split along K
+  if (ws && tiles < 1024 && K >= 512) {
+    splits = std::min({16, (1024 + tiles - 1) / tiles, K / 128});
     while (splits > 1 && long(splits) * M * N > ws_floats) --splits;
   }
   g.splits = std::max(splits, 1);

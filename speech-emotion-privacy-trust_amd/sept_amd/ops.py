@@ -193,7 +193,7 @@ def gemm_raw(A, sam, sak, Bm, sbk, sbn, C, ldc, M, N, K, bias=None, alpha=1.0, b
     """C[M][N] = alpha * A(M,K) B(K,N) (+bias) (+beta*C) with explicit element strides; A/B/C may
     be views (data_ptr carries the offset)."""
     wsp, wsn = 0, 0
-    if K >= 1024 and ((M + 63) // 64) * ((N + 63) // 64) < 256:   # weight-gradient shape: allow split-K
+    if K >= 512 and ((M + 63) // 64) * ((N + 63) // 64) < 1024:   # few tiles, long K: allow split-K
         wsn = 16 * M * N
         wsp = workspace("gemm_splitk", wsn, C.device).data_ptr()
     check(lib.sept_gemm(A.data_ptr(), sam, sak, _is_bf16(A), Bm.data_ptr(), sbk, sbn, _is_bf16(Bm), C.data_ptr(), ldc,

@@ -133,3 +133,36 @@ class FusedPipeline:
         x = self.features(wav)
         return self.trainer.train_step(x.view(x.shape[0], 1, self.win, self.n_mels), labels_emo_w, labels_gen_w,
                                        weights_w)
+
+    def capture(self, wav, labels_emo_w, labels_gen_w, weights_w=None):
+        """Record features + forward + loss + backward + gradient packing of ONE step into a HIP
+        graph (torch.cuda.CUDAGraph) over the given STATIC input tensors; returns `replay()`,
+        which launches the graph, then the gradient all-reduce and the optimiser kernel eagerly
+        (the collective and the step counter stay outside the graph).  Call after a few eager
+        warm-up steps (first-use setup such as LDS limits and workspaces happens there); refill
+        the static tensors with copy_() between replays.  SGD only (Adam's bias correction is a
+        host-side function of the step count)."""
+        tr = self.trainer
+        if tr.kind != "sgd" or tr.steps < 1:
+            raise RuntimeError("capture() needs optimizer='sgd' and at least one eager warm-up step")
+        tr.model.train()
+        tr.flat.zero_grad()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            x = self.features(wav)
+            preds, preds_grl, _ = tr.model(x.view(x.shape[0], 1, self.win, self.n_mels), mask=None, grl=False,
+                                           pooling="mean")
+            loss = tr.loss(preds, preds_grl, labels_emo_w, labels_gen_w, weights_w, training=True)
+            loss.backward()
+            tr.flat.gather_grads()
+            out = (loss.detach(), preds.detach(), preds_grl.detach())
+
+        def replay():
+            graph.replay()
+            if tr.world > 1:
+                torch.distributed.all_reduce(tr.flat.grad, group=tr.pg)
+            tr.optimizer_step()
+            return out
+
+        replay.graph = graph
+        return replay
