@@ -236,6 +236,17 @@ def main():
 
     if rank != 0:
         return
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process;
+    # the figure is the committed rocprofv3 --pmc measurement of this same command and shape
+    traffic, traffic_src = None, None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        if clips == 32 and F == 80:
+            for k in tj["kernels"].values():
+                if k.get("tag") == dominant:
+                    traffic, traffic_src = k["hbm_bytes_per_launch"], "profiles/r01_pmc_traffic.json"
+    except (OSError, ValueError, KeyError):
+        pass
     total_clips = clips * world * a.steps
     res = {
         "metric": "utterances/sec (feat-extract + fwd + bwd), 5 s @ 16 kHz",
@@ -252,7 +263,7 @@ def main():
         "roofline": {"bound": "mfma", "kernel": dominant, "launches_timed": n_launch,
                      "ms_per_launch": round(k_ms, 4), "flops_per_launch": flops,
                      "achieved": round(achieved / 1e12, 2), "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s",
-                     "frac": round(achieved / MFMA_PEAK, 4), "traffic": None,
+                     "frac": round(achieved / MFMA_PEAK, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "per_step_ms_by_kernel": {t: round(v, 3) for t, v in sorted(per_step.items())}},
         "mel": mel,
     }
