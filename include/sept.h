@@ -192,6 +192,10 @@ int sept_colsum(const float* a, long lda, int M, int N, float* ws, float* out, i
  * (the per-sample loop of train(), training_cloak_with_grl.py:143-154; weights nullable) */
 int sept_cross_entropy(const float* logits, const long long* labels, const float* weights, float scale, int B,
                        int C, float* loss, float* dlogits, int accumulate, void* stream);
+/* Sliding-window inference (training_cloak_with_grl.py:70-87, adversary_cloak_evaluation.py:40-110):
+ * probs[b] = mean over the nwin windows of utterance b of softmax(logits[b*nwin + i]); pred[b] =
+ * argmax (first maximum).  pred nullable. */
+int sept_softmax_mean(const float* logits, int B, int nwin, int C, float* probs, long long* pred, void* stream);
 /* loss -= lambda * log(*mean)  (training_cloak_with_grl.py:158-160) */
 int sept_loss_sub_log(float* loss, const float* mean, float lambda, void* stream);
 /* dst[n][w*C + c] = src[n][c*Wd + w] (inverse != 0: the other way): GRU weight_ih_l0 between

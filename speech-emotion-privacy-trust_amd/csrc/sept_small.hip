@@ -163,6 +163,33 @@ __global__ void ce_kernel(const float* logits, const long long* labels, const fl
   }
 }
 
+// sliding-window inference (training_cloak_with_grl.py:70-87): softmax each window's logits, average
+// the probabilities over the nwin windows of an utterance, arg-max.  One thread per utterance.
+__global__ void softmax_mean_kernel(const float* logits, int B, int nwin, int C, float* probs, long long* pred) {
+  GRID_STRIDE(b, B) {
+    float best = -1.f;
+    int arg = 0;
+    for (int c = 0; c < C; ++c) probs[b * C + c] = 0.f;
+    for (int i = 0; i < nwin; ++i) {
+      const float* l = logits + (size_t(b) * nwin + i) * C;
+      float mx = l[0];
+      for (int c = 1; c < C; ++c) mx = fmaxf(mx, l[c]);
+      float se = 0.f;
+      for (int c = 0; c < C; ++c) se += expf(l[c] - mx);
+      for (int c = 0; c < C; ++c) probs[b * C + c] += expf(l[c] - mx) / se;
+    }
+    for (int c = 0; c < C; ++c) {
+      const float p = probs[b * C + c] / float(nwin);
+      probs[b * C + c] = p;
+      if (p > best) {  // first maximum, as np.argmax
+        best = p;
+        arg = c;
+      }
+    }
+    if (pred) pred[b] = arg;
+  }
+}
+
 // loss -= lambda * log(mean)    (training_cloak_with_grl.py:158-160)
 __global__ void loss_sub_log_kernel(float* loss, const float* mean, float lambda) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *loss -= lambda * logf(*mean);
@@ -331,6 +358,15 @@ extern "C" int sept_cross_entropy(const float* logits, const long long* labels, 
   hipLaunchKernelGGL(ce_kernel, dim3(1), dim3(kThreads), 0, ST(stream), logits, labels, weights, scale, B, C, loss,
                      dlogits, accumulate);
   return sept::launch_check("ce_kernel");
+}
+
+extern "C" int sept_softmax_mean(const float* logits, int B, int nwin, int C, float* probs, long long* pred,
+                                 void* stream) {
+  if (B == 0) return SEPT_OK;
+  SEPT_REQUIRE(logits && probs && B > 0 && nwin > 0 && C > 0, SEPT_ERR_INVALID, "sept_softmax_mean: bad argument");
+  hipLaunchKernelGGL(softmax_mean_kernel, dim3(blocks_for(B)), dim3(kThreads), 0, ST(stream), logits, B, nwin, C, probs,
+                     pred);
+  return sept::launch_check("softmax_mean_kernel");
 }
 
 extern "C" int sept_loss_sub_log(float* loss, const float* mean, float lambda, void* stream) {

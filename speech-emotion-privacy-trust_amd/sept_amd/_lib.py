@@ -69,6 +69,7 @@ SIGNATURES = {
     "sept_colsum": (c_int, [c_void_p, c_long, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "sept_cross_entropy": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_void_p, c_int,
                                    c_void_p]),
+    "sept_softmax_mean": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "sept_loss_sub_log": (c_int, [c_void_p, c_void_p, c_float, c_void_p]),
     "sept_permute_cols": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "sept_window_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -376,3 +376,15 @@ def window_norm(mel_btf, mean=None, std=None, win=200, shift=50):
     check(lib.sept_window_norm(mel_btf.data_ptr(), _p(mean), _p(std), out.data_ptr(), B, T, F, win, shift, nwin,
                                _s(out)), "sept_window_norm")
     return out
+
+
+def softmax_mean(logits, nwin):
+    """logits (B*nwin, C) -> (mean softmax probabilities (B, C), argmax (B,) int64)."""
+    require_cuda(logits)
+    n, C = logits.shape
+    B = n // nwin
+    probs = torch.empty((B, C), dtype=torch.float32, device=logits.device)
+    pred = torch.empty(B, dtype=torch.int64, device=logits.device)
+    check(lib.sept_softmax_mean(logits.contiguous().data_ptr(), B, nwin, C, probs.data_ptr(), pred.data_ptr(),
+                                _s(logits)), "sept_softmax_mean")
+    return probs, pred

@@ -252,3 +252,62 @@ def test_gradient_reversal_module(G):
     (y * torch.arange(1.0, 7.0).reshape(2, 3).cuda()).sum().backward()
     np.testing.assert_allclose(z.grad.cpu().numpy(), G["grl_kat_grad"], rtol=1e-6)
     assert GradientReversal().lambda_ == 1
+
+
+def test_sliding_window_inference_matches_reference_loop():
+    """test() of the reference (training_cloak_with_grl.py:43-96): windows every 50 frames, eval
+    mode, softmax, mean over windows, arg-max -- oracle loop (one window per forward, as the
+    reference does) vs the batched HIP path."""
+    from sept_amd.inference import sliding_window_predict
+    F, T = 80, 501
+    torch.manual_seed(11)
+    feats = torch.randn(3, 1, T, F)
+    grl = build_grl(F).eval()
+    ref = _oracle_grl(F).eval()
+    ref.load_state_dict({k: v.cpu() for k, v in grl.state_dict().items()})
+    pred, probs = sliding_window_predict(grl, feats.cuda(), win_len=200, mask=None, pooling="mean")
+    assert pred.shape == (3,) and probs.shape == (3, 4)
+    test_len = int((T - 200) / 50) + 1
+    assert test_len == 7
+    for b in range(3):
+        plist = []
+        with torch.no_grad():
+            for i in range(test_len):
+                w = feats[b:b + 1, :, i * 50:i * 50 + 200, :]
+                p1, _, _ = ref(w, mask=None, grl=False, pooling="mean")
+                plist.append(torch.softmax(p1, dim=1)[0].numpy())
+        mean_p = np.mean(np.array(plist), axis=0)
+        np.testing.assert_allclose(probs[b].cpu().numpy(), mean_p, atol=1e-2)
+        if np.sort(mean_p)[-1] - np.sort(mean_p)[-2] > 2e-2:
+            assert int(pred[b]) == int(np.argmax(mean_p))
+    gp, gprobs = sliding_window_predict(grl, feats.cuda(), which="gender")
+    assert gprobs.shape == (3, 2) and torch.allclose(gprobs.sum(1), torch.ones(3, device="cuda"), atol=1e-5)
+
+
+def test_graph_replay_equals_eager_step():
+    """The HIP-graph replay of a step must produce the same update as the eager step."""
+    from sept_amd.trainer import FusedPipeline, GrlTrainer
+    F = 80
+    torch.manual_seed(3)
+    wav = (torch.randn(2, 48000) * 0.1).cuda()
+    le, lg = torch.tensor([0, 0, 0, 3, 3, 3]).cuda(), torch.tensor([1, 1, 1, 0, 0, 0]).cuda()
+    w = torch.ones(6).cuda()
+    mean, std = torch.full((F,), -20.0).cuda(), torch.full((F,), 12.0).cuda()
+    results = []
+    for use_graph in (False, True):
+        grl = build_grl(F).train()
+        zero_dropout(grl)
+        tr = GrlTrainer(grl, optimizer="sgd")
+        pipe = FusedPipeline(tr, n_mels=F, mean=mean, std=std)
+        pipe.train_step(wav, le, lg, w)                         # warm-up / first step (eager in both)
+        if use_graph:
+            step = pipe.capture(wav, le, lg, w)
+            loss, _, _ = step()
+            loss, _, _ = step()
+        else:
+            loss, _, _ = pipe.train_step(wav, le, lg, w)
+            loss, _, _ = pipe.train_step(wav, le, lg, w)
+        torch.cuda.synchronize()
+        results.append((float(loss), tr.flat.flat.clone()))
+    assert results[0][0] == pytest.approx(results[1][0], rel=1e-6)
+    assert torch.equal(results[0][1], results[1][1])          # deterministic kernels: bit-identical
