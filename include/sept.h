@@ -201,6 +201,16 @@ int sept_loss_sub_log(float* loss, const float* mean, float lambda, void* stream
 /* dst[n][w*C + c] = src[n][c*Wd + w] (inverse != 0: the other way): GRU weight_ih_l0 between
  * the reference's (c, w) feature order (cloak_models.py:166-168) and the NHWC (w, c) order */
 int sept_permute_cols(const float* src, float* dst, int N, int C, int Wd, int inverse, void* stream);
+/* one_d_cnn_lstm (baseline_models.py:47-62), channels-last fp32 [B][T][C]:
+ * Conv1d(k=5, pad=2) = sept_gemm on the unfolded input col[B][T][5*C] (col[..][k*C+c] = x[t+k-2][c]);
+ * its data gradient folds dcol back; ReLU + MaxPool1d(pool) + Dropout forward/backward with the
+ * arg-max byte map idx[B][T/pool][C] (first maximum). */
+int sept_unfold1d(const float* x, float* col, int B, int T, int C, void* stream);
+int sept_fold1d(const float* dcol, float* dx, int B, int T, int C, void* stream);
+int sept_relu_pool1d_forward(const float* x, const float* dropscale, float* y, unsigned char* idx, int B, int T,
+                             int C, int pool, void* stream);
+int sept_relu_pool1d_backward(const float* dy, const float* x, const float* dropscale, const unsigned char* idx,
+                              float* dx, int B, int T, int C, int pool, void* stream);
 /* Windowing + per-speaker z-normalisation between the two halves of the path: mel (B, T, F)
  * time-major -> out (B*nwin, win, F), window i = frames [shift*i, shift*i + win) (zero padded
  * past T), each value (x - mean[f]) / (std[f] + 1e-5) when mean/std are given

@@ -232,6 +232,72 @@ __global__ void window_norm_kernel(const float* mel, const float* mean, const fl
   }
 }
 
+// ---------------- one_d_cnn_lstm pieces (baseline_models.py:47-62) ----------------
+// Conv1d(k=5, pad=2) over time on channels-last data is a product with the unfolded input:
+// col[b][t][k*C + c] = x[b][t + k - 2][c] (zero outside [0, T)); the product itself is sept_gemm.
+__global__ void unfold1d_kernel(const float* x, float* col, int B, int T, int C) {
+  GRID_STRIDE(i, long(B) * T * 5 * C) {
+    const int c = i % C;
+    const int k = (i / C) % 5;
+    const int t = (i / (5L * C)) % T;
+    const long b = i / (5L * C * T);
+    const int ts = t + k - 2;
+    col[i] = (ts >= 0 && ts < T) ? x[(b * T + ts) * C + c] : 0.f;
+  }
+}
+// dx[b][t][c] = sum_k dcol[b][t - k + 2][k*C + c]
+__global__ void fold1d_kernel(const float* dcol, float* dx, int B, int T, int C) {
+  GRID_STRIDE(i, long(B) * T * C) {
+    const int c = i % C;
+    const int t = (i / C) % T;
+    const long b = i / (long(C) * T);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int tt = t - k + 2;
+      if (tt >= 0 && tt < T) s += dcol[((b * T + tt) * 5 + k) * C + c];
+    }
+    dx[i] = s;
+  }
+}
+// y[b][to][c] = dropscale * max_{j<P} relu(x[b][to*P + j][c]);  idx = arg max (first maximum)
+__global__ void relu_pool1d_fwd_kernel(const float* x, const float* drop, float* y, unsigned char* idx, int B, int T,
+                                       int C, int P) {
+  const int To = T / P;
+  GRID_STRIDE(i, long(B) * To * C) {
+    const int c = i % C;
+    const int to = (i / C) % To;
+    const long b = i / (long(C) * To);
+    float best = -1.f;
+    int arg = 0;
+    for (int j = 0; j < P; ++j) {
+      const float v = fmaxf(x[(b * T + to * P + j) * C + c], 0.f);
+      if (v > best) {
+        best = v;
+        arg = j;
+      }
+    }
+    y[i] = best * (drop ? drop[i] : 1.0f);
+    idx[i] = (unsigned char)arg;
+  }
+}
+__global__ void relu_pool1d_bwd_kernel(const float* dy, const float* x, const float* drop, const unsigned char* idx,
+                                       float* dx, int B, int T, int C, int P) {
+  const int To = T / P;
+  GRID_STRIDE(i, long(B) * T * C) {
+    const int c = i % C;
+    const int t = (i / C) % T;
+    const long b = i / (long(C) * T);
+    const int to = t / P;
+    float g = 0.f;
+    if (to < To) {
+      const long o = (b * To + to) * C + c;
+      if (idx[o] == t - to * P && x[i] > 0.f) g = dy[o] * (drop ? drop[o] : 1.0f);
+    }
+    dx[i] = g;
+  }
+}
+
 // ---------------- optimisers (training_cloak_with_grl.py:416-421) ----------------
 // torch.optim.SGD(momentum, weight_decay, dampening 0, nesterov False)
 __global__ void sgd_kernel(float* p, const float* g, float* buf, long n, float lr, float momentum, float wd,
@@ -392,6 +458,41 @@ extern "C" int sept_window_norm(const float* mel_btf, const float* mean, const f
   hipLaunchKernelGGL(window_norm_kernel, dim3(blocks_for(total)), dim3(kThreads), 0, ST(stream), mel_btf, mean, stdv, out,
                      B, T, F, win, shift, nwin);
   return sept::launch_check("window_norm_kernel");
+}
+
+extern "C" int sept_unfold1d(const float* x, float* col, int B, int T, int C, void* stream) {
+  if (B == 0) return SEPT_OK;
+  SEPT_REQUIRE(x && col && B > 0 && T > 0 && C > 0, SEPT_ERR_INVALID, "sept_unfold1d: bad argument");
+  hipLaunchKernelGGL(unfold1d_kernel, dim3(blocks_for(long(B) * T * 5 * C)), dim3(kThreads), 0, ST(stream), x, col, B, T, C);
+  return sept::launch_check("unfold1d_kernel");
+}
+
+extern "C" int sept_fold1d(const float* dcol, float* dx, int B, int T, int C, void* stream) {
+  if (B == 0) return SEPT_OK;
+  SEPT_REQUIRE(dcol && dx && B > 0 && T > 0 && C > 0, SEPT_ERR_INVALID, "sept_fold1d: bad argument");
+  hipLaunchKernelGGL(fold1d_kernel, dim3(blocks_for(long(B) * T * C)), dim3(kThreads), 0, ST(stream), dcol, dx, B, T, C);
+  return sept::launch_check("fold1d_kernel");
+}
+
+extern "C" int sept_relu_pool1d_forward(const float* x, const float* dropscale, float* y, unsigned char* idx, int B,
+                                        int T, int C, int pool, void* stream) {
+  if (B == 0) return SEPT_OK;
+  SEPT_REQUIRE(x && y && idx && B > 0 && T > 0 && C > 0 && pool > 0 && pool < 256 && T >= pool, SEPT_ERR_INVALID,
+               "sept_relu_pool1d_forward: bad argument");
+  hipLaunchKernelGGL(relu_pool1d_fwd_kernel, dim3(blocks_for(long(B) * (T / pool) * C)), dim3(kThreads), 0, ST(stream),
+                     x, dropscale, y, idx, B, T, C, pool);
+  return sept::launch_check("relu_pool1d_fwd_kernel");
+}
+
+extern "C" int sept_relu_pool1d_backward(const float* dy, const float* x, const float* dropscale,
+                                         const unsigned char* idx, float* dx, int B, int T, int C, int pool,
+                                         void* stream) {
+  if (B == 0) return SEPT_OK;
+  SEPT_REQUIRE(dy && x && idx && dx && B > 0 && T > 0 && C > 0 && pool > 0, SEPT_ERR_INVALID,
+               "sept_relu_pool1d_backward: bad argument");
+  hipLaunchKernelGGL(relu_pool1d_bwd_kernel, dim3(blocks_for(long(B) * T * C)), dim3(kThreads), 0, ST(stream), dy, x,
+                     dropscale, idx, dx, B, T, C, pool);
+  return sept::launch_check("relu_pool1d_bwd_kernel");
 }
 
 extern "C" int sept_sgd_step(float* p, const float* g, float* momentum_buf, long n, float lr, float momentum,

@@ -8,8 +8,7 @@ The torch sub-modules held here (`conv`, `rnn`, `dense1`, ...) are parameter con
 their own forward is never called and there is no eager/CPU fallback.
 
 Scope: att=None, rnn_cell='gru', hidden 64, global_feature concat
-not supported on the HIP path; `one_d_cnn_lstm` keeps its constructor/state-dict surface but
-its forward is not implemented yet (it raises).
+not supported on the HIP path.
 """
 try:
     from . import _paths  # noqa: F401
@@ -120,8 +119,8 @@ class deep_two_d_cnn_lstm(_TwoD):
 
 
 class one_d_cnn_lstm(nn.Module):
-    """Constructor / attribute / state-dict surface of baseline_models.py:19-99.  The forward
-    (a Conv1d stack, used only by the baseline trainer) has no HIP kernels yet."""
+    """baseline_models.py:19-140: a pure CNN over time (its RNN is constructed but never called,
+    :109).  Conv1d(k=5) = HIP unfold + exact-fp32 MFMA product; ReLU/MaxPool1d/Dropout fused."""
 
     def __init__(self, input_channel, input_spec_size, cnn_filter_size, lstm_hidden_size=128, num_layers_lstm=2,
                  pred='emotion', bidirectional=True, rnn_cell='gru', attention_size=256, variable_lengths=False,
@@ -163,4 +162,10 @@ class one_d_cnn_lstm(nn.Module):
         return None
 
     def forward(self, input_var, global_feature=None):
-        raise NotImplementedError("one_d_cnn_lstm.forward: Conv1d stack has no HIP kernels yet (SURVEY.md a8)")
+        if global_feature is not None:
+            raise NotImplementedError("global_feature concat (openSMILE functionals) is outside the HIP path")
+        if self.att is not None or self.pred == 'multitask':
+            raise NotImplementedError("att / multitask heads are outside the HIP path")
+        x = input_var.squeeze(dim=1).float()      # (B, T, F): time-major, mel bins are the Conv1d channels
+        head = self.pred_emotion_layer if self.pred == 'emotion' else self.pred_gender_layer
+        return SF.run_one_d(self, x, head)

@@ -72,6 +72,11 @@ SIGNATURES = {
     "sept_softmax_mean": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "sept_loss_sub_log": (c_int, [c_void_p, c_void_p, c_float, c_void_p]),
     "sept_permute_cols": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "sept_unfold1d": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "sept_fold1d": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "sept_relu_pool1d_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "sept_relu_pool1d_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                          c_void_p]),
     "sept_window_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                  c_void_p]),
     "sept_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float, c_int, c_float,

@@ -375,3 +375,94 @@ class GrlStepLossFn(torch.autograd.Function):
                                           scale_mean=mean, need_locs=False)
             drhos = ops.mul(drhos, g.expand_as(drhos).contiguous())
         return gd1, gd2, None, None, None, None, None, drhos, None, None
+
+
+# ---------------------------------------------------------------------------------------------
+# one_d_cnn_lstm (baseline_models.py:19-140): three Conv1d(k=5, pad=2)+ReLU+MaxPool1d+Dropout over
+# time with the mel bins as channels, flatten, classifier Linear+ReLU+Dropout, head.  A pure CNN
+# (its RNN is never called, :109).  Exact fp32: every product goes through sept_gemm.
+# ---------------------------------------------------------------------------------------------
+def one_d_forward(x, model, head, need_grad=True, injected=None):
+    require_cuda(x)
+    B, T, C = x.shape
+    train = model.training
+    inj = injected or {}
+    convs = [m for m in model.conv if isinstance(m, torch.nn.Conv1d)]
+    pools = [m.kernel_size if isinstance(m.kernel_size, int) else m.kernel_size[0]
+             for m in model.conv if isinstance(m, torch.nn.MaxPool1d)]
+    drops = [m.p for m in model.conv if isinstance(m, torch.nn.Dropout)]
+    S = SimpleNamespace(layers=[], B=B, train=train)
+    h = x.contiguous()
+    for li, (cv, pool, dp) in enumerate(zip(convs, pools, drops)):
+        cout, cin, _ = cv.weight.shape
+        t = h.shape[1]
+        wk = _cached("conv1d_w", cv.weight, lambda: ops.permute_cols(cv.weight.detach().reshape(cout, cin * 5), cin, 5))
+        col = ops.unfold1d(h)
+        y = ops.linear_forward(col, wk, cv.bias).view(B, t, cout)
+        mask = None
+        if train and (dp > 0 or "conv" in inj):
+            m = inj.get("conv")
+            mask = m[li] if m is not None else _drop_mask((B, t // pool, cout), x.device, dp)
+        out, idx = ops.relu_pool1d_forward(y, pool, mask)
+        S.layers.append(SimpleNamespace(col=col, y=y, idx=idx, mask=mask, pool=pool, wk=wk, cin=cin, cout=cout, t=t))
+        h = out
+    z = h.view(B, -1)
+    lin = model.classifier[0]
+    pdrop = model.classifier[2].p
+    d1 = ops.linear_forward(z, lin.weight, lin.bias)
+    dmask = None
+    if train and (pdrop > 0 or "dense" in inj):
+        m = inj.get("dense")
+        dmask = m if m is not None else _drop_mask(tuple(d1.shape), x.device, pdrop)
+    d1a = ops.relu_dropout_forward(d1, dmask)
+    logits = ops.linear_forward(d1a, head.weight, head.bias)
+    S.z, S.d1, S.dmask, S.d1a = z, d1, dmask, d1a
+    return logits, (S if need_grad else None)
+
+
+def one_d_backward(S, model, head, dlogits, need_dx=False):
+    grads = {}
+    B = S.B
+    convs = [m for m in model.conv if isinstance(m, torch.nn.Conv1d)]
+    lin = model.classifier[0]
+    dlogits = dlogits.contiguous()
+    d = ops.linear_backward_input(dlogits, head.weight)
+    grads[head.weight] = ops.linear_backward_weight(dlogits, S.d1a)
+    grads[head.bias] = ops.colsum(dlogits)
+    d = ops.relu_dropout_backward(d, S.d1, S.dmask)
+    grads[lin.weight] = ops.linear_backward_weight(d, S.z)
+    grads[lin.bias] = ops.colsum(d)
+    dh = ops.linear_backward_input(d, lin.weight)
+    for li in range(len(S.layers) - 1, -1, -1):
+        L, cv = S.layers[li], convs[li]
+        dh = dh.view(B, L.t // L.pool, L.cout)
+        dy = ops.relu_pool1d_backward(dh.contiguous(), L.y, L.idx, L.pool, L.mask).view(B * L.t, L.cout)
+        dwk = ops.linear_backward_weight(dy, L.col)
+        grads[cv.weight] = ops.permute_cols(dwk, L.cin, 5, inverse=True).view(L.cout, L.cin, 5)
+        grads[cv.bias] = ops.colsum(dy)
+        if li > 0 or need_dx:
+            dcol = ops.linear_backward_input(dy, L.wk)
+            dh = ops.fold1d(dcol, B, L.t, L.cin)
+    return (dh if need_dx else None), grads
+
+
+class OneDFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, model, head, injected, *params):
+        need = any(ctx.needs_input_grad)
+        logits, S = one_d_forward(x.detach().float().contiguous(), model, head, need_grad=need, injected=injected)
+        ctx.S, ctx.model, ctx.head, ctx.params = S, model, head, params
+        ctx.need_dx = x.requires_grad
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        dx, grads = one_d_backward(ctx.S, ctx.model, ctx.head, dlogits, need_dx=ctx.need_dx)
+        ctx.S = None
+        return (dx, None, None, None) + tuple(grads.get(p) if p.requires_grad else None for p in ctx.params)
+
+
+def run_one_d(model, x, head, injected=None):
+    params = [p for m in model.conv if isinstance(m, torch.nn.Conv1d) for p in (m.weight, m.bias)]
+    params += [model.classifier[0].weight, model.classifier[0].bias, head.weight, head.bias]
+    return OneDFn.apply(x, model, head, injected, *params)

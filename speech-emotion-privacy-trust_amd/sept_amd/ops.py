@@ -388,3 +388,34 @@ def softmax_mean(logits, nwin):
     check(lib.sept_softmax_mean(logits.contiguous().data_ptr(), B, nwin, C, probs.data_ptr(), pred.data_ptr(),
                                 _s(logits)), "sept_softmax_mean")
     return probs, pred
+
+
+def unfold1d(x):
+    """x (B, T, C) fp32 -> col (B*T, 5*C) for a k=5 / pad=2 Conv1d over T."""
+    B, T, C = x.shape
+    col = torch.empty((B * T, 5 * C), dtype=torch.float32, device=x.device)
+    check(lib.sept_unfold1d(x.data_ptr(), col.data_ptr(), B, T, C, _s(x)), "sept_unfold1d")
+    return col
+
+
+def fold1d(dcol, B, T, C):
+    dx = torch.empty((B, T, C), dtype=torch.float32, device=dcol.device)
+    check(lib.sept_fold1d(dcol.data_ptr(), dx.data_ptr(), B, T, C, _s(dcol)), "sept_fold1d")
+    return dx
+
+
+def relu_pool1d_forward(x, pool, dropscale=None):
+    B, T, C = x.shape
+    y = torch.empty((B, T // pool, C), dtype=torch.float32, device=x.device)
+    idx = torch.empty((B, T // pool, C), dtype=torch.uint8, device=x.device)
+    check(lib.sept_relu_pool1d_forward(x.data_ptr(), _p(dropscale), y.data_ptr(), idx.data_ptr(), B, T, C, pool, _s(x)),
+          "sept_relu_pool1d_forward")
+    return y, idx
+
+
+def relu_pool1d_backward(dy, x, idx, pool, dropscale=None):
+    B, T, C = x.shape
+    dx = torch.empty_like(x)
+    check(lib.sept_relu_pool1d_backward(dy.data_ptr(), x.data_ptr(), _p(dropscale), idx.data_ptr(), dx.data_ptr(), B, T,
+                                        C, pool, _s(x)), "sept_relu_pool1d_backward")
+    return dx

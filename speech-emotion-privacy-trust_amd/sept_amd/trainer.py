@@ -112,6 +112,45 @@ class GrlTrainer:
         return self.loss(preds, preds_grl, labels_emo, labels_gen, None, training=False), preds, preds_grl
 
 
+class BaselineTrainer:
+    """The baseline / adversary training step (training/training_adversary_baselines.py:165-185,
+    :424-429): a single classifier (two_d_cnn_lstm, deep_two_d_cnn_lstm or one_d_cnn_lstm), loss
+    sum_i w_i CE_i / B, SGD(lr 1e-4, m 0.9, wd 1e-4) or Adam(lr 5e-5, wd 1e-4, betas (0.9, 0.98),
+    eps 1e-9), one gradient all-reduce per step when sharded."""
+
+    def __init__(self, model, optimizer="sgd", lr=None, momentum=0.9, weight_decay=1e-4, betas=(0.9, 0.98),
+                 eps=1e-9, process_group=None):
+        self.model = model
+        self.flat = FlatParams(model.parameters())
+        self.kind = optimizer
+        if optimizer == "sgd":
+            self.lr = 1e-4 if lr is None else lr
+            self.buf = torch.zeros_like(self.flat.flat)
+        elif optimizer == "adam":
+            self.lr = 5e-5 if lr is None else lr
+            self.m, self.v = torch.zeros_like(self.flat.flat), torch.zeros_like(self.flat.flat)
+        else:
+            raise ValueError(f"unknown optimizer {optimizer}")
+        self.momentum, self.weight_decay, self.betas, self.eps = momentum, weight_decay, betas, eps
+        self.steps, self.pg, self.world = 0, process_group, 1
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self.world = torch.distributed.get_world_size(process_group)
+
+    optimizer_step = GrlTrainer.optimizer_step
+
+    def train_step(self, features, labels, weights=None):
+        self.model.train()
+        self.flat.zero_grad()
+        preds = self.model(features)
+        loss = SF.GrlStepLossFn.apply(preds, None, labels, None, weights, 0.0, 0.0, None, 0.0, 0.0)
+        loss.backward()
+        self.flat.gather_grads()
+        if self.world > 1:
+            torch.distributed.all_reduce(self.flat.grad, group=self.pg)
+        self.optimizer_step()
+        return loss.detach(), preds.detach()
+
+
 class FusedPipeline:
     """waveforms (B, L) on the device -> mel(n_fft 800, F) -> windows -> z-norm -> GRL step."""
 

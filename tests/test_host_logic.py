@@ -50,7 +50,7 @@ def test_product_modules_refuse_cpu():
     with pytest.raises((SeptError, RuntimeError)):
         grl(closed_form_input(2, W, 80), pooling="mean")
     from model import baseline_models as bm
-    with pytest.raises(NotImplementedError):
+    with pytest.raises((SeptError, RuntimeError)):
         bm.one_d_cnn_lstm(1, 80, 64, global_feature=0)(closed_form_input(2, W, 80))
 
 

@@ -311,3 +311,72 @@ def test_graph_replay_equals_eager_step():
         results.append((float(loss), tr.flat.flat.clone()))
     assert results[0][0] == pytest.approx(results[1][0], rel=1e-6)
     assert torch.equal(results[0][1], results[1][1])          # deterministic kernels: bit-identical
+
+
+@pytest.mark.parametrize("F", [80, 128])
+def test_one_d_cnn_vs_reference_and_oracle(F, G):
+    """one_d_cnn_lstm (baseline_models.py:19-140): eval logits against the reference golden; one
+    train-mode step (dropout off) against the oracle's gradients.  Exact fp32 path: tight bounds."""
+    from model import baseline_models as bm
+    x = closed_form_input(B, W, F)
+    kw = dict(lstm_hidden_size=64, num_layers_lstm=2, pred="emotion", attention_size=128, att=None, global_feature=0)
+    m = bm.one_d_cnn_lstm(1, F, 64, **kw)
+    sd = closed_form_state(m, prefix="one_d.")
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    with torch.no_grad():
+        np.testing.assert_allclose(m(x.cuda()).cpu().numpy(), G[f"f{F}_one_d_eval_logits"], rtol=1e-4, atol=1e-5)
+    ref = mo.one_d_cnn_lstm(1, F, 64, **kw)
+    ref.load_state_dict(sd)
+    m.train(), ref.train()
+    zero_dropout(m), zero_dropout(ref)
+    le, _, wts = closed_form_labels(B)
+    out = m(x.cuda())
+    (torch.nn.functional.cross_entropy(out, le.view(-1).cuda(), reduction="none") * wts.cuda()).mean().backward()
+    rout = ref(x)
+    (torch.nn.functional.cross_entropy(rout, le.view(-1), reduction="none") * wts).mean().backward()
+    assert torch.allclose(out.detach().cpu(), rout.detach(), rtol=1e-4, atol=1e-5)
+    got = dict(m.named_parameters())
+    for name, p in ref.named_parameters():
+        if p.grad is None:
+            assert got[name].grad is None, name
+            continue
+        g = got[name].grad.cpu()
+        assert float((g - p.grad).norm() / p.grad.norm()) < 5e-4, name   # fp32 path; summation order only
+
+
+def test_baseline_trainer_step_matches_torch_sgd():
+    """training_adversary_baselines.py step: weighted-mean CE + SGD(lr 1e-4, m 0.9, wd 1e-4) on a
+    one_d_cnn_lstm (exact fp32 path, so the updated parameters can be compared tightly)."""
+    from model import baseline_models as bm
+    from sept_amd.trainer import BaselineTrainer
+    F = 80
+    kw = dict(lstm_hidden_size=64, num_layers_lstm=2, pred="emotion", attention_size=128, att=None, global_feature=0)
+    m = bm.one_d_cnn_lstm(1, F, 64, **kw)
+    sd = closed_form_state(m, prefix="one_d.")
+    m.load_state_dict(sd)
+    m = m.cuda()
+    ref = mo.one_d_cnn_lstm(1, F, 64, **kw)
+    ref.load_state_dict(sd)
+    zero_dropout(m), zero_dropout(ref)
+    # the reference optimiser also updates the (unused) rnn / dense / attention parameters through
+    # weight decay only; restrict both sides to the parameters the forward touches
+    used = [n for n, p in ref.named_parameters() if n.startswith(("conv.", "classifier.", "pred_emotion_layer."))]
+    for n, p in m.named_parameters():
+        p.requires_grad = n in used
+    opt = torch.optim.SGD([p for n, p in ref.named_parameters() if n in used], lr=1e-4, momentum=0.9, weight_decay=1e-4)
+    tr = BaselineTrainer(m, optimizer="sgd")
+    x = closed_form_input(B, W, F)
+    le, _, wts = closed_form_labels(B)
+    for _ in range(2):
+        loss, _ = tr.train_step(x.cuda(), le.cuda(), wts.cuda())
+        ref.train()
+        opt.zero_grad()
+        rl = (torch.nn.functional.cross_entropy(ref(x), le.view(-1), reduction="none") * wts).sum() / B
+        rl.backward()
+        opt.step()
+        assert float(loss) == pytest.approx(float(rl), rel=1e-5)
+    got = dict(m.named_parameters())
+    for n, p in ref.named_parameters():
+        if n in used:
+            assert torch.allclose(got[n].detach().cpu(), p.detach(), rtol=1e-5, atol=1e-7), n
