@@ -211,6 +211,18 @@ int sept_relu_pool1d_forward(const float* x, const float* dropscale, float* y, u
                              int C, int pool, void* stream);
 int sept_relu_pool1d_backward(const float* dy, const float* x, const float* dropscale, const unsigned char* idx,
                               float* dx, int B, int T, int C, int pool, void* stream);
+/* Counter-based RNG (Philox4x32-10): element i of a draw is a function of (seed, offset, i) only.
+ * The effective stream offset is `offset + *offset_dev` (offset_dev nullable): a device-resident
+ * step counter (advanced with sept_counter_add) lets a captured graph draw fresh numbers on every
+ * replay, and equal (seed, offset) on every rank gives the ONE epsilon per step the reference
+ * broadcasts over the batch (cloak_models.py:37,45-50).
+ * sept_dropout_mask: 0 with probability p else 1/(1-p) (nn.Dropout / Dropout2d / GRU dropout
+ * scale masks, baseline_models.py:153,176,193);  sept_normal: N(mean, std) (Normal(0, 0.1)). */
+int sept_dropout_mask(float* out, long n, float p, unsigned long long seed, const long long* offset_dev,
+                      unsigned long long offset, void* stream);
+int sept_normal(float* out, long n, float mean, float stdv, unsigned long long seed, const long long* offset_dev,
+                unsigned long long offset, void* stream);
+int sept_counter_add(long long* counter, long long inc, void* stream);
 /* Windowing + per-speaker z-normalisation between the two halves of the path: mel (B, T, F)
  * time-major -> out (B*nwin, win, F), window i = frames [shift*i, shift*i + win) (zero padded
  * past T), each value (x - mean[f]) / (std[f] + 1e-5) when mean/std are given

@@ -298,6 +298,57 @@ __global__ void relu_pool1d_bwd_kernel(const float* dy, const float* x, const fl
   }
 }
 
+// ---------------- counter-based RNG (Philox4x32-10) ----------------
+// Stateless: element i of a draw is a pure function of (seed, stream offset, i), so every rank of
+// a data-parallel job that uses the same (seed, offset) gets the same epsilon and
+// a graph replay can advance the offset from a device counter.
+__device__ __forceinline__ uint4 philox4x32(uint4 ctr, uint2 key) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = 0xD2511F53ull * ctr.x, p1 = 0xCD9E8D57ull * ctr.z;
+    ctr = make_uint4(unsigned(p1 >> 32) ^ ctr.y ^ key.x, unsigned(p1), unsigned(p0 >> 32) ^ ctr.w ^ key.y, unsigned(p0));
+    key.x += 0x9E3779B9u;
+    key.y += 0xBB67AE85u;
+  }
+  return ctr;
+}
+__device__ __forceinline__ float u01(unsigned x) { return (float(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+// out[i] = 0 with probability p, else 1/(1-p)   (nn.Dropout / Dropout2d scale masks)
+__global__ void dropout_mask_kernel(float* out, long n, float p, unsigned long long seed, const long long* offset_dev,
+                                    unsigned long long offset) {
+  const unsigned long long off = offset + (offset_dev ? (unsigned long long)(*offset_dev) : 0ull);
+  const float keep = 1.0f / (1.0f - p);
+  GRID_STRIDE(q, (n + 3) / 4) {
+    const uint4 r = philox4x32(make_uint4(unsigned(q), unsigned(q >> 32), unsigned(off), unsigned(off >> 32)),
+                               make_uint2(unsigned(seed), unsigned(seed >> 32)));
+    const unsigned rv[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (4 * q + k < n) out[4 * q + k] = u01(rv[k]) >= p ? keep : 0.f;
+  }
+}
+// out[i] ~ N(mean, std)  (Box-Muller on Philox uniforms): the cloak epsilon, Normal(0, 0.1)
+__global__ void normal_kernel(float* out, long n, float mean, float stdv, unsigned long long seed,
+                              const long long* offset_dev, unsigned long long offset) {
+  const unsigned long long off = offset + (offset_dev ? (unsigned long long)(*offset_dev) : 0ull);
+  GRID_STRIDE(q, (n + 3) / 4) {
+    const uint4 r = philox4x32(make_uint4(unsigned(q), unsigned(q >> 32), unsigned(off), unsigned(off >> 32)),
+                               make_uint2(unsigned(seed), unsigned(seed >> 32)));
+    const float r0 = sqrtf(-2.0f * logf(u01(r.x))), r1 = sqrtf(-2.0f * logf(u01(r.z)));
+    float s0, c0, s1, c1;
+    sincosf(6.28318530718f * u01(r.y), &s0, &c0);
+    sincosf(6.28318530718f * u01(r.w), &s1, &c1);
+    const float v[4] = {r0 * c0, r0 * s0, r1 * c1, r1 * s1};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (4 * q + k < n) out[4 * q + k] = mean + stdv * v[k];
+  }
+}
+__global__ void counter_add_kernel(long long* c, long long inc) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *c += inc;
+}
+
 // ---------------- optimisers (training_cloak_with_grl.py:416-421) ----------------
 // torch.optim.SGD(momentum, weight_decay, dampening 0, nesterov False)
 __global__ void sgd_kernel(float* p, const float* g, float* buf, long n, float lr, float momentum, float wd,
@@ -493,6 +544,30 @@ extern "C" int sept_relu_pool1d_backward(const float* dy, const float* x, const 
   hipLaunchKernelGGL(relu_pool1d_bwd_kernel, dim3(blocks_for(long(B) * T * C)), dim3(kThreads), 0, ST(stream), dy, x,
                      dropscale, idx, dx, B, T, C, pool);
   return sept::launch_check("relu_pool1d_bwd_kernel");
+}
+
+extern "C" int sept_dropout_mask(float* out, long n, float p, unsigned long long seed, const long long* offset_dev,
+                                 unsigned long long offset, void* stream) {
+  if (n == 0) return SEPT_OK;
+  SEPT_REQUIRE(out && n > 0 && p >= 0.f && p < 1.f, SEPT_ERR_INVALID, "sept_dropout_mask: bad argument");
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(blocks_for((n + 3) / 4)), dim3(kThreads), 0, ST(stream), out, n, p, seed,
+                     offset_dev, offset);
+  return sept::launch_check("dropout_mask_kernel");
+}
+
+extern "C" int sept_normal(float* out, long n, float mean, float stdv, unsigned long long seed,
+                           const long long* offset_dev, unsigned long long offset, void* stream) {
+  if (n == 0) return SEPT_OK;
+  SEPT_REQUIRE(out && n > 0, SEPT_ERR_INVALID, "sept_normal: bad argument");
+  hipLaunchKernelGGL(normal_kernel, dim3(blocks_for((n + 3) / 4)), dim3(kThreads), 0, ST(stream), out, n, mean, stdv, seed,
+                     offset_dev, offset);
+  return sept::launch_check("normal_kernel");
+}
+
+extern "C" int sept_counter_add(long long* counter, long long inc, void* stream) {
+  SEPT_REQUIRE(counter, SEPT_ERR_INVALID, "sept_counter_add: null argument");
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, ST(stream), counter, inc);
+  return sept::launch_check("counter_add_kernel");
 }
 
 extern "C" int sept_sgd_step(float* p, const float* g, float* momentum_buf, long n, float lr, float momentum,

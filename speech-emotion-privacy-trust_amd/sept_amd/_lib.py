@@ -2,7 +2,7 @@
 library has not been built: the product path never falls back to CPU/eager code."""
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int, c_long, c_size_t, c_void_p
+from ctypes import POINTER, c_char_p, c_float, c_int, c_long, c_size_t, c_ulonglong, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "..", "csrc", "libsept_hip.so")
@@ -77,6 +77,9 @@ SIGNATURES = {
     "sept_relu_pool1d_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "sept_relu_pool1d_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                           c_void_p]),
+    "sept_dropout_mask": (c_int, [c_void_p, c_long, c_float, c_ulonglong, c_void_p, c_ulonglong, c_void_p]),
+    "sept_normal": (c_int, [c_void_p, c_long, c_float, c_float, c_ulonglong, c_void_p, c_ulonglong, c_void_p]),
+    "sept_counter_add": (c_int, [c_void_p, c_long, c_void_p]),
     "sept_window_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                  c_void_p]),
     "sept_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float, c_int, c_float,

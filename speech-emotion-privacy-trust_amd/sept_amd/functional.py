@@ -77,7 +77,8 @@ def trunk_params(model, head: str):
 
 
 def _drop_mask(shape, device, p=DROP_P):
-    return (torch.rand(shape, device=device) >= p).float().mul_(1.0 / (1.0 - p))
+    """0 / (1/(1-p)) scale mask from the device's Philox stream (one HIP launch)."""
+    return ops.rng(device, "dropout").dropout_mask(shape, p)
 
 
 def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None):

@@ -419,3 +419,53 @@ def relu_pool1d_backward(dy, x, idx, pool, dropscale=None):
     check(lib.sept_relu_pool1d_backward(dy.data_ptr(), x.data_ptr(), _p(dropscale), idx.data_ptr(), dx.data_ptr(), B, T,
                                         C, pool, _s(x)), "sept_relu_pool1d_backward")
     return dx
+
+
+class Rng:
+    """Philox stream of one device: `seed` fixed, a device-resident draw counter (so graph replays
+    keep drawing fresh numbers) plus a host-side sub-stream id per call site within a step."""
+
+    def __init__(self, seed: int, device):
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.counter = torch.zeros((), dtype=torch.int64, device=device)
+        self.sub = 0
+
+    def _next(self):
+        self.sub += 1
+        return self.sub << 40            # disjoint offset ranges per call site; the counter moves within one
+
+    def begin_step(self):
+        """Advance the device counter once per step and restart the call-site numbering."""
+        check(lib.sept_counter_add(self.counter.data_ptr(), 1, _s(self.counter)), "sept_counter_add")
+        self.sub = 0
+
+    def dropout_mask(self, shape, p):
+        out = torch.empty(shape, dtype=torch.float32, device=self.counter.device)
+        check(lib.sept_dropout_mask(out.data_ptr(), out.numel(), float(p), self.seed, self.counter.data_ptr(),
+                                    self._next(), _s(out)), "sept_dropout_mask")
+        return out
+
+    def normal(self, shape, mean=0.0, std=1.0):
+        out = torch.empty(shape, dtype=torch.float32, device=self.counter.device)
+        check(lib.sept_normal(out.data_ptr(), out.numel(), float(mean), float(std), self.seed,
+                              self.counter.data_ptr(), self._next(), _s(out)), "sept_normal")
+        return out
+
+
+_RNGS = {}
+
+
+def rng(device, name="dropout", seed=None) -> Rng:
+    """Per-(device, name) Philox stream.  'eps' is seeded identically on every rank (shared cloak
+    epsilon); 'dropout' mixes in the rank so shards draw different masks."""
+    key = (str(device), name)
+    r = _RNGS.get(key)
+    if r is None or seed is not None:
+        if seed is None:
+            seed = torch.initial_seed()
+            if name == "dropout" and torch.distributed.is_available() and torch.distributed.is_initialized():
+                seed = seed * 1000003 + 7919 * (torch.distributed.get_rank() + 1)
+            if name == "eps":
+                seed = seed ^ 0x5EED5EED
+        r = _RNGS[key] = Rng(seed, device)
+    return r

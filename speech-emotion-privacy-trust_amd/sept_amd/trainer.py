@@ -14,6 +14,12 @@ from . import ops
 from .mel import LAYOUT_BTF, get_mel_plan
 
 
+def _advance_rng(device):
+    """New Philox sub-streams for this step (device-side counters: also valid inside a graph)."""
+    ops.rng(device, "dropout").begin_step()
+    ops.rng(device, "eps").begin_step()
+
+
 class FlatParams:
     """Packs the trainable parameters into one flat fp32 buffer (parameters become views), so
     the optimiser is one kernel launch and data-parallel needs one all-reduce over one buffer."""
@@ -94,6 +100,7 @@ class GrlTrainer:
         (loss, preds, preds_grl); loss is a 0-dim device tensor (no host sync here)."""
         self.model.train()
         self.flat.zero_grad()
+        _advance_rng(features.device)
         preds, preds_grl, _ = self.model(features, mask=mask, grl=False, pooling=pooling)
         loss = self.loss(preds, preds_grl, labels_emo, labels_gen, weights, training=True)
         loss.backward()
@@ -141,6 +148,7 @@ class BaselineTrainer:
     def train_step(self, features, labels, weights=None):
         self.model.train()
         self.flat.zero_grad()
+        _advance_rng(features.device)
         preds = self.model(features)
         loss = SF.GrlStepLossFn.apply(preds, None, labels, None, weights, 0.0, 0.0, None, 0.0, 0.0)
         loss.backward()
@@ -188,6 +196,7 @@ class FusedPipeline:
         tr.flat.zero_grad()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
+            _advance_rng(wav.device)
             x = self.features(wav)
             preds, preds_grl, _ = tr.model(x.view(x.shape[0], 1, self.win, self.n_mels), mask=None, grl=False,
                                            pooling="mean")

@@ -153,3 +153,27 @@ def test_optimizer_steps_match_torch(kind):
         else:
             ops.adam_step(p, (2 * gr).cuda(), b1, b2, 5e-4, 0.9, 0.98, 1e-9, 1e-4, step, grad_scale=0.5)
         assert torch.allclose(p.cpu(), ref.detach(), rtol=1e-5, atol=1e-7), step
+
+
+def test_philox_dropout_and_normal_statistics():
+    """sept_dropout_mask / sept_normal: right distribution, reproducible for equal (seed, counter),
+    fresh after begin_step(), different sub-streams per call site."""
+    from sept_amd import ops
+    r = ops.Rng(1234, "cuda")
+    r.begin_step()
+    m = r.dropout_mask((1000, 1000), 0.2)
+    vals = torch.unique(m)
+    assert vals.numel() == 2 and float(vals[0]) == 0.0 and float(vals[1]) == pytest.approx(1.25)
+    assert abs(float((m == 0).float().mean()) - 0.2) < 2e-3
+    e = r.normal((1, 200, 128), 0.0, 0.1)
+    assert abs(float(e.mean())) < 2e-3 and abs(float(e.std()) - 0.1) < 2e-3
+    z = r.normal((1000, 1000))
+    assert abs(float(z.mean())) < 5e-3 and abs(float(z.std()) - 1.0) < 5e-3 and float(z.abs().max()) < 7.0
+    assert abs(float((z.abs() < 1.0).float().mean()) - 0.6827) < 3e-3
+    r2 = ops.Rng(1234, "cuda")          # same seed, same counter, same call order -> identical draws
+    r2.begin_step()
+    assert torch.equal(r2.dropout_mask((1000, 1000), 0.2), m)
+    assert torch.equal(r2.normal((1, 200, 128), 0.0, 0.1), e)
+    r2.begin_step()                      # next step: fresh numbers
+    assert not torch.equal(r2.dropout_mask((1000, 1000), 0.2), m)
+    assert not torch.equal(ops.Rng(99, "cuda").dropout_mask((1000, 1000), 0.2), m)
