@@ -16,7 +16,7 @@
 namespace {
 
 constexpr int kH = 64;   // hidden size (trainer: lstm_hidden_size = 64)
-constexpr int kBS = 4;   // samples per workgroup
+constexpr int kBS = 2;   // samples per workgroup (2 x 64 lanes: enough workgroups to cover 256 CUs at B = 224)
 
 struct GruArgs {
   const float* gi;   // [B][T][2][3H]

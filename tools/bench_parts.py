@@ -28,3 +28,11 @@ for (h, wd, C) in [(200, 80, 32), (100, 40, 64), (50, 20, 128)]:
     timeit(f"bn_fwd C={C}", lambda: ops.bn_relu_pool_forward(xa, mean, invstd, g, be, None, 2))
     dyp = torch.randn(B, h // 2, wd // 2, C, device="cuda").bfloat16()
     timeit(f"bn_bwd C={C}", lambda: ops.bn_relu_pool_backward(dyp, xa, mean, invstd, g, be, None, 2))
+T, Hh = 25, 64
+gi = torch.randn(B, T, 2, 192, device="cuda")
+whf, whr = torch.randn(192, 64, device="cuda") * 0.1, torch.randn(192, 64, device="cuda") * 0.1
+bhf, bhr = torch.randn(192, device="cuda"), torch.randn(192, device="cuda")
+out, gates = ops.gru_forward(gi, whf, whr, bhf, bhr)
+dout = torch.randn_like(out)
+timeit("gru_forward", lambda: ops.gru_forward(gi, whf, whr, bhf, bhr))
+timeit("gru_backward", lambda: ops.gru_backward(dout, out, gates, whf, whr))
