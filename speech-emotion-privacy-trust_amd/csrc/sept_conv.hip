@@ -43,8 +43,15 @@ __host__ __device__ constexpr int conv_nr_max(int mt, int w) { return (mt + w - 
 // The workgroup is a WP x WN grid of waves: WP pixel groups (PB blocks of 32 pixels each) times
 // WN slices of the output channels.  8-wave shapes put two waves on every SIMD, so the LDS /
 // global-load latency of one hides under the other's MFMAs (measured 1.3-1.9x over 4 waves).
-template <int CIN, int COUT, int PB, int WP, int WN>
+// TG taps share one barrier interval: their weight tiles are staged together (the next group is
+// prefetched into registers under the MFMAs), so a tile costs 2 * ceil(25 / TG) barriers instead
+// of 25 and each interval carries TG times the MFMA work to hide the staging latency under.
+// TG = 0: one tap per interval with TWO weight buffers (one barrier per tap); costs one more
+// weight tile of LDS, which matters when it decides how many workgroups share a CU.
+template <int CIN, int COUT, int PB, int WP, int WN, int TGP>
 __global__ __launch_bounds__(64 * WP * WN) void sept_conv5x5_mfma_kernel(ConvArgs a) {
+  constexpr bool DBUF = TGP == 0;
+  constexpr int TG = DBUF ? 1 : TGP;
   constexpr int MT = 32 * PB * WP;
   constexpr int NTHR = 64 * WP * WN;
   constexpr int NB = COUT / 32 / WN;  // output-channel blocks per wave
@@ -52,7 +59,8 @@ __global__ __launch_bounds__(64 * WP * WN) void sept_conv5x5_mfma_kernel(ConvArg
   constexpr int PS = CIN * 2 + 16;   // bytes per staged pixel (padded)
   constexpr int PSW = CIN * 2 + 16;  // bytes per staged weight row (padded)
   constexpr int CPP = CIN / 8;       // 16-B chunks per pixel
-  constexpr int WCH = (COUT * CPP + NTHR - 1) / NTHR;
+  constexpr int WCH = (TG * COUT * CPP + NTHR - 1) / NTHR;  // 16-B weight chunks a lane stages per group
+  constexpr int NG = (kTaps + TG - 1) / TG;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int W = a.W, H = a.H, HW = H * W, W4 = W + 4;
   unsigned char* tile = smem;
@@ -80,20 +88,22 @@ __global__ __launch_bounds__(64 * WP * WN) void sept_conv5x5_mfma_kernel(ConvArg
       *reinterpret_cast<uint4*>(tile + size_t(px) * PS + c * 16) = v;
     }
   }
-  auto wload = [&](int tap, uint4 (&r)[WCH]) {
-    const bf16* wsrc = a.wt + size_t(tap) * COUT * CIN;
+  auto wload = [&](int g, uint4 (&r)[WCH]) {  // group g = taps [g*TG, min(25, (g+1)*TG)), contiguous in wt
+    const bf16* wsrc = a.wt + size_t(g) * TG * COUT * CIN;
+    const int n = min(TG, kTaps - g * TG) * COUT * CPP;
 #pragma unroll
     for (int j = 0; j < WCH; ++j) {
       const int i = tid + NTHR * j;
-      if (i < COUT * CPP) r[j] = *reinterpret_cast<const uint4*>(wsrc + size_t(i) * 8);
+      if (i < n) r[j] = *reinterpret_cast<const uint4*>(wsrc + size_t(i) * 8);
     }
   };
-  auto wstore = [&](int buf, const uint4 (&r)[WCH]) {
-    unsigned char* dst = wbuf + size_t(buf) * COUT * PSW;
+  auto wstore = [&](int g, const uint4 (&r)[WCH]) {
+    const int n = min(TG, kTaps - g * TG) * COUT * CPP;
+    unsigned char* dst = wbuf + (DBUF ? size_t(g & 1) * COUT * PSW : 0);
 #pragma unroll
     for (int j = 0; j < WCH; ++j) {
       const int i = tid + NTHR * j;
-      if (i < COUT * CPP) *reinterpret_cast<uint4*>(dst + (i / CPP) * PSW + (i % CPP) * 16) = r[j];
+      if (i < n) *reinterpret_cast<uint4*>(dst + (i / CPP) * PSW + (i % CPP) * 16) = r[j];  // row = tap_local*COUT + cout
     }
   };
   {
@@ -120,29 +130,40 @@ __global__ __launch_bounds__(64 * WP * WN) void sept_conv5x5_mfma_kernel(ConvArg
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[pb][nb][r] = 0.f;
 
-  for (int tap = 0; tap < kTaps; ++tap) {
-    const int kh = tap / 5, kw = tap - kh * 5;
-    const int tapoff = (kh * W4 + kw) * PS;
+  for (int g = 0; g < NG; ++g) {
     uint4 wreg[WCH];
-    if (tap + 1 < kTaps) wload(tap + 1, wreg);
-    const unsigned char* wb = wbuf + size_t(tap & 1) * COUT * PSW;
+    if (g + 1 < NG) wload(g + 1, wreg);  // in flight under this group's MFMAs
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      bf16x8 bfrag[PB], afrag[NB];
+    for (int tl = 0; tl < TG; ++tl) {
+      const int tap = g * TG + tl;
+      if (tap >= kTaps) break;
+      const int kh = tap / 5, kw = tap - kh * 5;
+      const int tapoff = (kh * W4 + kw) * PS;
+      const unsigned char* wb = wbuf + size_t(DBUF ? (g & 1) : tl) * COUT * PSW;
 #pragma unroll
-      for (int pb = 0; pb < PB; ++pb)
-        bfrag[pb] = *reinterpret_cast<const bf16x8*>(tile + lane_base[pb] + tapoff + ks * 32);
+      for (int ks = 0; ks < KS; ++ks) {
+        bf16x8 bfrag[PB], afrag[NB];
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb)
-        afrag[nb] = *reinterpret_cast<const bf16x8*>(wb + nb * 32 * PSW + a_base + ks * 32);
-#pragma unroll
-      for (int pb = 0; pb < PB; ++pb)
+        for (int pb = 0; pb < PB; ++pb)
+          bfrag[pb] = *reinterpret_cast<const bf16x8*>(tile + lane_base[pb] + tapoff + ks * 32);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
-          acc[pb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[nb], bfrag[pb], acc[pb][nb], 0, 0, 0);
+          afrag[nb] = *reinterpret_cast<const bf16x8*>(wb + nb * 32 * PSW + a_base + ks * 32);
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[pb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[nb], bfrag[pb], acc[pb][nb], 0, 0, 0);
+      }
     }
-    if (tap + 1 < kTaps) wstore((tap + 1) & 1, wreg);
-    __syncthreads();
+    if constexpr (DBUF) {
+      if (g + 1 < NG) wstore(g + 1, wreg);  // other buffer: nobody reads it during this interval
+      __syncthreads();
+    } else if (g + 1 < NG) {
+      __syncthreads();  // every wave is done reading this group's weights
+      wstore(g + 1, wreg);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: + bias, round to bf16, 8-byte NHWC stores ----
@@ -187,20 +208,28 @@ __global__ void sept_conv5x5_prep_kernel(const float* w, bf16* wt, int cout, int
 }
 
 struct ConvVariant {
-  int cin, cout, pb, wp, wn;
+  int cin, cout, pb, wp, wn, tg;
   const void* fn;
 };
-#define SEPT_CONV_VARIANT(ci, co, pb, wp, wn) \
-  { ci, co, pb, wp, wn, reinterpret_cast<const void*>(&sept_conv5x5_mfma_kernel<ci, co, pb, wp, wn>) }
-// first entry that fits the LDS wins; order = measured preference at the training shapes
-// (tools/sweep_conv.py): the 8-wave 256-pixel tiles first, 4-wave fallbacks for wide images.
+#define SEPT_CONV_VARIANT(ci, co, pb, wp, wn, tg) \
+  { ci, co, pb, wp, wn, tg, reinterpret_cast<const void*>(&sept_conv5x5_mfma_kernel<ci, co, pb, wp, wn, tg>) }
+// Order = measured preference of tile shapes at the training shapes (tools/sweep_conv.py): the
+// 8-wave 256-pixel tiles first, smaller tiles for wide images.  Within one tile shape the
+// double-buffered form (TG 0, one barrier per tap) is listed before the single-buffered one
+// (TG 1); the dispatcher takes the single-buffered form when dropping the second weight buffer
+// lets one more workgroup share the CU (e.g. 64->128 at 50x20: 2 workgroups, 163 -> 136 us).
 const ConvVariant kConvVariants[] = {
-    SEPT_CONV_VARIANT(32, 64, 2, 4, 2),   SEPT_CONV_VARIANT(32, 64, 2, 4, 1),   SEPT_CONV_VARIANT(32, 64, 1, 4, 1),
-    SEPT_CONV_VARIANT(64, 128, 2, 4, 2),  SEPT_CONV_VARIANT(64, 128, 1, 4, 2),  SEPT_CONV_VARIANT(64, 128, 1, 4, 1),
-    SEPT_CONV_VARIANT(64, 32, 1, 8, 1),   SEPT_CONV_VARIANT(64, 32, 1, 4, 1),   SEPT_CONV_VARIANT(64, 32, 2, 4, 1),
-    SEPT_CONV_VARIANT(128, 64, 2, 4, 2),  SEPT_CONV_VARIANT(128, 64, 1, 4, 2),  SEPT_CONV_VARIANT(128, 64, 1, 4, 1),
-    SEPT_CONV_VARIANT(128, 128, 2, 4, 2), SEPT_CONV_VARIANT(128, 128, 1, 4, 2), SEPT_CONV_VARIANT(128, 128, 1, 4, 1),
+    SEPT_CONV_VARIANT(32, 64, 2, 4, 2, 0),   SEPT_CONV_VARIANT(32, 64, 2, 4, 2, 1),   SEPT_CONV_VARIANT(32, 64, 1, 4, 1, 1),
+    SEPT_CONV_VARIANT(64, 128, 2, 4, 2, 0),  SEPT_CONV_VARIANT(64, 128, 2, 4, 2, 1),  SEPT_CONV_VARIANT(64, 128, 2, 4, 2, 2),
+    SEPT_CONV_VARIANT(64, 128, 1, 4, 2, 1),  SEPT_CONV_VARIANT(64, 128, 1, 4, 1, 1),
+    SEPT_CONV_VARIANT(64, 32, 1, 8, 1, 0),   SEPT_CONV_VARIANT(64, 32, 1, 8, 1, 1),   SEPT_CONV_VARIANT(64, 32, 1, 4, 1, 1),
+    SEPT_CONV_VARIANT(128, 64, 2, 4, 2, 0),  SEPT_CONV_VARIANT(128, 64, 2, 4, 2, 1),  SEPT_CONV_VARIANT(128, 64, 1, 4, 2, 0),
+    SEPT_CONV_VARIANT(128, 64, 1, 4, 2, 1),  SEPT_CONV_VARIANT(128, 64, 1, 4, 1, 1),
+    SEPT_CONV_VARIANT(128, 128, 2, 4, 2, 0), SEPT_CONV_VARIANT(128, 128, 2, 4, 2, 1), SEPT_CONV_VARIANT(128, 128, 1, 4, 2, 1),
+    SEPT_CONV_VARIANT(128, 128, 1, 4, 1, 1),
 };
+
+
 
 }  // namespace
 
@@ -225,15 +254,21 @@ extern "C" int sept_conv5x5_forward(const void* x, const void* wt, const float* 
   size_t best_smem = 0;
   const int force_pb = getenv("SEPT_CONV_PB") ? atoi(getenv("SEPT_CONV_PB")) : 0;  // tuning aids
   const int force_ns = getenv("SEPT_CONV_NS") ? atoi(getenv("SEPT_CONV_NS")) : 0;
+  const int force_tg = getenv("SEPT_CONV_TG") ? atoi(getenv("SEPT_CONV_TG")) : 0;
   for (const ConvVariant& v : kConvVariants) {
     if (v.cin != cin || v.cout != cout) continue;
     if (force_pb && v.pb != force_pb) continue;
     if (force_ns && v.wp * v.wn != 4 * force_ns) continue;
+    if (force_tg && v.tg != (force_tg == 9 ? 0 : force_tg)) continue;  // SEPT_CONV_TG=9 selects the double-buffered form
     const int mt = 32 * v.pb * v.wp;
     const size_t ps = size_t(cin) * 2 + 16;
-    const size_t smem = size_t(conv_nr_max(mt, W)) * (W + 4) * ps + 2 * size_t(cout) * ps;
+    const size_t smem = size_t(conv_nr_max(mt, W)) * (W + 4) * ps + size_t(v.tg == 0 ? 2 : v.tg) * cout * ps;
     if (smem > 160 * 1024) continue;
     if (!best) {
+      best = &v;
+      best_smem = smem;
+    } else if (!force_tg && best->tg == 0 && v.tg == 1 && v.pb == best->pb && v.wp == best->wp && v.wn == best->wn &&
+               (160 * 1024) / smem > (160 * 1024) / best_smem) {
       best = &v;
       best_smem = smem;
     }
