@@ -16,6 +16,7 @@
 // output channels; weights stream through a double-buffered per-tap LDS tile (prefetched
 // into registers under the MFMAs, one barrier per tap).  Pixel stride in LDS is padded by
 // 16 B so the 16-lane groups of ds_read_b128 hit distinct banks.
+#include <algorithm>
 #include <cstdlib>
 
 #include "sept_common.h"
@@ -48,10 +49,14 @@ __host__ __device__ constexpr int conv_nr_max(int mt, int w) { return (mt + w - 
 // of 25 and each interval carries TG times the MFMA work to hide the staging latency under.
 // TG = 0: one tap per interval with TWO weight buffers (one barrier per tap); costs one more
 // weight tile of LDS, which matters when it decides how many workgroups share a CU.
-template <int CIN, int COUT, int PB, int WP, int WN, int TGP>
+// CS > 1: the input channels are processed in CS slices, each with its own staged tile and weight
+// tiles (the accumulators run across slices): for wide inputs (128 channels) this halves the
+// LDS tile so that two workgroups fit on a CU.
+template <int CINF, int COUT, int PB, int WP, int WN, int TGP, int CS>
 __global__ __launch_bounds__(64 * WP * WN) void sept_conv5x5_mfma_kernel(ConvArgs a) {
   constexpr bool DBUF = TGP == 0;
   constexpr int TG = DBUF ? 1 : TGP;
+  constexpr int CIN = CINF / CS;  // channels per slice
   constexpr int MT = 32 * PB * WP;
   constexpr int NTHR = 64 * WP * WN;
   constexpr int NB = COUT / 32 / WN;  // output-channel blocks per wave
@@ -74,27 +79,14 @@ __global__ __launch_bounds__(64 * WP * WN) void sept_conv5x5_mfma_kernel(ConvArg
   const int h_last = min(q0 + MT - 1, HW - 1) / W;
   const int NR = h_last - h_first + 5;
 
-  // ---- stage input rows [h_first-2, h_last+2] x cols [-2, W+2) ----
-  {
-    const bf16* xb = a.x + size_t(b) * HW * CIN;
-    const int total = NR * W4 * CPP;
-    for (int i = tid; i < total; i += NTHR) {
-      const int c = i % CPP, px = i / CPP;
-      const int col = px % W4, row = px / W4;
-      const int h = h_first - 2 + row, w = col - 2;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (h >= 0 && h < H && w >= 0 && w < W)
-        v = *reinterpret_cast<const uint4*>(xb + (size_t(h) * W + w) * CIN + c * 8);
-      *reinterpret_cast<uint4*>(tile + size_t(px) * PS + c * 16) = v;
-    }
-  }
+  int c0 = 0;  // first input channel of the current slice
   auto wload = [&](int g, uint4 (&r)[WCH]) {  // group g = taps [g*TG, min(25, (g+1)*TG)), contiguous in wt
-    const bf16* wsrc = a.wt + size_t(g) * TG * COUT * CIN;
+    const bf16* wsrc = a.wt + size_t(g) * TG * COUT * CINF + c0;
     const int n = min(TG, kTaps - g * TG) * COUT * CPP;
 #pragma unroll
     for (int j = 0; j < WCH; ++j) {
       const int i = tid + NTHR * j;
-      if (i < n) r[j] = *reinterpret_cast<const uint4*>(wsrc + size_t(i) * 8);
+      if (i < n) r[j] = *reinterpret_cast<const uint4*>(wsrc + size_t(i / CPP) * CINF + (i % CPP) * 8);
     }
   };
   auto wstore = [&](int g, const uint4 (&r)[WCH]) {
@@ -106,13 +98,6 @@ __global__ __launch_bounds__(64 * WP * WN) void sept_conv5x5_mfma_kernel(ConvArg
       if (i < n) *reinterpret_cast<uint4*>(dst + (i / CPP) * PSW + (i % CPP) * 16) = r[j];  // row = tap_local*COUT + cout
     }
   };
-  {
-    uint4 r[WCH];
-    wload(0, r);
-    wstore(0, r);
-  }
-  __syncthreads();
-
   int lane_base[PB];
 #pragma unroll
   for (int pb = 0; pb < PB; ++pb) {
@@ -130,6 +115,29 @@ __global__ __launch_bounds__(64 * WP * WN) void sept_conv5x5_mfma_kernel(ConvArg
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[pb][nb][r] = 0.f;
 
+  for (int cs = 0; cs < CS; ++cs) {
+  c0 = cs * CIN;
+  if (cs > 0) __syncthreads();  // previous slice's tile and weights are no longer read
+  // ---- stage input rows [h_first-2, h_last+2] x cols [-2, W+2) ----
+  {
+    const bf16* xb = a.x + size_t(b) * HW * CINF + c0;
+    const int total = NR * W4 * CPP;
+    for (int i = tid; i < total; i += NTHR) {
+      const int c = i % CPP, px = i / CPP;
+      const int col = px % W4, row = px / W4;
+      const int h = h_first - 2 + row, w = col - 2;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (h >= 0 && h < H && w >= 0 && w < W)
+        v = *reinterpret_cast<const uint4*>(xb + (size_t(h) * W + w) * CINF + c * 8);
+      *reinterpret_cast<uint4*>(tile + size_t(px) * PS + c * 16) = v;
+    }
+  }
+  {
+    uint4 r[WCH];
+    wload(0, r);
+    wstore(0, r);
+  }
+  __syncthreads();
   for (int g = 0; g < NG; ++g) {
     uint4 wreg[WCH];
     if (g + 1 < NG) wload(g + 1, wreg);  // in flight under this group's MFMAs
@@ -165,6 +173,7 @@ __global__ __launch_bounds__(64 * WP * WN) void sept_conv5x5_mfma_kernel(ConvArg
       __syncthreads();
     }
   }
+  }  // channel slices
 
   // ---- epilogue: + bias, round to bf16, 8-byte NHWC stores ----
   bf16* yb = a.y + size_t(b) * HW * COUT;
@@ -208,28 +217,27 @@ __global__ void sept_conv5x5_prep_kernel(const float* w, bf16* wt, int cout, int
 }
 
 struct ConvVariant {
-  int cin, cout, pb, wp, wn, tg;
+  int cin, cout, pb, wp, wn, tg, cs;
   const void* fn;
 };
-#define SEPT_CONV_VARIANT(ci, co, pb, wp, wn, tg) \
-  { ci, co, pb, wp, wn, tg, reinterpret_cast<const void*>(&sept_conv5x5_mfma_kernel<ci, co, pb, wp, wn, tg>) }
+#define SEPT_CONV_VARIANT(ci, co, pb, wp, wn, tg, cs) \
+  { ci, co, pb, wp, wn, tg, cs, reinterpret_cast<const void*>(&sept_conv5x5_mfma_kernel<ci, co, pb, wp, wn, tg, cs>) }
 // Order = measured preference of tile shapes at the training shapes (tools/sweep_conv.py): the
-// 8-wave 256-pixel tiles first, smaller tiles for wide images.  Within one tile shape the
-// double-buffered form (TG 0, one barrier per tap) is listed before the single-buffered one
-// (TG 1); the dispatcher takes the single-buffered form when dropping the second weight buffer
-// lets one more workgroup share the CU (e.g. 64->128 at 50x20: 2 workgroups, 163 -> 136 us).
+// 8-wave 256-pixel tiles first, smaller tiles for wide images.  Within the first tile shape that
+// fits, the dispatcher scores the buffering (TG 0 double / TG 1 single) and channel-slice (CS)
+// forms by whether two workgroups fit on a CU -- e.g. 64->128 at 50x20: one workgroup (163 us),
+// single buffer -> two (136 us), two channel slices + double buffer -> two (105 us, 875 TFLOP/s).
 const ConvVariant kConvVariants[] = {
-    SEPT_CONV_VARIANT(32, 64, 2, 4, 2, 0),   SEPT_CONV_VARIANT(32, 64, 2, 4, 2, 1),   SEPT_CONV_VARIANT(32, 64, 1, 4, 1, 1),
-    SEPT_CONV_VARIANT(64, 128, 2, 4, 2, 0),  SEPT_CONV_VARIANT(64, 128, 2, 4, 2, 1),  SEPT_CONV_VARIANT(64, 128, 2, 4, 2, 2),
-    SEPT_CONV_VARIANT(64, 128, 1, 4, 2, 1),  SEPT_CONV_VARIANT(64, 128, 1, 4, 1, 1),
-    SEPT_CONV_VARIANT(64, 32, 1, 8, 1, 0),   SEPT_CONV_VARIANT(64, 32, 1, 8, 1, 1),   SEPT_CONV_VARIANT(64, 32, 1, 4, 1, 1),
-    SEPT_CONV_VARIANT(128, 64, 2, 4, 2, 0),  SEPT_CONV_VARIANT(128, 64, 2, 4, 2, 1),  SEPT_CONV_VARIANT(128, 64, 1, 4, 2, 0),
-    SEPT_CONV_VARIANT(128, 64, 1, 4, 2, 1),  SEPT_CONV_VARIANT(128, 64, 1, 4, 1, 1),
-    SEPT_CONV_VARIANT(128, 128, 2, 4, 2, 0), SEPT_CONV_VARIANT(128, 128, 2, 4, 2, 1), SEPT_CONV_VARIANT(128, 128, 1, 4, 2, 1),
-    SEPT_CONV_VARIANT(128, 128, 1, 4, 1, 1),
+    SEPT_CONV_VARIANT(32, 64, 2, 4, 2, 0, 1),   SEPT_CONV_VARIANT(32, 64, 2, 4, 2, 1, 1),   SEPT_CONV_VARIANT(32, 64, 1, 4, 1, 1, 1),
+    SEPT_CONV_VARIANT(64, 128, 2, 4, 2, 0, 1),  SEPT_CONV_VARIANT(64, 128, 2, 4, 2, 1, 1),  SEPT_CONV_VARIANT(64, 128, 1, 4, 2, 1, 1),
+    SEPT_CONV_VARIANT(64, 128, 1, 4, 1, 1, 1),  SEPT_CONV_VARIANT(64, 128, 2, 4, 2, 0, 2),  SEPT_CONV_VARIANT(64, 128, 2, 4, 2, 1, 2),
+    SEPT_CONV_VARIANT(64, 32, 1, 8, 1, 0, 1),   SEPT_CONV_VARIANT(64, 32, 1, 8, 1, 1, 1),   SEPT_CONV_VARIANT(64, 32, 1, 4, 1, 1, 1),
+    SEPT_CONV_VARIANT(64, 32, 1, 8, 1, 0, 2),   SEPT_CONV_VARIANT(64, 32, 1, 8, 1, 1, 2),
+    SEPT_CONV_VARIANT(128, 64, 2, 4, 2, 0, 2),  SEPT_CONV_VARIANT(128, 64, 2, 4, 2, 1, 2),  SEPT_CONV_VARIANT(128, 64, 2, 4, 2, 0, 1),
+    SEPT_CONV_VARIANT(128, 64, 1, 4, 2, 1, 1),  SEPT_CONV_VARIANT(128, 64, 1, 4, 1, 1, 1),
+    SEPT_CONV_VARIANT(128, 128, 2, 4, 2, 0, 2), SEPT_CONV_VARIANT(128, 128, 2, 4, 2, 1, 2), SEPT_CONV_VARIANT(128, 128, 1, 4, 2, 1, 1),
+    SEPT_CONV_VARIANT(128, 128, 1, 4, 1, 1, 1),
 };
-
-
 
 }  // namespace
 
@@ -252,25 +260,29 @@ extern "C" int sept_conv5x5_forward(const void* x, const void* wt, const float* 
   SEPT_REQUIRE(B <= 65535, SEPT_ERR_UNSUPPORTED, "sept_conv5x5_forward: B=%d exceeds grid.y", B);
   const ConvVariant* best = nullptr;
   size_t best_smem = 0;
+  int best_score = -1;
   const int force_pb = getenv("SEPT_CONV_PB") ? atoi(getenv("SEPT_CONV_PB")) : 0;  // tuning aids
   const int force_ns = getenv("SEPT_CONV_NS") ? atoi(getenv("SEPT_CONV_NS")) : 0;
   const int force_tg = getenv("SEPT_CONV_TG") ? atoi(getenv("SEPT_CONV_TG")) : 0;
+  const int force_cs = getenv("SEPT_CONV_CS") ? atoi(getenv("SEPT_CONV_CS")) : 0;
   for (const ConvVariant& v : kConvVariants) {
     if (v.cin != cin || v.cout != cout) continue;
     if (force_pb && v.pb != force_pb) continue;
     if (force_ns && v.wp * v.wn != 4 * force_ns) continue;
     if (force_tg && v.tg != (force_tg == 9 ? 0 : force_tg)) continue;  // SEPT_CONV_TG=9 selects the double-buffered form
+    if (force_cs && v.cs != force_cs) continue;
     const int mt = 32 * v.pb * v.wp;
-    const size_t ps = size_t(cin) * 2 + 16;
+    const size_t ps = size_t(cin / v.cs) * 2 + 16;
     const size_t smem = size_t(conv_nr_max(mt, W)) * (W + 4) * ps + size_t(v.tg == 0 ? 2 : v.tg) * cout * ps;
     if (smem > 160 * 1024) continue;
-    if (!best) {
+    // measured on MI355X (tools/sweep_conv.py): what matters is whether TWO workgroups share a CU
+    // (a third adds nothing); then the double-buffered form; then table order (tile shape)
+    const int occ = int(std::min<size_t>(2, (160 * 1024) / smem));
+    const int score = 10 * occ + (v.tg == 0 ? 1 : 0);
+    if (!best || (v.pb == best->pb && v.wp == best->wp && v.wn == best->wn && score > best_score)) {
       best = &v;
       best_smem = smem;
-    } else if (!force_tg && best->tg == 0 && v.tg == 1 && v.pb == best->pb && v.wp == best->wp && v.wn == best->wn &&
-               (160 * 1024) / smem > (160 * 1024) / best_smem) {
-      best = &v;
-      best_smem = smem;
+      best_score = score;
     }
   }
   SEPT_REQUIRE(best, SEPT_ERR_UNSUPPORTED,

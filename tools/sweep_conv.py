@@ -12,9 +12,9 @@ for (H, W, ci, co, mode) in [(100, 40, 32, 64, 0), (50, 20, 64, 128, 0), (100, 4
     w = torch.randn((co, ci, 5, 5) if mode == 0 else (ci, co, 5, 5), device="cuda") * 0.05
     wt = ops.conv5x5_prep_weights(w, mode)
     res = []
-    for pb, ns, tg in [(p_, n_, t_) for p_ in (1, 2) for n_ in (1, 2) for t_ in (1, 2, 9)]:
+    for pb, ns, tg, cs in [(p_, n_, t_, c_) for p_ in (1, 2) for n_ in (2,) for t_ in (1, 9) for c_ in (1, 2)]:
         if True:
-            os.environ["SEPT_CONV_PB"], os.environ["SEPT_CONV_NS"], os.environ["SEPT_CONV_TG"] = str(pb), str(ns), str(tg)
+            os.environ["SEPT_CONV_PB"], os.environ["SEPT_CONV_NS"], os.environ["SEPT_CONV_TG"], os.environ["SEPT_CONV_CS"] = str(pb), str(ns), str(tg), str(cs)
             try:
                 y = ops.conv5x5(x, wt)
             except SeptError:
@@ -28,6 +28,6 @@ for (H, W, ci, co, mode) in [(100, 40, 32, 64, 0), (50, 20, 64, 128, 0), (100, 4
                 ops.conv5x5(x, wt, out=y)
             e.record()
             torch.cuda.synchronize()
-            res.append((s.elapsed_time(e) / 20 * 1e3, pb, ns, tg))
+            res.append((s.elapsed_time(e) / 20 * 1e3, pb, ns, f'{tg}c{cs}'))
     fl = 2.0 * B * H * W * ci * co * 25
     print(f"{ci}->{co} {H}x{W}: " + "  ".join(f"pb{pb}ns{ns}tg{tg}: {us:.0f}us ({fl/us/1e6:.0f}TF)" for us, pb, ns, tg in res))
