@@ -40,6 +40,31 @@ def _cached(tag, t, fn):
     return hit[1]
 
 
+def _cached_pair(tag, t1, t2, fn):
+    """As _cached, for an operand derived from two parameters (forward + reverse GRU weights)."""
+    store = t1.__dict__.setdefault("_sept_derived", {})
+    stamp = (t1.data_ptr(), t1._version, t2.data_ptr(), t2._version, _EPOCH[0])
+    hit = store.get(tag)
+    if hit is None or hit[0] != stamp:
+        hit = store[tag] = (stamp, fn())
+    return hit[1]
+
+
+def _gru_cat_weights(wif, wir, bif, bir, layer, C, Wd):
+    """[W_ih forward; W_ih reverse] as ONE (384, K) operand (layer 0: columns permuted to the NHWC
+    feature order) and the matching (384,) bias, so both directions share one product per GEMM."""
+    K = wif.shape[1]
+    wcat = torch.empty((384, K), dtype=torch.float32, device=wif.device)
+    bcat = torch.empty(384, dtype=torch.float32, device=wif.device)
+    for d, (w_, b_) in enumerate(((wif, bif), (wir, bir))):
+        if layer == 0:
+            ops.permute_cols(w_.detach(), C, Wd, out=wcat[192 * d:192 * (d + 1)])
+        else:
+            ops.scale(w_.detach(), 1.0, out=wcat[192 * d:192 * (d + 1)])
+        ops.scale(b_.detach(), 1.0, out=bcat[192 * d:192 * (d + 1)])
+    return wcat, bcat
+
+
 # ---------------------------------------------------------------------------------------------
 # parameter view of a two_d_cnn_lstm / deep_two_d_cnn_lstm module
 # ---------------------------------------------------------------------------------------------
@@ -129,17 +154,12 @@ def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None):
                  f"weight_hh_l{layer}_reverse", f"bias_ih_l{layer}", f"bias_ih_l{layer}_reverse",
                  f"bias_hh_l{layer}", f"bias_hh_l{layer}_reverse"]
         wif, wir, whf, whr, bif, bir, bhf, bhr = [getattr(r, n) for n in names]
-        if layer == 0:
-            wif_k = _cached("wih_perm", wif, lambda: ops.permute_cols(wif, C, w))
-            wir_k = _cached("wih_perm", wir, lambda: ops.permute_cols(wir, C, w))
-        else:
-            wif_k, wir_k = wif, wir
+        wcat, bcat = _cached_pair(f"wih_cat{layer}", wif, wir,
+                                  lambda: _gru_cat_weights(wif, wir, bif, bir, layer, C, w))
         K = layer_in.shape[1]
-        gi = torch.empty((B * T, 2 * 192), dtype=torch.float32, device=dev)
-        ops.gemm_raw(layer_in, K, 1, wif_k, 1, K, gi, 384, B * T, 192, K, bif)
-        ops.gemm_raw(layer_in, K, 1, wir_k, 1, K, gi[:, 192:], 384, B * T, 192, K, bir)
+        gi = ops.linear_forward(layer_in, wcat, bcat)          # (B*T, 384): both directions in one product
         out, gates = ops.gru_forward(gi.view(B, T, 2, 192), whf, whr, bhf, bhr)
-        G = SimpleNamespace(inp=layer_in, out=out, gates=gates, wif_k=wif_k, wir_k=wir_k, whf=whf, whr=whr, mask=None)
+        G = SimpleNamespace(inp=layer_in, out=out, gates=gates, wcat=wcat, whf=whf, whr=whr, mask=None)
         if layer == 0:
             nxt = out.view(B * T, 128)
             if train and (r.dropout > 0 or "rnn" in inj):
@@ -191,23 +211,20 @@ def trunk_backward(S, P, dlogits, need_wgrad=True, need_dx=True):
         dgi2, dgh2, hp2 = dgi.view(B * T, 384), dgh.view(B * T, 384), hprev.view(B * T, 128)
         K = G.inp.shape[1]
         if need_wgrad:
+            dwcat = ops.linear_backward_weight(dgi2, G.inp)      # (384, K): both directions in one product
+            dbih, dbhh = ops.colsum(dgi2), ops.colsum(dgh2)
             for d, tag in ((0, ""), (1, "_reverse")):
-                gs = dgi2[:, d * 192:(d + 1) * 192]
                 gh = dgh2[:, d * 192:(d + 1) * 192]
-                dwih = ops.linear_backward_weight(gs, G.inp)
+                dwih = dwcat[d * 192:(d + 1) * 192]
                 if layer == 0:
                     dwih = ops.permute_cols(dwih, S.C, S.Wd, inverse=True)
                 put(getattr(r, "weight_ih" + sfx + tag), dwih)
                 put(getattr(r, "weight_hh" + sfx + tag), ops.linear_backward_weight(gh, hp2[:, d * 64:(d + 1) * 64]))
-                put(getattr(r, "bias_ih" + sfx + tag), ops.colsum(gs))
-                put(getattr(r, "bias_hh" + sfx + tag), ops.colsum(gh))
-        # gradient wrt the layer input: dgi_f W_if + dgi_r W_ir
-        if layer == 1:
-            din = torch.empty((B * T, K), dtype=torch.float32, device=dgi.device)
-        else:
-            din = torch.empty((B * T, K), dtype=torch.bfloat16, device=dgi.device)
-        ops.gemm_raw(dgi2, 384, 1, G.wif_k, K, 1, din, K, B * T, K, 192)
-        ops.gemm_raw(dgi2[:, 192:], 384, 1, G.wir_k, K, 1, din, K, B * T, K, 192, beta=1.0)
+                put(getattr(r, "bias_ih" + sfx + tag), dbih[d * 192:(d + 1) * 192])
+                put(getattr(r, "bias_hh" + sfx + tag), dbhh[d * 192:(d + 1) * 192])
+        # gradient wrt the layer input: dgi [W_if; W_ir]  (one product, K = 384)
+        din = ops.linear_backward_input(dgi2, G.wcat,
+                                        out_dtype=torch.float32 if layer == 1 else torch.bfloat16)
         if layer == 1:
             dout = din.view(B, T, 128)
             if S.gru[0].mask is not None:

@@ -292,8 +292,8 @@ def cloak_backward(dxa, dxb, gscale_b, rhos, eps, mask, min_scale, max_scale, sc
     return dlocs, drhos
 
 
-def scale(x, a):
-    y = torch.empty_like(x)
+def scale(x, a, out=None):
+    y = torch.empty_like(x) if out is None else out
     check(lib.sept_scale(x.data_ptr(), float(a), y.data_ptr(), x.numel(), _s(x)), "sept_scale")
     return y
 
@@ -347,9 +347,9 @@ def loss_sub_log(loss, mean, lam):
     check(lib.sept_loss_sub_log(loss.data_ptr(), mean.data_ptr(), float(lam), _s(loss)), "sept_loss_sub_log")
 
 
-def permute_cols(src, C, Wd, inverse=False):
+def permute_cols(src, C, Wd, inverse=False, out=None):
     N = src.shape[0]
-    dst = torch.empty_like(src)
+    dst = torch.empty_like(src) if out is None else out
     check(lib.sept_permute_cols(src.data_ptr(), dst.data_ptr(), N, C, Wd, int(inverse), _s(src)),
           "sept_permute_cols")
     return dst
