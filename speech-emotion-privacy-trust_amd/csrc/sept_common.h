@@ -42,6 +42,13 @@ inline int launch_check(const char* what) {
 // on first use so the launch functions themselves stay graph-capture safe afterwards).
 hipError_t allow_max_lds(const void* fn);
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it waits
+// for every global load / store in flight -- which throws away a software prefetch that is meant to
+// stay in flight across the barrier (cdna_hip_programming.md, "Pipelining across barriers").  Here
+// only this wave's LDS operations are waited for; the compiler still inserts the counted vmcnt
+// wait in front of the first use of a prefetched register.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // wave-local LDS hand-off: the lanes of one wavefront execute in lockstep and a wave's LDS
 // operations retire in order, so data written by one lane is visible to a later read by
 // another lane of the SAME wave without a workgroup barrier; the fences only stop the

@@ -17,6 +17,8 @@ typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(8))) float f32x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int kC = 32, kTaps = 25, kMT = 256;
 constexpr int kDyPS = 80;  // bytes per staged dy pixel (64 + 16 pad)
@@ -206,13 +208,120 @@ __global__ void sept_conv1_wgrad_finalize_kernel(const float* ws, int nparts, fl
     db[i - kC * kTaps] = float(s);
 }
 
+// ---- data gradient, streaming MFMA form ------------------------------------------------------
+// dx[r][w] = sum_{dh,dw} Z[r+dh-2][w+dw][dh*5+dw]  with  Z[y][px][tap] = sum_c dy[y][px-2][c] * wflip[tap][c].
+// The channel contraction (the only dense part) runs on MFMA: per staged dy row, 32 pixels x 32
+// (25 used) taps x 32 channels = two v_mfma_f32_32x32x16_bf16.  A workgroup walks the rows of its
+// image chunk ONCE: each step stages one dy row (prefetched a step ahead), turns it into a Z row
+// kept in a 6-row LDS ring, and emits the output row whose five Z rows are complete -- so dy is
+// read exactly once (no halo re-reads) and each output pixel costs 25 LDS words instead of 25 x 64 B.
+constexpr int kZS = 25;      // floats per pixel in the Z ring (odd stride: conflict-free gathers)
+constexpr int kRing = 6;
+__global__ __launch_bounds__(256) void sept_conv1_dgrad_stream_kernel(const bf16* __restrict__ dy,
+                                                                      const float* __restrict__ wprep,
+                                                                      float* __restrict__ dx, int B, int H, int W,
+                                                                      int rows_per_chunk) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int W4 = W + 4;
+  const int NP = (W4 + 31) / 32 * 32;  // staged pixels per row, padded to whole MFMA blocks
+  unsigned char* dyrow = smem;                                              // [2][NP][kDyPS]
+  float* zring = reinterpret_cast<float*>(smem + size_t(2) * NP * kDyPS);   // [kRing][NP][kZS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y;
+  const int r0 = blockIdx.x * rows_per_chunk, r1 = min(H, r0 + rows_per_chunk);
+  const bf16* dyb = dy + size_t(b) * H * W * kC;
+
+  // zero both row buffers once (halo columns and the padding up to NP stay zero for good)
+  for (int i = tid; i < 2 * NP * (kDyPS / 16); i += 256) reinterpret_cast<uint4*>(dyrow)[i] = make_uint4(0, 0, 0, 0);
+  // B operand: this lane's tap column of the flipped weights, 8 channels per k-step half
+  const int tap = lane & 31;
+  bf16x8 bw[2];
+  {
+    const uint4* wflip = reinterpret_cast<const uint4*>(wprep + kTaps * kC + kC);  // [25][4] x 8 bf16
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (tap < kTaps) v = wflip[tap * 4 + ks * 2 + (lane >> 5)];
+      bw[ks] = __builtin_bit_cast(bf16x8, v);
+    }
+  }
+  // row loader: chunk i of a dy row = 16 bytes = 8 channels of pixel i/4.  Rows are fetched TWO
+  // steps ahead into alternating register sets, so a global load has a full step to land.
+  const int nchunks = W * 4;
+  auto gload = [&](int y, uint4 (&pre)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int i = tid + 256 * j;
+      pre[j] = make_uint4(0, 0, 0, 0);
+      if (i < nchunks && y >= 0 && y < H) pre[j] = *reinterpret_cast<const uint4*>(dyb + (size_t(y) * W) * kC + size_t(i) * 8);
+    }
+  };
+  auto lstore = [&](int buf, const uint4 (&pre)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int i = tid + 256 * j;
+      if (i < nchunks)
+        *reinterpret_cast<uint4*>(dyrow + size_t(buf) * NP * kDyPS + size_t((i >> 2) + 2) * kDyPS + (i & 3) * 16) = pre[j];
+    }
+  };
+  uint4 preA[2], preB[2];
+  __syncthreads();
+  gload(r0 - 2, preA);
+  lstore(0, preA);
+  gload(r0 - 1, preB);  // row of step 1, stored at the end of step 0
+  __syncthreads();
+
+  const int nsteps = (r1 - r0) + 5;  // rows r0-2 .. r1+1 are transformed, plus one flush step
+  auto step = [&](int s, uint4 (&pre_next2)[2], const uint4 (&pre_next1)[2]) {
+    const int y = r0 - 2 + s;        // dy row transformed in this step (zeros outside the image)
+    gload(y + 2, pre_next2);         // two rows ahead
+    // ---- Z row of dy row y: waves take 32-pixel blocks ----
+    const unsigned char* cur = dyrow + size_t(s & 1) * NP * kDyPS;
+    float* zrow = zring + size_t(s % kRing) * NP * kZS;
+    for (int blk = wave; blk < NP / 32; blk += 4) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(cur + size_t(blk * 32 + (lane & 31)) * kDyPS + ks * 32 + (lane >> 5) * 16);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bw[ks], acc, 0, 0, 0);
+      }
+      if (tap < kTaps) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int px = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          zrow[px * kZS + tap] = acc[r];
+        }
+      }
+    }
+    // ---- output row r = y - 3: its Z rows y-5 .. y-1 were completed in earlier steps ----
+    const int r = y - 3;
+    if (r >= r0 && r < r1 && tid < W) {
+      float sum = 0.f;
+#pragma unroll
+      for (int dh = 0; dh < 5; ++dh) {
+        const int sz = s - 5 + dh;   // step that produced Z row r + dh - 2 = y - 5 + dh
+        const float* zr = zring + size_t(sz % kRing) * NP * kZS + tid * kZS + dh * 5;
+#pragma unroll
+        for (int dw = 0; dw < 5; ++dw) sum += zr[dw * kZS + dw];
+      }
+      dx[(size_t(b) * H + r) * W + tid] = sum;
+    }
+    lstore((s + 1) & 1, pre_next1);  // row y + 1, requested one step ago
+    sept::lds_barrier();             // LDS-only barrier: the row requested above stays in flight
+  };
+  for (int s = 0; s < nsteps; s += 2) {
+    step(s, preA, preB);
+    if (s + 1 < nsteps) step(s + 1, preB, preA);
+  }
+}
+
 // ---- weight gradient on MFMA (image width a multiple of 8) -------------------------------
 // D[c][tap] += sum_pixels dy[pixel][c] * x[pixel + tap]:  A[c][pixel] comes from the NHWC dy tile by
 // the transposing LDS read (as in sept_conv_wgrad.hip); B[pixel][tap] is built on the fly -- lane
 // (tap = l & 31) reads the 8 consecutive fp32 inputs its tap sees for pixels 8*(l>>5)..+7 and
 // rounds them to bf16.  Column 25 of B is the constant 1, so D[c][25] is the bias gradient.
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 __global__ __launch_bounds__(256) void sept_conv1_wgrad_mfma_kernel(const float* __restrict__ x,
                                                                     const bf16* __restrict__ dy,
@@ -327,6 +436,18 @@ extern "C" int sept_conv1_backward_data(const void* dy, const float* w, float* w
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(sept_conv1_prep_kernel, dim3((kTaps * kC + 255) / 256), dim3(256), 0, st, w,
                      static_cast<const float*>(nullptr), wprep);
+  if (W * 4 <= 512 && H >= 1) {  // streaming MFMA form: a dy row fits two 16-byte chunks per lane
+    const int NP = (W + 4 + 31) / 32 * 32;
+    const size_t smem_s = size_t(2) * NP * kDyPS + size_t(kRing) * NP * kZS * sizeof(float);
+    // enough row chunks to give every CU about two workgroups, but at least 16 rows per chunk
+    int chunks = std::max(1, std::min((H + 15) / 16, (512 + B - 1) / B));
+    const int rows = (H + chunks - 1) / chunks;
+    chunks = (H + rows - 1) / rows;
+    SEPT_HIP(sept::allow_max_lds(reinterpret_cast<const void*>(&sept_conv1_dgrad_stream_kernel)));
+    hipLaunchKernelGGL(sept_conv1_dgrad_stream_kernel, dim3(chunks, B), dim3(256), smem_s, st,
+                       static_cast<const bf16*>(dy), static_cast<const float*>(wprep), dx, B, H, W, rows);
+    return sept::launch_check("sept_conv1_dgrad_stream_kernel");
+  }
   const size_t smem = size_t(nr_max(W)) * (W + 4) * kDyPS;
   SEPT_REQUIRE(smem <= 160 * 1024, SEPT_ERR_UNSUPPORTED, "sept_conv1_backward_data: W=%d needs %zu B of LDS", W, smem);
   SEPT_HIP(sept::allow_max_lds(reinterpret_cast<const void*>(&sept_conv1_dgrad_kernel)));
