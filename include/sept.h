@@ -223,6 +223,15 @@ int sept_dropout_mask(float* out, long n, float p, unsigned long long seed, cons
 int sept_normal(float* out, long n, float mean, float stdv, unsigned long long seed, const long long* offset_dev,
                 unsigned long long offset, void* stream);
 int sept_counter_add(long long* counter, long long inc, void* stream);
+/* MFCC pieces (audio_feature_extraction.py:15-26: torchaudio MFCC(16000, n_mfcc=40) on the audio and
+ * on numpy.gradient(audio) with spacing 1 and 2): the mel front end is sept_mel_forward with
+ * (n_fft 400, hop 200, 128 mels); sept_topdb_clamp applies AmplitudeToDB's top_db = 80 per clip
+ * (x = max(x, max(x) - top_db)); the ortho DCT-II is a sept_gemm with the (128, 40) DCT matrix;
+ * sept_transpose_last2 brings (B, T, 40) to the reference's (B, 40, T);  sept_gradient1d is
+ * numpy.gradient along the last axis (central differences, one-sided at the ends). */
+int sept_topdb_clamp(float* x, int B, long n_per, float top_db, void* stream);
+int sept_gradient1d(const float* x, float* g, int B, long L, float spacing, void* stream);
+int sept_transpose_last2(const float* in, float* out, int B, int R, int C, void* stream);
 /* Windowing + per-speaker z-normalisation between the two halves of the path: mel (B, T, F)
  * time-major -> out (B*nwin, win, F), window i = frames [shift*i, shift*i + win) (zero padded
  * past T), each value (x - mean[f]) / (std[f] + 1e-5) when mean/std are given

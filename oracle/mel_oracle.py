@@ -104,3 +104,35 @@ def mel_spectrogram_f64(audio: np.ndarray, n_fft: int, feature_len: int, hop: in
                         fb: np.ndarray = None) -> np.ndarray:
     mel = mel_power_f64(audio, n_fft, feature_len, hop, fb)
     return 10.0 * np.log10(np.maximum(mel, AMIN))
+
+
+# ----------------------------------------------------------------------------------------
+# MFCC (+ deltas): audio_feature_extraction.py:15-26 -> torchaudio.transforms.MFCC(16000, n_mfcc=40)
+#   melkwargs None -> MelSpectrogram(n_fft=400, hop_length=200, n_mels=128, ...defaults...)
+#   log_mels False  -> AmplitudeToDB('power', top_db=80): x_db = max(x_db, x_db.max() - 80)
+#   dct_type 2, norm 'ortho' -> create_dct(40, 128, 'ortho'); mfcc = (mel_db^T @ dct)^T
+# PARITY UNPINNED (same reason as above); pinned by the float64 path and DCT identities.
+# ----------------------------------------------------------------------------------------
+def create_dct_ortho(n_mfcc: int = 40, n_mels: int = 128) -> torch.Tensor:
+    n = torch.arange(float(n_mels))
+    k = torch.arange(float(n_mfcc)).unsqueeze(1)
+    dct = torch.cos(math.pi / float(n_mels) * (n + 0.5) * k)
+    dct[0] *= 1.0 / math.sqrt(2.0)
+    dct *= math.sqrt(2.0 / float(n_mels))
+    return dct.t()
+
+
+def mfcc_f64(audio: np.ndarray, n_mfcc: int = 40, top_db: float = 80.0) -> np.ndarray:
+    """audio (1, L) -> (1, n_mfcc, 1 + L//200) float64."""
+    db = mel_spectrogram_f64(audio, 400, 128, hop=200)            # (1, 128, T)
+    db = np.maximum(db, db.max() - top_db)
+    dct = create_dct_ortho(n_mfcc, 128).double().numpy()          # (128, n_mfcc)
+    return np.transpose(np.transpose(db, (0, 2, 1)) @ dct, (0, 2, 1))
+
+
+def mfcc_with_deltas_f64(audio: np.ndarray) -> np.ndarray:
+    """reference mfcc(audio): concat of MFCC(x), MFCC(np.gradient(x)), MFCC(np.gradient(x, 2))."""
+    x = np.asarray(audio, dtype=np.float64)
+    d1 = np.gradient(x[0])[None]
+    d2 = np.gradient(x[0], 2)[None]
+    return np.concatenate((mfcc_f64(x), mfcc_f64(d1), mfcc_f64(d2)), axis=1)

@@ -349,6 +349,46 @@ __global__ void counter_add_kernel(long long* c, long long inc) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *c += inc;
 }
 
+// ---------------- MFCC pieces (audio_feature_extraction.py:15-26) ----------------
+// AmplitudeToDB(top_db): per clip, x = max(x, max(x) - top_db).  One workgroup per clip.
+__global__ __launch_bounds__(256) void topdb_clamp_kernel(float* x, long n_per, float top_db) {
+  __shared__ float red[kThreads];
+  float* xb = x + size_t(blockIdx.x) * n_per;
+  float m = -INFINITY;
+  for (long i = threadIdx.x; i < n_per; i += kThreads) m = fmaxf(m, xb[i]);
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int k = kThreads / 2; k > 0; k >>= 1) {
+    if (threadIdx.x < k) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + k]);
+    __syncthreads();
+  }
+  const float floor_ = red[0] - top_db;
+  for (long i = threadIdx.x; i < n_per; i += kThreads) xb[i] = fmaxf(xb[i], floor_);
+}
+// numpy.gradient(x, h) along the last axis (edge_order 1): central differences inside,
+// one-sided first differences at the two ends
+__global__ void gradient1d_kernel(const float* x, float* g, int B, long L, float h) {
+  GRID_STRIDE(i, long(B) * L) {
+    const long t = i % L;
+    const float* xb = x + (i - t);
+    float v;
+    if (L == 1) v = 0.f;
+    else if (t == 0) v = (xb[1] - xb[0]) / h;
+    else if (t == L - 1) v = (xb[L - 1] - xb[L - 2]) / h;
+    else v = (xb[t + 1] - xb[t - 1]) / (2.0f * h);
+    g[i] = v;
+  }
+}
+// out[b][c][r] = in[b][r][c]   (R x C -> C x R per batch item)
+__global__ void transpose_last2_kernel(const float* in, float* out, int B, int R, int C) {
+  GRID_STRIDE(i, long(B) * R * C) {
+    const int r = i % R;
+    const int c = (i / R) % C;
+    const long b = i / (long(R) * C);
+    out[i] = in[(b * R + r) * C + c];
+  }
+}
+
 // ---------------- optimisers (training_cloak_with_grl.py:416-421) ----------------
 // torch.optim.SGD(momentum, weight_decay, dampening 0, nesterov False)
 __global__ void sgd_kernel(float* p, const float* g, float* buf, long n, float lr, float momentum, float wd,
@@ -568,6 +608,27 @@ extern "C" int sept_counter_add(long long* counter, long long inc, void* stream)
   SEPT_REQUIRE(counter, SEPT_ERR_INVALID, "sept_counter_add: null argument");
   hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, ST(stream), counter, inc);
   return sept::launch_check("counter_add_kernel");
+}
+
+extern "C" int sept_topdb_clamp(float* x, int B, long n_per, float top_db, void* stream) {
+  if (B == 0) return SEPT_OK;
+  SEPT_REQUIRE(x && B > 0 && n_per > 0, SEPT_ERR_INVALID, "sept_topdb_clamp: bad argument");
+  hipLaunchKernelGGL(topdb_clamp_kernel, dim3(B), dim3(kThreads), 0, ST(stream), x, n_per, top_db);
+  return sept::launch_check("topdb_clamp_kernel");
+}
+
+extern "C" int sept_gradient1d(const float* x, float* g, int B, long L, float spacing, void* stream) {
+  if (B == 0) return SEPT_OK;
+  SEPT_REQUIRE(x && g && B > 0 && L > 0 && spacing != 0.f, SEPT_ERR_INVALID, "sept_gradient1d: bad argument");
+  hipLaunchKernelGGL(gradient1d_kernel, dim3(blocks_for(long(B) * L)), dim3(kThreads), 0, ST(stream), x, g, B, L, spacing);
+  return sept::launch_check("gradient1d_kernel");
+}
+
+extern "C" int sept_transpose_last2(const float* in, float* out, int B, int R, int C, void* stream) {
+  if (B == 0) return SEPT_OK;
+  SEPT_REQUIRE(in && out && B > 0 && R > 0 && C > 0, SEPT_ERR_INVALID, "sept_transpose_last2: bad argument");
+  hipLaunchKernelGGL(transpose_last2_kernel, dim3(blocks_for(long(B) * R * C)), dim3(kThreads), 0, ST(stream), in, out, B, R, C);
+  return sept::launch_check("transpose_last2_kernel");
 }
 
 extern "C" int sept_sgd_step(float* p, const float* g, float* momentum_buf, long n, float lr, float momentum,

@@ -8,8 +8,8 @@ reference :182) is copied to the current GPU and the result is returned on the i
 device, so the call site at :186-187 works unchanged.  There is no CPU fallback: without a
 GPU / the built library this raises.
 
-The dataset crawl, MFCC and openSMILE functionals of the reference script are outside this
-path (OUT OF SCOPE).
+`mfcc(audio)` (reference :15-26) is provided the same way.  The dataset crawl and the openSMILE
+functionals of the reference script are outside this path (OUT OF SCOPE).
 """
 import os
 import sys
@@ -21,6 +21,20 @@ if _PKG not in sys.path:
     sys.path.insert(0, _PKG)
 
 from sept_amd.mel import LAYOUT_BFT, LAYOUT_BTF, get_mel_plan  # noqa: E402
+from sept_amd.mfcc import mfcc_with_deltas  # noqa: E402
+
+
+def mfcc(audio):
+    """Reference signature (audio_feature_extraction.py:15-26): audio (1, L) float32 -> numpy array
+    (1, 120, 1 + L//200): MFCC(40) of the audio, of np.gradient(audio[0]) and of
+    np.gradient(audio[0], 2), concatenated along axis 1."""
+    if not isinstance(audio, torch.Tensor):
+        audio = torch.as_tensor(audio)
+    if audio.dim() == 1:
+        audio = audio.unsqueeze(0)
+    if not torch.cuda.is_available():
+        raise RuntimeError("mfcc: no GPU visible; this build has no CPU fallback")
+    return mfcc_with_deltas(audio[:1].to("cuda")).cpu().numpy()
 
 
 def mel_spectrogram(audio, n_fft=1024, feature_len=128):

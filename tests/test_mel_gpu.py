@@ -138,3 +138,25 @@ def test_full_batch_properties():
     assert torch.allclose(doubled, full[:8] + 10 * np.log10(4.0), atol=2e-4)
     want = mo.mel_spectrogram_f64(x[idx].numpy(), 800, 80)
     assert np.abs(full[idx].numpy() - want).max() < ABS_DB
+
+
+def test_mfcc_with_deltas_vs_oracle():
+    """mfcc(audio) of the reference (audio_feature_extraction.py:15-26): 3 x 40 coefficients, per
+    clip top_db clamp, ortho DCT-II; also numpy.gradient on the device."""
+    from feature_extraction.audio_feature_extraction import mfcc
+    from sept_amd.mfcc import gradient1d, mfcc_batched
+    torch.manual_seed(4)
+    audio = torch.randn(1, 48000) * 0.1
+    got = mfcc(audio)
+    want = mo.mfcc_with_deltas_f64(audio.numpy())
+    assert got.shape == want.shape == (1, 120, 241)
+    assert np.abs(got - want).max() < 1e-3 and np.abs(got - want).mean() < 5e-5   # values are O(100)
+    x = torch.randn(3, 1001)
+    for h in (1.0, 2.0):
+        g = gradient1d(x.cuda(), h).cpu().numpy()
+        np.testing.assert_allclose(g, np.gradient(x.numpy(), h, axis=1), rtol=1e-5, atol=1e-6)
+    # batched call = per-clip calls (top_db is per clip, as the reference's one-file-at-a-time loop)
+    xb = torch.randn(3, 16000) * torch.tensor([[0.01], [0.1], [1.0]])
+    full = mfcc_batched(xb.cuda())
+    for i in range(3):
+        assert torch.allclose(mfcc_batched(xb[i:i + 1].cuda()), full[i:i + 1], atol=1e-4)

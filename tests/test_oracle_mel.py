@@ -103,3 +103,24 @@ def test_product_tables_match_oracle_tables():
         assert torch.equal(melscale.melscale_fbanks_htk(n_fft // 2 + 1, F),
                            mo.melscale_fbanks_htk(n_fft // 2 + 1, F))
         assert torch.equal(melscale.hann_window(n_fft), torch.hann_window(n_fft))
+
+
+def test_mfcc_oracle_identities():
+    """MFCC restatement (audio_feature_extraction.py:15-26): the ortho DCT-II has orthonormal
+    columns, coefficient 0 is sum(mel_db)/sqrt(n_mels), the top_db clamp holds per clip, and the
+    120-row layout is [x, gradient(x), gradient(x, 2)]."""
+    dct = mo.create_dct_ortho(40, 128).double().numpy()
+    np.testing.assert_allclose(dct.T @ dct, np.eye(40), atol=5e-6)      # float32 table
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((1, 8000)) * 0.05
+    x[:, 4000:] = 0.0                                   # silence -> -100 dB before the clamp
+    db = mo.mel_spectrogram_f64(x, 400, 128, hop=200)
+    m = mo.mfcc_f64(x)
+    assert m.shape == (1, 40, 41)
+    clamped = np.maximum(db, db.max() - 80.0)
+    assert clamped.min() >= db.max() - 80.0 - 1e-9 and db.min() < db.max() - 80.0
+    np.testing.assert_allclose(m[:, 0], clamped.sum(axis=1) / np.sqrt(128.0), rtol=1e-6)   # float32 DCT table
+    full = mo.mfcc_with_deltas_f64(x)
+    assert full.shape == (1, 120, 41)
+    np.testing.assert_allclose(full[:, :40], m)
+    np.testing.assert_allclose(full[:, 80:], mo.mfcc_f64(np.gradient(x[0], 2)[None]))
