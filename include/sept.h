@@ -141,6 +141,15 @@ int sept_gemm(const void* A, long sam, long sak, int a_is_bf16, const void* B, l
               int b_is_bf16, void* C, long ldc, int c_is_bf16, const float* bias, int M, int N, int K,
               float alpha, float beta, float* ws, long ws_floats, void* stream);
 
+/* Long-K "NT" product on the bf16 matrix pipe with split operands (GRU layer-0 input projections,
+ * baseline_models.py:191-193 and their data gradient): C[m][n] = sum_k A[m][k] B[n][k] (+ bias[n]).
+ * A is bf16 (exact) or fp32 (split hi+lo in the kernel), B is fp32 (split hi+lo), both k-contiguous
+ * with 16-byte aligned rows (K a multiple of 32; lda a multiple of 8 for bf16 A / 4 for fp32 A; ldb a
+ * multiple of 4);
+ * products are accumulated in fp32 from the hi*hi, hi*lo (and lo*hi) passes: ~2^-17 relative. */
+int sept_gemm_nt_split(const void* A, long lda, int a_is_bf16, const float* B, long ldb, void* C, long ldc,
+                       int c_is_bf16, const float* bias, int M, int N, int K, void* stream);
+
 /* Recurrent part of nn.GRU(.., hidden 64, bidirectional, batch_first) -- one launch per layer
  * for both directions and all T steps (baseline_models.py:191-193; gate order r, z, n).
  *   gi    [B][T][2][3H]  x W_ih^T + b_ih for (forward, reverse)     (from sept_gemm)

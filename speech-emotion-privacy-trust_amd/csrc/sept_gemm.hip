@@ -198,6 +198,190 @@ __global__ void sept_gemm_splitk_reduce_kernel(GemmArgs g) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// "NT" product on the bf16 matrix pipe with split operands, for the long-K GRU layer-0 input
+// projections (y = x W_ih^T and dx = dgi W_ih; model/baseline_models.py:191-193):
+//   C[m][n] = sum_k A[m][k] * B[n][k]  (+ bias[n])          A, B both k-contiguous
+// B (fp32 master weights) is split on the fly into bf16 hi + lo planes (w = hi + lo up to 2^-17
+// relative) and multiplied in two passes; A is either bf16 activations (exact, 2 passes) or fp32
+// (split as well, 3 passes: hi*hi + hi*lo + lo*hi), so the result carries ~fp32 products at 8x
+// the rate of v_mfma_f32_32x32x2_f32.  64x64 tile, 4 waves x (32x32), K step 32, double-buffered
+// LDS planes with the next step's global loads in flight during the MFMAs, one LDS-only barrier
+// per step.  Rows are padded to 40 bf16 (80 B) so the 16-byte fragment reads are conflict free.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+struct NtArgs {
+  const void* A;
+  const float* B;
+  void* C;
+  const float* bias;
+  long lda, ldb, ldc;
+  int M, N, K, c_bf16;
+};
+
+__device__ __forceinline__ void split4(const float4 v, bf16x4& hi, bf16x4& lo) {
+  const float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    hi[i] = (bf16)f[i];
+    lo[i] = (bf16)(f[i] - float(hi[i]));
+  }
+}
+
+// MB: 32-row blocks per wave along M (tile = 64*MB x 64); BK: K step per barrier
+template <bool A_BF16, int MB, int BK>
+__global__ __launch_bounds__(256) void sept_gemm_nt_split_kernel(NtArgs g) {
+  constexpr int NA = A_BF16 ? 1 : 2;
+  constexpr int TMB = 64 * MB;
+  constexpr int LD = BK + 8;               // bf16 per LDS row: 80 / 144 B strides are conflict free
+  constexpr int PLANE = 64 * LD;
+  constexpr int CA16 = BK / 8, CA4 = BK / 4;  // 16-byte chunks per row: bf16 / fp32 operand
+  constexpr int NA16 = MB * BK / 32, NA4 = MB * BK / 16, NB4 = BK / 16;  // loads per thread
+  __shared__ __attribute__((aligned(16))) bf16 As[2][NA][MB * PLANE];
+  __shared__ __attribute__((aligned(16))) bf16 Bs[2][2][PLANE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // XCD-aware tile order: workgroup ids go round-robin over the 8 XCDs, so give each XCD whole
+  // rows of tiles (all N tiles of one M tile share that XCD's L2 copy of the A rows)
+  const int ntn = (g.N + 63) / 64, ntm = (g.M + TMB - 1) / TMB;
+  const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+  const int mt = (slot / ntn) * 8 + xcd, nt = slot % ntn;
+  if (mt >= ntm) return;
+  const int m0 = mt * TMB, n0 = nt * 64;
+  const int wm = (wave >> 1) * 32 * MB, wn = (wave & 1) * 32;
+  f32x16 acc[MB];
+#pragma unroll
+  for (int b = 0; b < MB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+
+  // register stage for the next K step (plain arrays: a struct here ends up in scratch)
+  uint4 a16_0[A_BF16 ? NA16 : 1], a16_1[A_BF16 ? NA16 : 1];
+  float4 a4_0[A_BF16 ? 1 : NA4], b4_0[NB4], a4_1[A_BF16 ? 1 : NA4], b4_1[NB4];
+  // per-thread row pointers are fixed for the whole K loop; rows past the matrix edge are clamped
+  // to the last row (their products land in output rows / columns that are never stored), and K
+  // is a multiple of BK, so the loop body has no guards and no 64-bit address arithmetic
+  const bf16* pa16[A_BF16 ? NA16 : 1];
+  const float* pa4[A_BF16 ? 1 : NA4];
+  const float* pb4[NB4];
+  if (A_BF16) {
+#pragma unroll
+    for (int i = 0; i < NA16; ++i) {
+      const int e = tid + 256 * i, row = min(m0 + e / CA16, g.M - 1);
+      pa16[i] = static_cast<const bf16*>(g.A) + long(row) * g.lda + (e % CA16) * 8;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NA4; ++i) {
+      const int e = tid + 256 * i, row = min(m0 + e / CA4, g.M - 1);
+      pa4[i] = static_cast<const float*>(g.A) + long(row) * g.lda + (e % CA4) * 4;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NB4; ++i) {
+    const int e = tid + 256 * i, row = min(n0 + e / CA4, g.N - 1);
+    pb4[i] = g.B + long(row) * g.ldb + (e % CA4) * 4;
+  }
+  auto load_globals = [&](auto& a16, auto& a4, auto& b4, int k0) {
+    if (A_BF16) {
+#pragma unroll
+      for (int i = 0; i < NA16; ++i) a16[i] = *reinterpret_cast<const uint4*>(pa16[i] + k0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NA4; ++i) a4[i] = *reinterpret_cast<const float4*>(pa4[i] + k0);
+    }
+#pragma unroll
+    for (int i = 0; i < NB4; ++i) b4[i] = *reinterpret_cast<const float4*>(pb4[i] + k0);
+  };
+  auto store_lds = [&](const auto& a16, const auto& a4, const auto& b4, int buf) {
+    bf16x4 hi, lo;
+    if (A_BF16) {
+#pragma unroll
+      for (int i = 0; i < NA16; ++i) {
+        const int e = tid + 256 * i;
+        *reinterpret_cast<uint4*>(&As[buf][0][(e / CA16) * LD + (e % CA16) * 8]) = a16[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NA4; ++i) {
+        const int e = tid + 256 * i, off = (e / CA4) * LD + (e % CA4) * 4;
+        split4(a4[i], hi, lo);
+        *reinterpret_cast<bf16x4*>(&As[buf][0][off]) = hi;
+        *reinterpret_cast<bf16x4*>(&As[buf][NA - 1][off]) = lo;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NB4; ++i) {
+      const int e = tid + 256 * i, off = (e / CA4) * LD + (e % CA4) * 4;
+      split4(b4[i], hi, lo);
+      *reinterpret_cast<bf16x4*>(&Bs[buf][0][off]) = hi;
+      *reinterpret_cast<bf16x4*>(&Bs[buf][1][off]) = lo;
+    }
+  };
+
+  const int nk = g.K / BK;
+  const int aoff = (wm + (lane & 31)) * LD + 8 * (lane >> 5);
+  const int boff = (wn + (lane & 31)) * LD + 8 * (lane >> 5);
+  auto compute = [&](int buf) {
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 16) {
+      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&Bs[buf][0][boff + kk]);
+      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&Bs[buf][1][boff + kk]);
+#pragma unroll
+      for (int b = 0; b < MB; ++b) {
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&As[buf][0][aoff + b * 32 * LD + kk]);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[b], 0, 0, 0);
+        if (!A_BF16) {
+          const bf16x8 al = *reinterpret_cast<const bf16x8*>(&As[buf][NA - 1][aoff + b * 32 * LD + kk]);
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[b], 0, 0, 0);
+        }
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[b], 0, 0, 0);
+      }
+    }
+  };
+  // Two register stages: global loads run two K steps ahead of their LDS stores.  Steps past
+  // the end re-load the last tile (never computed on), so the loop body is unconditional:
+  // LDS buffer 0 holds step ks, stage 1 holds step ks+1, stage 0 is free for step ks+2.
+  auto kof = [&](int step) { return min(step, nk - 1) * BK; };
+  load_globals(a16_0, a4_0, b4_0, 0);
+  load_globals(a16_1, a4_1, b4_1, kof(1));
+  store_lds(a16_0, a4_0, b4_0, 0);
+  __syncthreads();
+  int ks = 0;
+  for (; ks + 1 < nk; ks += 2) {
+    load_globals(a16_0, a4_0, b4_0, kof(ks + 2));
+    compute(0);
+    store_lds(a16_1, a4_1, b4_1, 1);
+    sept::lds_barrier();
+    load_globals(a16_1, a4_1, b4_1, kof(ks + 3));
+    compute(1);
+    store_lds(a16_0, a4_0, b4_0, 0);
+    sept::lds_barrier();
+  }
+  if (ks < nk) compute(0);
+  const int n = n0 + wn + (lane & 31);
+  if (n >= g.N) return;
+  const float bv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+  for (int b = 0; b < MB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (m >= g.M) continue;
+      const long off = long(m) * g.ldc + n;
+      const float v = acc[b][r] + bv;
+      if (g.c_bf16) static_cast<bf16*>(g.C)[off] = (bf16)v;
+      else static_cast<float*>(g.C)[off] = v;
+    }
+}
+
+template <bool A_BF16, int MB, int BK>
+void launch_nt(const NtArgs& g, hipStream_t st) {
+  const int ntn = (g.N + 63) / 64, ntm = (g.M + 64 * MB - 1) / (64 * MB);
+  const int grid = ((ntm + 7) / 8) * 8 * ntn;   // whole XCD rounds; surplus workgroups exit at once
+  hipLaunchKernelGGL((sept_gemm_nt_split_kernel<A_BF16, MB, BK>), dim3(grid), dim3(256), 0, st, g);
+}
+
 }  // namespace
 
 extern "C" int sept_gemm(const void* A, long sam, long sak, int a_is_bf16, const void* B, long sbk, long sbn,
@@ -228,4 +412,35 @@ extern "C" int sept_gemm(const void* A, long sam, long sak, int a_is_bf16, const
                        0, st, g);
   }
   return sept::launch_check("sept_gemm_f32_kernel");
+}
+
+
+extern "C" int sept_gemm_nt_split(const void* A, long lda, int a_is_bf16, const float* B, long ldb, void* C, long ldc,
+                                  int c_is_bf16, const float* bias, int M, int N, int K, void* stream) {
+  SEPT_REQUIRE(M >= 0 && N >= 0 && K >= 0, SEPT_ERR_INVALID, "sept_gemm_nt_split: M=%d N=%d K=%d", M, N, K);
+  if (M == 0 || N == 0) return SEPT_OK;
+  SEPT_REQUIRE(A && B && C, SEPT_ERR_INVALID, "sept_gemm_nt_split: null argument");
+  const int kq = a_is_bf16 ? 8 : 4;
+  SEPT_REQUIRE(K > 0 && K % 32 == 0 && lda % kq == 0 && ldb % 4 == 0 && lda >= K && ldb >= K && ldc >= N &&
+                   reinterpret_cast<uintptr_t>(A) % 16 == 0 && reinterpret_cast<uintptr_t>(B) % 16 == 0,
+               SEPT_ERR_INVALID, "sept_gemm_nt_split: K=%d lda=%ld ldb=%ld ldc=%ld need 16-byte aligned k-contiguous rows",
+               K, lda, ldb, ldc);
+  NtArgs g{A, B, C, bias, lda, ldb, ldc, M, N, K, c_is_bf16};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  static const int force_bk = getenv("SEPT_NT_BK") ? atoi(getenv("SEPT_NT_BK")) : 0;
+  static const int force_mb = getenv("SEPT_NT_MB") ? atoi(getenv("SEPT_NT_MB")) : 0;
+  const int bk = (force_bk == 64 && K % 64 == 0) ? 64 : 32;
+  const int mb = force_mb == 2 ? 2 : 1;
+  if (a_is_bf16) {
+    if (bk == 64 && mb == 2) launch_nt<true, 2, 64>(g, st);
+    else if (bk == 64) launch_nt<true, 1, 64>(g, st);
+    else if (mb == 2) launch_nt<true, 2, 32>(g, st);
+    else launch_nt<true, 1, 32>(g, st);
+  } else {
+    if (bk == 64 && mb == 2) launch_nt<false, 2, 64>(g, st);
+    else if (bk == 64) launch_nt<false, 1, 64>(g, st);
+    else if (mb == 2) launch_nt<false, 2, 32>(g, st);
+    else launch_nt<false, 1, 32>(g, st);
+  }
+  return sept::launch_check("sept_gemm_nt_split_kernel");
 }

@@ -51,6 +51,8 @@ SIGNATURES = {
     "sept_bn_eval_stats": (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "sept_bn_relu_pool_forward": (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p]),
     "sept_bn_relu_pool_backward": (c_int, [c_void_p] * 11 + [c_int] * 5 + [c_void_p]),
+    "sept_gemm_nt_split": (c_int, [c_void_p, c_long, c_int, c_void_p, c_long, c_void_p, c_long, c_int, c_void_p,
+                                   c_int, c_int, c_int, c_void_p]),
     "sept_gemm": (c_int, [c_void_p, c_long, c_long, c_int, c_void_p, c_long, c_long, c_int, c_void_p, c_long, c_int,
                           c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_long, c_void_p]),
     "sept_gru_forward": (c_int, [c_void_p] * 7 + [c_int] * 3 + [c_void_p]),

@@ -62,7 +62,11 @@ def _gru_cat_weights(wif, wir, bif, bir, layer, C, Wd):
         else:
             ops.scale(w_.detach(), 1.0, out=wcat[192 * d:192 * (d + 1)])
         ops.scale(b_.detach(), 1.0, out=bcat[192 * d:192 * (d + 1)])
-    return wcat, bcat
+    return wcat, bcat, ops.transpose2d(wcat)     # (K, 384) copy: the k-contiguous operand of dx = dgi W
+
+
+def _nt_ok(K):
+    return K % 32 == 0
 
 
 # ---------------------------------------------------------------------------------------------
@@ -154,12 +158,13 @@ def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None):
                  f"weight_hh_l{layer}_reverse", f"bias_ih_l{layer}", f"bias_ih_l{layer}_reverse",
                  f"bias_hh_l{layer}", f"bias_hh_l{layer}_reverse"]
         wif, wir, whf, whr, bif, bir, bhf, bhr = [getattr(r, n) for n in names]
-        wcat, bcat = _cached_pair(f"wih_cat{layer}", wif, wir,
-                                  lambda: _gru_cat_weights(wif, wir, bif, bir, layer, C, w))
+        wcat, bcat, wcatT = _cached_pair(f"wih_cat{layer}", wif, wir,
+                                         lambda: _gru_cat_weights(wif, wir, bif, bir, layer, C, w))
         K = layer_in.shape[1]
-        gi = ops.linear_forward(layer_in, wcat, bcat)          # (B*T, 384): both directions in one product
+        # (B*T, 384): both directions in one product, on the split-bf16 matrix pipe when K allows
+        gi = ops.linear_nt_split(layer_in, wcat, bcat) if _nt_ok(K) else ops.linear_forward(layer_in, wcat, bcat)
         out, gates = ops.gru_forward(gi.view(B, T, 2, 192), whf, whr, bhf, bhr)
-        G = SimpleNamespace(inp=layer_in, out=out, gates=gates, wcat=wcat, whf=whf, whr=whr, mask=None)
+        G = SimpleNamespace(inp=layer_in, out=out, gates=gates, wcat=wcat, wcatT=wcatT, whf=whf, whr=whr, mask=None)
         if layer == 0:
             nxt = out.view(B * T, 128)
             if train and (r.dropout > 0 or "rnn" in inj):
@@ -223,8 +228,8 @@ def trunk_backward(S, P, dlogits, need_wgrad=True, need_dx=True):
                 put(getattr(r, "bias_ih" + sfx + tag), dbih[d * 192:(d + 1) * 192])
                 put(getattr(r, "bias_hh" + sfx + tag), dbhh[d * 192:(d + 1) * 192])
         # gradient wrt the layer input: dgi [W_if; W_ir]  (one product, K = 384)
-        din = ops.linear_backward_input(dgi2, G.wcat,
-                                        out_dtype=torch.float32 if layer == 1 else torch.bfloat16)
+        odt = torch.float32 if layer == 1 else torch.bfloat16
+        din = ops.linear_nt_split(dgi2, G.wcatT, None, out_dtype=odt)   # reduction length 384
         if layer == 1:
             dout = din.view(B, T, 128)
             if S.gru[0].mask is not None:

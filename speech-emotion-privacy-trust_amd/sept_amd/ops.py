@@ -210,6 +210,25 @@ def linear_forward(x, W, bias=None, out=None, out_dtype=torch.float32):
     return gemm_raw(x, K, 1, W, 1, K, out, out.stride(0), M, N, K, bias)
 
 
+def transpose2d(x):
+    """(R, C) fp32 -> contiguous (C, R) copy."""
+    R, C = x.shape
+    out = torch.empty((C, R), dtype=torch.float32, device=x.device)
+    check(lib.sept_transpose_last2(x.data_ptr(), out.data_ptr(), 1, R, C, _s(x)), "sept_transpose_last2")
+    return out
+
+
+def linear_nt_split(x, W, bias=None, out_dtype=torch.float32):
+    """y[M][N] = x[M][K] W[N][K]^T + bias on the bf16 matrix pipe with hi/lo-split operands
+    (sept_gemm_nt_split): x bf16 or fp32, W fp32, both row-major with K contiguous."""
+    M, K = x.shape
+    N = W.shape[0]
+    out = torch.empty((M, N), dtype=out_dtype, device=x.device)
+    check(lib.sept_gemm_nt_split(x.data_ptr(), x.stride(0), _is_bf16(x), W.data_ptr(), W.stride(0), out.data_ptr(),
+                                 out.stride(0), _is_bf16(out), _p(bias), M, N, K, _s(out)), "sept_gemm_nt_split")
+    return out
+
+
 def linear_backward_input(dy, W, out=None, out_dtype=torch.float32):
     """dx[M][K] = dy[M][N] W[N][K]."""
     M, N = dy.shape

@@ -39,6 +39,32 @@ def test_linear_three_products(M, N, K, abf16):
     assert torch.allclose(out.float().cpu(), 2 * (dy @ W), rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("M,N,K,abf16", [(5600, 384, 1280, True), (5600, 1280, 384, False), (70, 100, 96, True),
+                                         (33, 65, 64, False), (1, 1, 32, True), (64, 64, 32, False)])
+def test_gemm_nt_split(M, N, K, abf16):
+    """sept_gemm_nt_split (bf16 MFMA, hi/lo-split operands) vs a float64 product: the split keeps
+    ~2^-17 relative per product, i.e. fp32-GEMM quality (the GRU layer-0 projections)."""
+    from sept_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x = torch.randn(M, K, generator=g)
+    if abf16:
+        x = x.bfloat16()
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    want = x.double() @ W.double().t() + b.double()
+    y = ops.linear_nt_split(x.cuda(), W.cuda(), b.cuda()).cpu()
+    assert (y.double() - want).abs().max() < 2e-5 * (1 + want.abs().max())
+    yb = ops.linear_nt_split(x.cuda(), W.cuda(), None, out_dtype=torch.bfloat16).cpu()
+    assert torch.allclose(yb.float(), (want - b.double()).float(), rtol=1e-2, atol=1e-2)
+    # rows given through a view with a larger leading dimension
+    xw = torch.zeros(M, K + 8, dtype=x.dtype)
+    xw[:, :K] = x
+    y2 = ops.linear_nt_split(xw.cuda()[:, :K], W.cuda(), b.cuda()).cpu()
+    assert torch.equal(y2, y)
+    with pytest.raises(Exception):
+        ops.linear_nt_split(x.cuda()[:, 8:], W.cuda()[:, 8:])          # K not a multiple of 32
+
+
 @pytest.mark.parametrize("B,T", [(7, 25), (4, 3), (1, 1)])
 def test_gru_layer_forward_backward(B, T):
     """One bidirectional GRU layer (input projections by sept_gemm + recurrent kernel) vs nn.GRU."""

@@ -1,0 +1,33 @@
+"""Times the GEMM entry points on the GRU layer-0 shapes of the bench step."""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "speech-emotion-privacy-trust_amd"))
+import torch
+from sept_amd import ops
+
+
+def t(fn, n=20):
+    for _ in range(3):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3
+
+
+M = 5600
+x = torch.randn(M, 1280, device="cuda").bfloat16()
+W = torch.randn(384, 1280, device="cuda") / 36
+WT = W.t().contiguous()
+b = torch.randn(384, device="cuda")
+dgi = torch.randn(M, 384, device="cuda")
+print("fwd  f32 %.1f us   nt_split %.1f us" % (t(lambda: ops.linear_forward(x, W, b)), t(lambda: ops.linear_nt_split(x, W, b))))
+print("dX   f32 %.1f us   nt_split %.1f us" % (t(lambda: ops.linear_backward_input(dgi, W, out_dtype=torch.bfloat16)),
+                                            t(lambda: ops.linear_nt_split(dgi, WT, None, out_dtype=torch.bfloat16))))
+x1 = torch.randn(M, 128, device="cuda")
+W1 = torch.randn(384, 128, device="cuda") / 11
+print("l1 fwd f32 %.1f us   nt_split %.1f us" % (t(lambda: ops.linear_forward(x1, W1, b)), t(lambda: ops.linear_nt_split(x1, W1, b))))
+W1T = W1.t().contiguous()
+print("l1 dX f32 %.1f us   nt_split %.1f us" % (t(lambda: ops.linear_backward_input(dgi, W1)), t(lambda: ops.linear_nt_split(dgi, W1T))))
