@@ -33,7 +33,8 @@ def _cached(tag, t, fn):
     served to another tensor that happens to reuse the address) and refreshed whenever torch
     bumps the tensor version or the HIP optimiser bumps the epoch."""
     store = t.__dict__.setdefault("_sept_derived", {})
-    stamp = (t.data_ptr(), t._version, _EPOCH[0])
+    # frozen parameters (requires_grad False) are never touched by the raw-pointer optimiser
+    stamp = (t.data_ptr(), t._version, _EPOCH[0] if t.requires_grad else -1)
     hit = store.get(tag)
     if hit is None or hit[0] != stamp:
         hit = store[tag] = (stamp, fn())
@@ -43,7 +44,8 @@ def _cached(tag, t, fn):
 def _cached_pair(tag, t1, t2, fn):
     """As _cached, for an operand derived from two parameters (forward + reverse GRU weights)."""
     store = t1.__dict__.setdefault("_sept_derived", {})
-    stamp = (t1.data_ptr(), t1._version, t2.data_ptr(), t2._version, _EPOCH[0])
+    stamp = (t1.data_ptr(), t1._version, t2.data_ptr(), t2._version,
+             _EPOCH[0] if (t1.requires_grad or t2.requires_grad) else -1)
     hit = store.get(tag)
     if hit is None or hit[0] != stamp:
         hit = store[tag] = (stamp, fn())
