@@ -150,6 +150,15 @@ int sept_gemm(const void* A, long sam, long sak, int a_is_bf16, const void* B, l
 int sept_gemm_nt_split(const void* A, long lda, int a_is_bf16, const float* B, long ldb, void* C, long ldc,
                        int c_is_bf16, const float* bias, int M, int N, int K, void* stream);
 
+/* Weight-gradient ("TN") product with split operands: C[m][n] = sum_k A[k][m] B[k][n], A fp32
+ * (gradient rows, split hi+lo), B bf16 (exact) or fp32 (split hi+lo), both with k as the row index
+ * (16-byte aligned rows; M, lda multiples of 4; N, ldb multiples of 8 for bf16 B / 4 for fp32 B).
+ * K is split over workgroups into `ws` (sept_gemm_tn_workspace_floats(M, N) floats, may be NULL)
+ * and summed in fixed order.  Replaces the dW = dy^T x products of nn.GRU / nn.Linear autograd. */
+size_t sept_gemm_tn_workspace_floats(int M, int N);
+int sept_gemm_tn_split(const float* A, long lda, const void* B, long ldb, int b_is_bf16, float* C, long ldc,
+                       int M, int N, int K, float* ws, long ws_floats, void* stream);
+
 /* Recurrent part of nn.GRU(.., hidden 64, bidirectional, batch_first) -- one launch per layer
  * for both directions and all T steps (baseline_models.py:191-193; gate order r, z, n).
  *   gi    [B][T][2][3H]  x W_ih^T + b_ih for (forward, reverse)     (from sept_gemm)

@@ -382,6 +382,141 @@ void launch_nt(const NtArgs& g, hipStream_t st) {
   hipLaunchKernelGGL((sept_gemm_nt_split_kernel<A_BF16, MB, BK>), dim3(grid), dim3(256), 0, st, g);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// "TN" product with split operands for the weight gradients of the GRU / Linear layers
+// (dW = dy^T x; autograd of model/baseline_models.py:191-193, 208-210):
+//   C[m][n] = sum_k A[k][m] * B[k][n]          A fp32 (gradient rows), B bf16 or fp32 (layer input)
+// Both operands are k-strided (rows are samples), so tiles are staged as [k][m] / [k][n] planes
+// (fp32 operands split into bf16 hi + lo on the way in) and the MFMA fragments are fetched with
+// the transposing LDS read ds_read_b64_tr_b16.  Passes: hi*hi + lo*hi (+ hi*lo when B is fp32).
+// K = batch*time is long and M x N small, so K is split over grid.z into a workspace of partial
+// slabs that a second kernel sums in fixed order (deterministic, no float atomics).
+struct TnArgs {
+  const float* A;
+  const void* B;
+  float* C;
+  float* ws;
+  long lda, ldb, ldc;
+  int M, N, K, kchunk, splits;
+};
+
+constexpr int TN_RS = 192;              // bytes per LDS row: 64 bf16 + pad (4 rows x 64 B hit 64 distinct banks)
+constexpr int TN_PLANE = 32 * TN_RS;    // 32 k-rows
+
+__device__ __forceinline__ bf16x4 lds_tr4(const unsigned char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(reinterpret_cast<uintptr_t>(p)));
+}
+__device__ __forceinline__ bf16x8 lds_tr8(const unsigned char* p) {   // k rows r..r+3 and r+4..r+7
+  return __builtin_shufflevector(lds_tr4(p), lds_tr4(p + 4 * TN_RS), 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <bool B_BF16>
+__global__ __launch_bounds__(256) void sept_gemm_tn_split_kernel(TnArgs g) {
+  constexpr int NBP = B_BF16 ? 1 : 2;
+  __shared__ __attribute__((aligned(16))) unsigned char As[2][2][TN_PLANE];
+  __shared__ __attribute__((aligned(16))) unsigned char Bs[2][NBP][TN_PLANE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  const int kbeg = blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  // staging: fp32 operand -> 2 float4 per thread (k row e>>4, 4 columns at (e&15)*4);
+  //          bf16 operand -> one 16-byte load per thread (k row tid>>3, 8 columns at (tid&7)*8).
+  // Column chunks past the edge are clamped (they only feed outputs that are never stored);
+  // k rows past the end are zeroed in A (B rows are clamped, so the products are exact zeros).
+  float4 a4[2], b4[B_BF16 ? 1 : 2];
+  uint4 b16 = make_uint4(0, 0, 0, 0);
+  int acol[2], bcol[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int e = tid + 256 * i;
+    acol[i] = min(m0 + (e & 15) * 4, g.M - 4);
+    bcol[i] = min(n0 + (e & 15) * 4, g.N - 4);
+  }
+  const int bcol16 = min(n0 + (tid & 7) * 8, g.N - 8);
+  auto load_globals = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int k = k0 + ((tid + 256 * i) >> 4);
+      const float4 v = *reinterpret_cast<const float4*>(g.A + long(min(k, g.K - 1)) * g.lda + acol[i]);
+      a4[i] = k < kend ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!B_BF16)
+        b4[i] = *reinterpret_cast<const float4*>(static_cast<const float*>(g.B) + long(min(k, g.K - 1)) * g.ldb + bcol[i]);
+    }
+    if (B_BF16) {
+      const int k = min(k0 + (tid >> 3), g.K - 1);
+      b16 = *reinterpret_cast<const uint4*>(static_cast<const bf16*>(g.B) + long(k) * g.ldb + bcol16);
+    }
+  };
+  auto store_lds = [&](int buf) {
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + 256 * i, off = (e >> 4) * TN_RS + (e & 15) * 8;
+      split4(a4[i], hi, lo);
+      *reinterpret_cast<bf16x4*>(&As[buf][0][off]) = hi;
+      *reinterpret_cast<bf16x4*>(&As[buf][1][off]) = lo;
+      if (!B_BF16) {
+        split4(b4[i], hi, lo);
+        *reinterpret_cast<bf16x4*>(&Bs[buf][0][off]) = hi;
+        *reinterpret_cast<bf16x4*>(&Bs[buf][NBP - 1][off]) = lo;
+      }
+    }
+    if (B_BF16) *reinterpret_cast<uint4*>(&Bs[buf][0][(tid >> 3) * TN_RS + (tid & 7) * 16]) = b16;
+  };
+  // transposing fragment reads: within each 16-lane group lane i fetches k row (i>>2), columns
+  // 4*(i&3)..+3 and receives column i, k rows 0..3
+  const int tr_off = (8 * (lane >> 5) + ((lane & 15) >> 2)) * TN_RS + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+  const int aoff = tr_off + wm * 2, boff = tr_off + wn * 2;
+
+  const int nk = (kend - kbeg + 31) / 32;
+  if (nk > 0) {
+    load_globals(kbeg);
+    store_lds(0);
+  }
+  __syncthreads();
+  for (int ks = 0; ks < nk; ++ks) {
+    const int buf = ks & 1;
+    if (ks + 1 < nk) load_globals(kbeg + (ks + 1) * 32);
+#pragma unroll
+    for (int kk = 0; kk < 32; kk += 16) {
+      const bf16x8 ah = lds_tr8(&As[buf][0][aoff + kk * TN_RS]);
+      const bf16x8 al = lds_tr8(&As[buf][1][aoff + kk * TN_RS]);
+      const bf16x8 bh = lds_tr8(&Bs[buf][0][boff + kk * TN_RS]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+      if (!B_BF16) {
+        const bf16x8 bl = lds_tr8(&Bs[buf][NBP - 1][boff + kk * TN_RS]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+    }
+    if (ks + 1 < nk) store_lds(buf ^ 1);
+    sept::lds_barrier();
+  }
+  const int n = n0 + wn + (lane & 31);
+  if (n >= g.N) return;
+  float* out = g.splits > 1 ? g.ws + size_t(blockIdx.z) * g.M * g.N : g.C;
+  const long ld = g.splits > 1 ? g.N : g.ldc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (m < g.M) out[long(m) * ld + n] = acc[r];
+  }
+}
+
+__global__ void sept_gemm_tn_reduce_kernel(TnArgs g) {
+  const long total = long(g.M) * g.N;
+  for (long i = long(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += long(gridDim.x) * blockDim.x) {
+    float s = 0.f;
+    for (int z = 0; z < g.splits; ++z) s += g.ws[size_t(z) * total + i];
+    g.C[(i / g.N) * g.ldc + i % g.N] = s;
+  }
+}
+
 }  // namespace
 
 extern "C" int sept_gemm(const void* A, long sam, long sak, int a_is_bf16, const void* B, long sbk, long sbn,
@@ -443,4 +578,39 @@ extern "C" int sept_gemm_nt_split(const void* A, long lda, int a_is_bf16, const 
     else launch_nt<false, 1, 32>(g, st);
   }
   return sept::launch_check("sept_gemm_nt_split_kernel");
+}
+
+
+extern "C" size_t sept_gemm_tn_workspace_floats(int M, int N) { return size_t(16) * size_t(M) * size_t(N); }
+
+extern "C" int sept_gemm_tn_split(const float* A, long lda, const void* B, long ldb, int b_is_bf16, float* C, long ldc,
+                                  int M, int N, int K, float* ws, long ws_floats, void* stream) {
+  SEPT_REQUIRE(M >= 0 && N >= 0 && K >= 0, SEPT_ERR_INVALID, "sept_gemm_tn_split: M=%d N=%d K=%d", M, N, K);
+  if (M == 0 || N == 0) return SEPT_OK;
+  SEPT_REQUIRE(A && B && C && K > 0, SEPT_ERR_INVALID, "sept_gemm_tn_split: null argument or K == 0");
+  const int nq = b_is_bf16 ? 8 : 4;
+  SEPT_REQUIRE(M % 4 == 0 && N % nq == 0 && lda % 4 == 0 && ldb % nq == 0 && lda >= M && ldb >= N && ldc >= N &&
+                   reinterpret_cast<uintptr_t>(A) % 16 == 0 && reinterpret_cast<uintptr_t>(B) % 16 == 0,
+               SEPT_ERR_INVALID, "sept_gemm_tn_split: M=%d N=%d lda=%ld ldb=%ld ldc=%ld need 16-byte aligned rows", M, N,
+               lda, ldb, ldc);
+  TnArgs g{A, B, C, ws, lda, ldb, ldc, M, N, K, 0, 1};
+  const int tiles = ((N + 63) / 64) * ((M + 63) / 64);
+  int splits = 1;
+  if (ws && tiles < 1024 && K >= 256) {
+    splits = std::min({16, (1024 + tiles - 1) / tiles, K / 128});
+    while (splits > 1 && long(splits) * M * N > ws_floats) --splits;
+  }
+  splits = std::max(splits, 1);
+  g.kchunk = ((K + splits - 1) / splits + 31) / 32 * 32;
+  g.splits = (K + g.kchunk - 1) / g.kchunk;
+  const dim3 grid((N + 63) / 64, (M + 63) / 64, g.splits);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (b_is_bf16) hipLaunchKernelGGL(sept_gemm_tn_split_kernel<true>, grid, dim3(256), 0, st, g);
+  else hipLaunchKernelGGL(sept_gemm_tn_split_kernel<false>, grid, dim3(256), 0, st, g);
+  if (g.splits > 1) {
+    const long total = long(M) * N;
+    hipLaunchKernelGGL(sept_gemm_tn_reduce_kernel, dim3(int(std::min<long>((total + 255) / 256, 2048))), dim3(256), 0,
+                       st, g);
+  }
+  return sept::launch_check("sept_gemm_tn_split_kernel");
 }

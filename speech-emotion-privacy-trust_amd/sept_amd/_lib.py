@@ -53,6 +53,9 @@ SIGNATURES = {
     "sept_bn_relu_pool_backward": (c_int, [c_void_p] * 11 + [c_int] * 5 + [c_void_p]),
     "sept_gemm_nt_split": (c_int, [c_void_p, c_long, c_int, c_void_p, c_long, c_void_p, c_long, c_int, c_void_p,
                                    c_int, c_int, c_int, c_void_p]),
+    "sept_gemm_tn_workspace_floats": (c_size_t, [c_int, c_int]),
+    "sept_gemm_tn_split": (c_int, [c_void_p, c_long, c_void_p, c_long, c_int, c_void_p, c_long, c_int, c_int, c_int,
+                                   c_void_p, c_long, c_void_p]),
     "sept_gemm": (c_int, [c_void_p, c_long, c_long, c_int, c_void_p, c_long, c_long, c_int, c_void_p, c_long, c_int,
                           c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_long, c_void_p]),
     "sept_gru_forward": (c_int, [c_void_p] * 7 + [c_int] * 3 + [c_void_p]),

@@ -244,6 +244,17 @@ def linear_backward_weight(dy, x, out=None):
     K = x.shape[1]
     if out is None:
         out = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+    xq = 8 if _is_bf16(x) else 4
+    if (M >= 512 and dy.dtype == torch.float32 and dy.stride(1) == 1 and x.stride(1) == 1 and N % 4 == 0
+            and K % xq == 0 and dy.stride(0) % 4 == 0 and x.stride(0) % xq == 0 and out.stride(1) == 1
+            and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0):
+        # long sample axis: split-operand bf16 MFMA with transposing LDS reads (sept_gemm_tn_split)
+        wsn = lib.sept_gemm_tn_workspace_floats(N, K)
+        ws = workspace("gemm_tn", wsn, dy.device)
+        check(lib.sept_gemm_tn_split(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), _is_bf16(x),
+                                     out.data_ptr(), out.stride(0), N, K, M, ws.data_ptr(), wsn, _s(out)),
+              "sept_gemm_tn_split")
+        return out
     return gemm_raw(dy, 1, dy.stride(0), x, x.stride(0), 1, out, out.stride(0), N, K, M)
 
 

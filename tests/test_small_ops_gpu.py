@@ -65,6 +65,28 @@ def test_gemm_nt_split(M, N, K, abf16):
         ops.linear_nt_split(x.cuda()[:, 8:], W.cuda()[:, 8:])          # K not a multiple of 32
 
 
+@pytest.mark.parametrize("S,N,K,xbf16", [(5600, 384, 1280, True), (5600, 192, 64, False), (5600, 384, 128, False),
+                                         (777, 36, 40, True), (600, 4, 132, False), (512, 128, 8, True)])
+def test_gemm_tn_split(S, N, K, xbf16):
+    """sept_gemm_tn_split (dW = dy^T x on the bf16 MFMA with hi/lo-split operands, split-K) vs
+    float64; also views with an offset / larger leading dimension (the dW_hh products) and
+    run-to-run determinism."""
+    from sept_amd import ops
+    g = torch.Generator().manual_seed(S + N + K)
+    dy = torch.randn(S, N, generator=g)
+    x = torch.randn(S, K, generator=g)
+    if xbf16:
+        x = x.bfloat16()
+    want = dy.double().t() @ x.double()
+    got = ops.linear_backward_weight(dy.cuda(), x.cuda())
+    assert (got.cpu().double() - want).abs().max() < 3e-5 * S ** 0.5 * (1 + want.abs().max() / S ** 0.5)
+    assert torch.equal(got, ops.linear_backward_weight(dy.cuda(), x.cuda()))
+    if N % 8 == 0 and K % 16 == 0:
+        dyw, xw = dy.cuda(), x.cuda()
+        got2 = ops.linear_backward_weight(dyw[:, N // 2:], xw[:, K // 2:])
+        assert torch.allclose(got2, got[N // 2:, K // 2:], rtol=1e-5, atol=1e-4)
+
+
 @pytest.mark.parametrize("B,T", [(7, 25), (4, 3), (1, 1)])
 def test_gru_layer_forward_backward(B, T):
     """One bidirectional GRU layer (input projections by sept_gemm + recurrent kernel) vs nn.GRU."""
