@@ -22,33 +22,59 @@ def _advance_rng(device):
 
 class FlatParams:
     """Packs the trainable parameters into one flat fp32 buffer (parameters become views), so
-    the optimiser is one kernel launch and data-parallel needs one all-reduce over one buffer."""
+    the optimiser is one kernel launch and data-parallel needs one all-reduce over one buffer.
+
+    Parameters that receive no gradient (heads / attention matrices the forward never touches)
+    are skipped by torch.optim -- no weight decay, no momentum.  The first gather_grads() finds
+    them and moves them behind the `n_active` prefix that the optimiser and the all-reduce use."""
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
+        self._settled = False
+        self._pack()
+
+    def _pack(self):
         dev = self.params[0].device
         self.numel = sum(p.numel() for p in self.params)
-        self.flat = torch.empty(self.numel, dtype=torch.float32, device=dev)
+        self.n_active = getattr(self, "n_active", self.numel)
+        flat = torch.empty(self.numel, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(self.numel, dtype=torch.float32, device=dev)
         off = 0
         self.views = []
         for p in self.params:
             n = p.numel()
-            v = self.flat[off:off + n].view_as(p)
+            v = flat[off:off + n].view_as(p)
             v.copy_(p.data)
             p.data = v
             self.views.append((off, n))
             off += n
+        self.flat = flat
 
     def gather_grads(self):
         """Pack the autograd-produced gradients into the flat gradient buffer (one launch) and
         expose them as views."""
+        if not self._settled:
+            self._settled = True
+            active = [p for p in self.params if p.grad is not None]
+            if len(active) < len(self.params):
+                grads = {id(p): p.grad for p in active}
+                self.params = active + [p for p in self.params if p.grad is None]
+                self.n_active = sum(p.numel() for p in active)
+                self._pack()
+                for p in active:
+                    p.grad = grads[id(p)]
+            self._n_act_params = len(active)
+        act = self.params[:self._n_act_params]
         torch.cat([p.grad.reshape(-1) if p.grad is not None else torch.zeros(p.numel(), device=self.flat.device)
-                   for p in self.params], out=self.grad)
-        for p, (off, n) in zip(self.params, self.views):
+                   for p in act], out=self.grad[:self.n_active])
+        for p, (off, n) in zip(act, self.views):
             p.grad = self.grad[off:off + n].view_as(p)
+        for p in self.params[self._n_act_params:]:
+            if p.grad is not None:
+                raise RuntimeError("a parameter without a gradient in the first step received one later; "
+                                   "rebuild the trainer after changing which heads are in use")
 
     def zero_grad(self):
         for p in self.params:
@@ -63,10 +89,8 @@ class GrlTrainer:
         self.kind = optimizer
         if optimizer == "sgd":       # :417  SGD(lr=0.001, momentum=0.9, weight_decay=1e-4)
             self.lr = 1e-3 if lr is None else lr
-            self.buf = torch.zeros_like(self.flat.flat)
         elif optimizer == "adam":    # :420  Adam(lr=0.0005, weight_decay=1e-4, betas=(0.9, 0.98), eps=1e-9)
             self.lr = 5e-4 if lr is None else lr
-            self.m, self.v = torch.zeros_like(self.flat.flat), torch.zeros_like(self.flat.flat)
         else:
             raise ValueError(f"unknown optimizer {optimizer}")
         self.momentum, self.weight_decay, self.betas, self.eps = momentum, weight_decay, betas, eps
@@ -85,13 +109,20 @@ class GrlTrainer:
                                       self.scale_lamda, rhos, float(noise.min_scale), float(noise.max_scale))
 
     def optimizer_step(self):
+        """One update of the parameters that received a gradient (the active prefix of the flat
+        buffer); state is created at the first call, when that set is known."""
         f = self.flat
+        w, g = f.flat[:f.n_active], f.grad[:f.n_active]
         gscale = 1.0 / self.world
         self.steps += 1
         if self.kind == "sgd":
-            ops.sgd_step(f.flat, f.grad, self.buf, self.lr, self.momentum, self.weight_decay, self.steps == 1, gscale)
+            if self.steps == 1:
+                self.buf = torch.zeros_like(w)
+            ops.sgd_step(w, g, self.buf, self.lr, self.momentum, self.weight_decay, self.steps == 1, gscale)
         else:
-            ops.adam_step(f.flat, f.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps,
+            if self.steps == 1:
+                self.m, self.v = torch.zeros_like(w), torch.zeros_like(w)
+            ops.adam_step(w, g, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps,
                           self.weight_decay, self.steps, gscale)
         SF.invalidate_weight_cache()  # parameters changed through raw pointers
 
@@ -108,7 +139,7 @@ class GrlTrainer:
         if self.world > 1:
             # the loss is a mean over the local shard (:150-151), so averaging equal shards gives
             # the global-batch gradient; the scale term is batch independent and survives averaging
-            torch.distributed.all_reduce(self.flat.grad, group=self.pg)
+            torch.distributed.all_reduce(self.flat.grad[:self.flat.n_active], group=self.pg)
         self.optimizer_step()
         return loss.detach(), preds.detach(), preds_grl.detach()
 
@@ -132,10 +163,8 @@ class BaselineTrainer:
         self.kind = optimizer
         if optimizer == "sgd":
             self.lr = 1e-4 if lr is None else lr
-            self.buf = torch.zeros_like(self.flat.flat)
         elif optimizer == "adam":
             self.lr = 5e-5 if lr is None else lr
-            self.m, self.v = torch.zeros_like(self.flat.flat), torch.zeros_like(self.flat.flat)
         else:
             raise ValueError(f"unknown optimizer {optimizer}")
         self.momentum, self.weight_decay, self.betas, self.eps = momentum, weight_decay, betas, eps
@@ -154,7 +183,7 @@ class BaselineTrainer:
         loss.backward()
         self.flat.gather_grads()
         if self.world > 1:
-            torch.distributed.all_reduce(self.flat.grad, group=self.pg)
+            torch.distributed.all_reduce(self.flat.grad[:self.flat.n_active], group=self.pg)
         self.optimizer_step()
         return loss.detach(), preds.detach()
 
@@ -208,7 +237,7 @@ class FusedPipeline:
         def replay():
             graph.replay()
             if tr.world > 1:
-                torch.distributed.all_reduce(tr.flat.grad, group=tr.pg)
+                torch.distributed.all_reduce(tr.flat.grad[:tr.flat.n_active], group=tr.pg)
             tr.optimizer_step()
             return out
 

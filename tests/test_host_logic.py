@@ -69,6 +69,12 @@ def test_flat_params_pack_and_gather():
     assert torch.equal(a.data, 2 * va)
     fp.zero_grad()
     assert a.grad is None
+    # b never received a gradient: like torch.optim it stays outside the updated / reduced prefix
+    assert fp.n_active == 12 and fp.params[0] is a and fp.params[1] is b
+    assert b.data.data_ptr() == fp.flat[12:].data_ptr() and torch.equal(b.data, 2 * vb)
+    a.grad, b.grad = torch.ones(3, 4), torch.ones(5)
+    with pytest.raises(RuntimeError):
+        fp.gather_grads()
 
 
 def _dp_worker(rank, world, port, F, ret):

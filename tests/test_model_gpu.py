@@ -359,12 +359,11 @@ def test_baseline_trainer_step_matches_torch_sgd():
     ref = mo.one_d_cnn_lstm(1, F, 64, **kw)
     ref.load_state_dict(sd)
     zero_dropout(m), zero_dropout(ref)
-    # the reference optimiser also updates the (unused) rnn / dense / attention parameters through
-    # weight decay only; restrict both sides to the parameters the forward touches
+    # torch.optim skips parameters whose grad is None (the unused rnn / dense / attention tensors):
+    # no weight decay, no momentum.  Both sides get ALL parameters; the unused ones must not move.
     used = [n for n, p in ref.named_parameters() if n.startswith(("conv.", "classifier.", "pred_emotion_layer."))]
-    for n, p in m.named_parameters():
-        p.requires_grad = n in used
-    opt = torch.optim.SGD([p for n, p in ref.named_parameters() if n in used], lr=1e-4, momentum=0.9, weight_decay=1e-4)
+    before = {n: p.detach().clone() for n, p in ref.named_parameters()}
+    opt = torch.optim.SGD(ref.parameters(), lr=1e-4, momentum=0.9, weight_decay=1e-4)
     tr = BaselineTrainer(m, optimizer="sgd")
     x = closed_form_input(B, W, F)
     le, _, wts = closed_form_labels(B)
@@ -377,6 +376,8 @@ def test_baseline_trainer_step_matches_torch_sgd():
         opt.step()
         assert float(loss) == pytest.approx(float(rl), rel=1e-5)
     got = dict(m.named_parameters())
+    assert tr.flat.n_active == sum(p.numel() for n, p in ref.named_parameters() if n in used) < tr.flat.numel
     for n, p in ref.named_parameters():
-        if n in used:
-            assert torch.allclose(got[n].detach().cpu(), p.detach(), rtol=1e-5, atol=1e-7), n
+        assert torch.allclose(got[n].detach().cpu(), p.detach(), rtol=1e-5, atol=1e-7), n
+        if n not in used:
+            assert torch.equal(p.detach(), before[n]) and torch.equal(got[n].detach().cpu(), before[n]), n
