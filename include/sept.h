@@ -219,6 +219,12 @@ int sept_loss_sub_log(float* loss, const float* mean, float lambda, void* stream
 /* dst[n][w*C + c] = src[n][c*Wd + w] (inverse != 0: the other way): GRU weight_ih_l0 between
  * the reference's (c, w) feature order (cloak_models.py:166-168) and the NHWC (w, c) order */
 int sept_permute_cols(const float* src, float* dst, int N, int C, int Wd, int inverse, void* stream);
+/* Operands of the GRU input projections of one layer in one launch: wcat (2G, K) = [W_ih; W_ih_reverse]
+ * (layer 0: columns permuted from the reference's (c, w) feature order to NHWC (w, c), C*Wd == K;
+ * C == 0 copies), its transpose wcatT (K, 2G) for dx = dgi W, and bcat (2G) = [b_ih; b_ih_reverse].
+ * G = 3*hidden.  baseline_models.py:191-193, cloak_models.py:166-168. */
+int sept_gru_pack(const float* w_fwd, const float* w_rev, const float* b_fwd, const float* b_rev, int G, int K,
+                  int C, int Wd, float* wcat, float* wcatT, float* bcat, void* stream);
 /* one_d_cnn_lstm (baseline_models.py:47-62), channels-last fp32 [B][T][C]:
  * Conv1d(k=5, pad=2) = sept_gemm on the unfolded input col[B][T][5*C] (col[..][k*C+c] = x[t+k-2][c]);
  * its data gradient folds dcol back; ReLU + MaxPool1d(pool) + Dropout forward/backward with the

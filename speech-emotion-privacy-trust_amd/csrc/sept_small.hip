@@ -212,6 +212,21 @@ __global__ void permute_cols_kernel(const float* src, float* dst, int N, int C, 
   }
 }
 
+// One launch that builds the operands of the GRU input projections of one layer from the four
+// nn.GRU tensors: wcat (2G, K) = [W_ih forward; W_ih reverse] with the layer-0 columns permuted to
+// the NHWC feature order (C > 0; C == 0 copies), its transpose wcatT (K, 2G) and bcat (2G).
+__global__ void gru_pack_kernel(const float* wf, const float* wr, const float* bf, const float* br, int G, int K,
+                                int C, int Wd, float* wcat, float* wcatT, float* bcat) {
+  GRID_STRIDE(i, long(2) * G * K) {
+    const int n = i / K, k = i % K;
+    const float* src = n < G ? wf + long(n) * K : wr + long(n - G) * K;
+    const float v = C > 0 ? src[(k % C) * Wd + k / C] : src[k];
+    wcat[i] = v;
+    wcatT[long(k) * 2 * G + n] = v;
+    if (k == 0) bcat[n] = n < G ? bf[n] : br[n - G];
+  }
+}
+
 // ---------------- windowing + per-speaker z-normalisation ----------------
 // preprocess_adversary_data.py:131 (windows of win frames every shift frames, :71 of the trainer)
 // and :377-378 (x - mean) / (std + 1e-5) per mel bin.  mel (B, T, F) time-major ->
@@ -537,6 +552,16 @@ extern "C" int sept_permute_cols(const float* src, float* dst, int N, int C, int
   hipLaunchKernelGGL(permute_cols_kernel, dim3(blocks_for(long(N) * C * Wd)), dim3(kThreads), 0, ST(stream), src, dst,
                      N, C, Wd, inverse);
   return sept::launch_check("permute_cols_kernel");
+}
+
+extern "C" int sept_gru_pack(const float* w_fwd, const float* w_rev, const float* b_fwd, const float* b_rev, int G, int K,
+                             int C, int Wd, float* wcat, float* wcatT, float* bcat, void* stream) {
+  SEPT_REQUIRE(w_fwd && w_rev && b_fwd && b_rev && wcat && wcatT && bcat && G > 0 && K > 0, SEPT_ERR_INVALID,
+               "sept_gru_pack: bad argument");
+  SEPT_REQUIRE(C == 0 || (C > 0 && Wd > 0 && C * Wd == K), SEPT_ERR_INVALID, "sept_gru_pack: C*Wd=%d*%d != K=%d", C, Wd, K);
+  hipLaunchKernelGGL(gru_pack_kernel, dim3(blocks_for(long(2) * G * K)), dim3(kThreads), 0, ST(stream), w_fwd, w_rev,
+                     b_fwd, b_rev, G, K, C, Wd, wcat, wcatT, bcat);
+  return sept::launch_check("gru_pack_kernel");
 }
 
 extern "C" int sept_window_norm(const float* mel_btf, const float* mean, const float* stdv, float* out, int B, int T,

@@ -8,6 +8,7 @@ product modules (model/*.py) keep the reference's call surface.  Nothing here co
 CPU or through eager torch math: torch supplies storage, views, RNG draws and the autograd
 tape only.
 """
+import math
 from types import SimpleNamespace
 
 import torch
@@ -54,17 +55,17 @@ def _cached_pair(tag, t1, t2, fn):
 
 def _gru_cat_weights(wif, wir, bif, bir, layer, C, Wd):
     """[W_ih forward; W_ih reverse] as ONE (384, K) operand (layer 0: columns permuted to the NHWC
-    feature order) and the matching (384,) bias, so both directions share one product per GEMM."""
-    K = wif.shape[1]
-    wcat = torch.empty((384, K), dtype=torch.float32, device=wif.device)
-    bcat = torch.empty(384, dtype=torch.float32, device=wif.device)
-    for d, (w_, b_) in enumerate(((wif, bif), (wir, bir))):
-        if layer == 0:
-            ops.permute_cols(w_.detach(), C, Wd, out=wcat[192 * d:192 * (d + 1)])
-        else:
-            ops.scale(w_.detach(), 1.0, out=wcat[192 * d:192 * (d + 1)])
-        ops.scale(b_.detach(), 1.0, out=bcat[192 * d:192 * (d + 1)])
-    return wcat, bcat, ops.transpose2d(wcat)     # (K, 384) copy: the k-contiguous operand of dx = dgi W
+    feature order), its (K, 384) transpose (the k-contiguous operand of dx = dgi W) and the matching
+    (384,) bias, so both directions share one product per GEMM.  One launch (sept_gru_pack)."""
+    G, K = wif.shape
+    dev = wif.device
+    wcat = torch.empty((2 * G, K), dtype=torch.float32, device=dev)
+    wcatT = torch.empty((K, 2 * G), dtype=torch.float32, device=dev)
+    bcat = torch.empty(2 * G, dtype=torch.float32, device=dev)
+    ops.check(ops.lib.sept_gru_pack(wif.data_ptr(), wir.data_ptr(), bif.data_ptr(), bir.data_ptr(), G, K,
+                                    C if layer == 0 else 0, Wd if layer == 0 else 0, wcat.data_ptr(), wcatT.data_ptr(),
+                                    bcat.data_ptr(), ops.current_stream_ptr(dev)), "sept_gru_pack")
+    return wcat, bcat, wcatT
 
 
 def _nt_ok(K):
@@ -112,6 +113,24 @@ def _drop_mask(shape, device, p=DROP_P):
     return ops.rng(device, "dropout").dropout_mask(shape, p)
 
 
+def _drop_masks(device, specs):
+    """All dropout scale masks of one forward in one launch per distinct p: `specs` is a list of
+    (key, shape, p); returns {key: mask} for the entries with p > 0."""
+    out = {}
+    by_p = {}
+    for key, shape, p in specs:
+        if p > 0:
+            by_p.setdefault(float(p), []).append((key, shape))
+    for p, items in by_p.items():
+        sizes = [(math.prod(shape) + 7) // 8 * 8 for _, shape in items]
+        flat = ops.rng(device, "dropout").dropout_mask((sum(sizes),), p)
+        off = 0
+        for (key, shape), n in zip(items, sizes):
+            out[key] = flat[off:off + math.prod(shape)].view(shape)
+            off += n
+    return out
+
+
 def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None):
     """x (B, H, W) fp32 CUDA -> logits (B, C).  Returns (logits, saved) where `saved` holds
     what trunk_backward needs.  BatchNorm uses batch statistics (and updates the running
@@ -126,6 +145,18 @@ def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None):
     S = SimpleNamespace(x=x, blocks=[], train=train, pooling=pooling, B=B)
     act = None
     h, w = H, W
+    masks = {}
+    if train:   # every mask the step needs, drawn up front (injected ones take precedence below)
+        t_out = H
+        for pool in P.pools:
+            t_out //= pool
+        specs = [(("c", li), (B, cv.weight.shape[0]), P.drop_ps[li]) for li, cv in enumerate(P.convs)
+                 if "drop2d" not in inj]
+        if "rnn" not in inj:
+            specs.append(("rnn", (B, t_out, 128), P.rnn.dropout))
+        if "dense" not in inj:
+            specs.append(("dense", (B, P.dense1.weight.shape[0]), P.dense_p))
+        masks = _drop_masks(dev, specs)
     for li, (cv, bn, pool) in enumerate(zip(P.convs, P.bns, P.pools)):
         cout = cv.weight.shape[0]
         if li == 0:
@@ -141,7 +172,7 @@ def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None):
         drop = None
         if train and (P.drop_ps[li] > 0 or "drop2d" in inj):
             d2 = inj.get("drop2d")
-            drop = d2[li] if d2 is not None else _drop_mask((B, cout), dev, P.drop_ps[li])
+            drop = d2[li] if d2 is not None else masks[("c", li)]
         out = ops.bn_relu_pool_forward(pre, mean, invstd, bn.weight, bn.bias, drop, pool)
         S.blocks.append(SimpleNamespace(inp=act, pre=pre, mean=mean, invstd=invstd, drop=drop, pool=pool, h=h, w=w,
                                         bn_train=bn.training))
@@ -171,7 +202,7 @@ def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None):
             nxt = out.view(B * T, 128)
             if train and (r.dropout > 0 or "rnn" in inj):
                 m = inj.get("rnn")
-                G.mask = m if m is not None else _drop_mask((B, T, 128), dev, r.dropout)
+                G.mask = m if m is not None else masks["rnn"]
                 nxt = ops.mul(out, G.mask).view(B * T, 128)
             layer_in = nxt
         S.gru.append(G)
@@ -181,7 +212,7 @@ def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None):
     dmask = None
     if train and (P.dense_p > 0 or "dense" in inj):
         m = inj.get("dense")
-        dmask = m if m is not None else _drop_mask((B, d1.shape[1]), dev, P.dense_p)
+        dmask = m if m is not None else masks["dense"]
     d1a = ops.relu_dropout_forward(d1, dmask)
     logits = ops.linear_forward(d1a, P.head.weight, P.head.bias)
     S.z, S.d1, S.dmask, S.d1a = z, d1, dmask, d1a

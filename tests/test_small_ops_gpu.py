@@ -87,6 +87,21 @@ def test_gemm_tn_split(S, N, K, xbf16):
         assert torch.allclose(got2, got[N // 2:, K // 2:], rtol=1e-5, atol=1e-4)
 
 
+def test_gru_pack_matches_permute_and_transpose():
+    from sept_amd import functional as SF
+    g = torch.Generator().manual_seed(5)
+    C, Wd = 128, 10
+    wf, wr = torch.randn(192, C * Wd, generator=g), torch.randn(192, C * Wd, generator=g)
+    bf, br = torch.randn(192, generator=g), torch.randn(192, generator=g)
+    for layer in (0, 1):
+        wcat, bcat, wcatT = SF._gru_cat_weights(wf.cuda(), wr.cuda(), bf.cuda(), br.cuda(), layer, C, Wd)
+        want = torch.cat([wf, wr])
+        if layer == 0:   # reference feature order (c, w) -> NHWC (w, c)
+            want = want.view(384, C, Wd).transpose(1, 2).reshape(384, C * Wd)
+        assert torch.equal(wcat.cpu(), want) and torch.equal(wcatT.cpu(), want.t())
+        assert torch.equal(bcat.cpu(), torch.cat([bf, br]))
+
+
 @pytest.mark.parametrize("B,T", [(7, 25), (4, 3), (1, 1)])
 def test_gru_layer_forward_backward(B, T):
     """One bidirectional GRU layer (input projections by sept_gemm + recurrent kernel) vs nn.GRU."""
