@@ -61,7 +61,15 @@ template <int CPP>
 __global__ __launch_bounds__(256) void sept_bn_stats_partial_kernel(const bf16* x, long n_items, float* ws) {
   __shared__ float lds[256 * 16];
   f32x8 s = {0, 0, 0, 0, 0, 0, 0, 0}, ss = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (long i = long(blockIdx.x) * 256 + threadIdx.x; i < n_items; i += long(gridDim.x) * 256) {
+  long i = long(blockIdx.x) * 256 + threadIdx.x;
+  const long step = long(gridDim.x) * 256;   // a multiple of CPP: the channel chunk of a lane is fixed
+  for (; i + 3 * step < n_items; i += 4 * step) {   // four independent 16-byte loads in flight
+    const f32x8 v0 = load8(x + i * 8), v1 = load8(x + (i + step) * 8);
+    const f32x8 v2 = load8(x + (i + 2 * step) * 8), v3 = load8(x + (i + 3 * step) * 8);
+    s += (v0 + v1) + (v2 + v3);
+    ss += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+  }
+  for (; i < n_items; i += step) {
     const f32x8 v = load8(x + i * 8);
     s += v;
     ss += v * v;
@@ -145,14 +153,19 @@ struct BnBwdArgs {
 // position only (first maximum in window scan order, as ATen's max_pool2d picks) and only
 // if the ReLU was active there.  Returns g (gradient wrt the BN output at that position),
 // xh (normalised input there) and the window index `arg` per channel.
-template <int CPP>
+template <int CPP, int P>
 __device__ __forceinline__ void bn_bwd_window(const BnBwdArgs& a, long px, int chunk, const f32x8& mu,
                                               const f32x8& is, const f32x8& sc, const f32x8& sh, f32x8& g,
-                                              f32x8& xh, int (&arg)[8]) {
-  const int C = CPP * 8, P = a.pool;
+                                              f32x8& xh, int (&arg)[8], f32x8 (&xv)[P * P]) {
+  constexpr int C = CPP * 8;
   const int Ho = a.H / P, Wo = a.W / P;
   const int wo = px % Wo, ho = (px / Wo) % Ho, b = px / (long(Wo) * Ho);
   const bf16* xp = a.x + ((long(b) * a.H + ho * P) * a.W + wo * P) * C + chunk * 8;
+  // all loads of the window (and its gradient) are issued before any of them is consumed
+#pragma unroll
+  for (int q = 0; q < P * P; ++q) xv[q] = load8(xp + (long(q / P) * a.W + q % P) * C);
+  g = load8(a.dy + px * C + chunk * 8);
+  if (a.drop) g *= loadf8(a.drop + long(b) * C + chunk * 8);
   f32x8 best, bx;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -160,32 +173,28 @@ __device__ __forceinline__ void bn_bwd_window(const BnBwdArgs& a, long px, int c
     bx[e] = 0.f;
     arg[e] = 0;
   }
-  for (int dh = 0; dh < P; ++dh)
-    for (int dw = 0; dw < P; ++dw) {
-      const f32x8 xv = load8(xp + (long(dh) * a.W + dw) * C);
-      const f32x8 v = xv * sc + sh;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float r = fmaxf(v[e], 0.f);
-        if (r > best[e]) {
-          best[e] = r;
-          bx[e] = xv[e];
-          arg[e] = dh * P + dw;
-        }
+  for (int q = 0; q < P * P; ++q) {
+    const f32x8 v = xv[q] * sc + sh;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float r = fmaxf(v[e], 0.f);
+      if (r > best[e]) {
+        best[e] = r;
+        bx[e] = xv[q][e];
+        arg[e] = q;
       }
     }
-  g = load8(a.dy + px * C + chunk * 8);
-  if (a.drop) g *= loadf8(a.drop + long(b) * C + chunk * 8);
+  }
 #pragma unroll
   for (int e = 0; e < 8; ++e)
     if (!(best[e] > 0.f)) g[e] = 0.f;  // ReLU inactive (or window all <= 0)
   xh = (bx - mu) * is;
 }
 
-template <int CPP>
+template <int CPP, int P>
 __global__ __launch_bounds__(256) void sept_bn_bwd_reduce_kernel(BnBwdArgs a) {
   __shared__ float lds[256 * 16];
-  const int P = a.pool;
   const long n_items = long(a.B) * (a.H / P) * (a.W / P) * CPP;
   const int chunk = threadIdx.x % CPP;
   const f32x8 mu = loadf8(a.mean + chunk * 8), is = loadf8(a.invstd + chunk * 8);
@@ -193,9 +202,9 @@ __global__ __launch_bounds__(256) void sept_bn_bwd_reduce_kernel(BnBwdArgs a) {
   const f32x8 sc = ga * is, sh = be - mu * ga * is;
   f32x8 s1 = {0, 0, 0, 0, 0, 0, 0, 0}, s2 = {0, 0, 0, 0, 0, 0, 0, 0};
   for (long i = long(blockIdx.x) * 256 + threadIdx.x; i < n_items; i += long(gridDim.x) * 256) {
-    f32x8 g, xh;
+    f32x8 g, xh, xv[P * P];
     int arg[8];
-    bn_bwd_window<CPP>(a, i / CPP, chunk, mu, is, sc, sh, g, xh, arg);
+    bn_bwd_window<CPP, P>(a, i / CPP, chunk, mu, is, sc, sh, g, xh, arg, xv);
     s1 += g;
     s2 += g * xh;
   }
@@ -214,9 +223,9 @@ __global__ void sept_bn_bwd_finalize_kernel(float* ws, int nparts, int C, float*
   if (dgamma) dgamma[c] = float(s2);
 }
 
-template <int CPP>
+template <int CPP, int P>
 __global__ __launch_bounds__(256) void sept_bn_bwd_apply_kernel(BnBwdArgs a) {
-  const int C = CPP * 8, P = a.pool;
+  constexpr int C = CPP * 8;
   const int Ho = a.H / P, Wo = a.W / P;
   const long n_items = long(a.B) * Ho * Wo * CPP;
   const int chunk = threadIdx.x % CPP;
@@ -228,23 +237,22 @@ __global__ __launch_bounds__(256) void sept_bn_bwd_apply_kernel(BnBwdArgs a) {
   const f32x8 m1 = loadf8(sums + chunk * 8) * inv_n, m2 = loadf8(sums + C + chunk * 8) * inv_n;
   for (long i = long(blockIdx.x) * 256 + threadIdx.x; i < n_items; i += long(gridDim.x) * 256) {
     const long px = i / CPP;
-    f32x8 g, xh;
+    f32x8 g, xh, xv[P * P];
     int arg[8];
-    bn_bwd_window<CPP>(a, px, chunk, mu, is, sc, sh, g, xh, arg);
+    bn_bwd_window<CPP, P>(a, px, chunk, mu, is, sc, sh, g, xh, arg, xv);
     const int wo = px % Wo, ho = (px / Wo) % Ho, b = px / (long(Wo) * Ho);
     const long base = ((long(b) * a.H + ho * P) * a.W + wo * P) * C + chunk * 8;
-    for (int dh = 0; dh < P; ++dh)
-      for (int dw = 0; dw < P; ++dw) {
-        const long off = base + (long(dh) * a.W + dw) * C;
-        const f32x8 xhat = (load8(a.x + off) - mu) * is;
-        f32x8 d;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float ge = (arg[e] == dh * P + dw) ? g[e] : 0.f;
-          d[e] = sc[e] * (ge - m1[e] - xhat[e] * m2[e]);
-        }
-        store8(a.dx + off, d);
+    for (int q = 0; q < P * P; ++q) {
+      const f32x8 xhat = (xv[q] - mu) * is;   // the window values are still in registers
+      f32x8 d;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float ge = (arg[e] == q) ? g[e] : 0.f;
+        d[e] = sc[e] * (ge - m1[e] - xhat[e] * m2[e]);
       }
+      store8(a.dx + base + (long(q / P) * a.W + q % P) * C, d);
+    }
   }
   // rows/cols dropped by floor-mode pooling (odd H or W) receive only the mean terms
   if (a.H % P || a.W % P) {
@@ -328,9 +336,17 @@ extern "C" int sept_bn_relu_pool_backward(const void* dy, const void* x, const f
               ws, static_cast<bf16*>(dx), B, H, W, C, pool};
   const long items = long(B) * (H / pool) * (W / pool) * (C / 8);
   const int grid = grid_for(items);
-  SEPT_CPP_DISPATCH(C, hipLaunchKernelGGL(sept_bn_bwd_reduce_kernel<CPP>, dim3(grid), dim3(256), 0, st, a));
+  if (pool == 2) {
+    SEPT_CPP_DISPATCH(C, hipLaunchKernelGGL((sept_bn_bwd_reduce_kernel<CPP, 2>), dim3(grid), dim3(256), 0, st, a));
+  } else {
+    SEPT_CPP_DISPATCH(C, hipLaunchKernelGGL((sept_bn_bwd_reduce_kernel<CPP, 1>), dim3(grid), dim3(256), 0, st, a));
+  }
   hipLaunchKernelGGL(sept_bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, ws, grid, C, dgamma, dbeta);
   const int grid2 = int(std::min<long>((items + 255) / 256, 4096));
-  SEPT_CPP_DISPATCH(C, hipLaunchKernelGGL(sept_bn_bwd_apply_kernel<CPP>, dim3(grid2), dim3(256), 0, st, a));
+  if (pool == 2) {
+    SEPT_CPP_DISPATCH(C, hipLaunchKernelGGL((sept_bn_bwd_apply_kernel<CPP, 2>), dim3(grid2), dim3(256), 0, st, a));
+  } else {
+    SEPT_CPP_DISPATCH(C, hipLaunchKernelGGL((sept_bn_bwd_apply_kernel<CPP, 1>), dim3(grid2), dim3(256), 0, st, a));
+  }
   return sept::launch_check("sept_bn_relu_pool_backward");
 }
