@@ -204,18 +204,34 @@ __global__ __launch_bounds__(256) void sept_conv5x5_wgrad_kernel(WgArgs a) {
   }
 }
 
-// sums the G slabs of each z-slice in fixed order and scatters into OIHW fp32
+// sums the G slabs of each z-slice in fixed order and scatters into OIHW fp32.  A workgroup owns
+// 64 consecutive slab elements; wave j adds slabs j, j+4, ... (eight loads in flight), and the four
+// wave sums are combined in wave order through LDS.
 template <int CIN, int COUT, int MBZ, int NBZ>
-__global__ void sept_conv5x5_wgrad_finalize_kernel(const float* ws, int G, float* dw) {
+__global__ __launch_bounds__(256) void sept_conv5x5_wgrad_finalize_kernel(const float* ws, int G, float* dw) {
   constexpr int MSL = COUT / 32 / MBZ;
   constexpr int NBLK = 25 * MBZ * NBZ;
+  __shared__ float part[4][64];
   const int z = blockIdx.y;
   const int msl = z % MSL, nsl = z / MSL;
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= NBLK * 1024) return;
-  float s = 0.f;
-  for (int g = 0; g < G; ++g) s += ws[(size_t(z) * G + g) * (NBLK * 1024) + e];
-  const int lane = e & 63, r = (e >> 6) & 15, blk = e >> 10;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + lane;   // NBLK * 1024 is a multiple of 64
+  const float* p = ws + size_t(z) * G * (NBLK * 1024) + e;
+  float s0 = 0.f, s1 = 0.f;
+  int g = wave;
+  for (; g + 28 < G; g += 32) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[size_t(g + 4 * u) * (NBLK * 1024)];
+    s0 += (v[0] + v[1]) + (v[2] + v[3]);
+    s1 += (v[4] + v[5]) + (v[6] + v[7]);
+  }
+  for (; g < G; g += 4) s0 += p[size_t(g) * (NBLK * 1024)];
+  part[wave][lane] = s0 + s1;
+  __syncthreads();
+  if (wave != 0) return;
+  const float s = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+  const int r = (e >> 6) & 15, blk = e >> 10;
   const int nb = blk % NBZ, mb = (blk / NBZ) % MBZ, tap = blk / (NBZ * MBZ);
   const int cout = msl * MBZ * 32 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
   const int cin = nsl * NBZ * 32 + nb * 32 + (lane & 31);
@@ -241,7 +257,7 @@ int launch_wgrad(const WgArgs& a0, float* dw, hipStream_t st) {
   const void* fn = reinterpret_cast<const void*>(&sept_conv5x5_wgrad_kernel<CIN, COUT, MBZ, NBZ>);
   SEPT_HIP(sept::allow_max_lds(fn));
   hipLaunchKernelGGL((sept_conv5x5_wgrad_kernel<CIN, COUT, MBZ, NBZ>), dim3(G, 1, Z), dim3(256), smem, st, a);
-  hipLaunchKernelGGL((sept_conv5x5_wgrad_finalize_kernel<CIN, COUT, MBZ, NBZ>), dim3((NBLK * 1024 + 255) / 256, Z),
+  hipLaunchKernelGGL((sept_conv5x5_wgrad_finalize_kernel<CIN, COUT, MBZ, NBZ>), dim3(NBLK * 1024 / 64, Z),
                      dim3(256), 0, st, a.ws, G, dw);
   return sept::launch_check("sept_conv5x5_wgrad_kernel");
 }
