@@ -96,6 +96,74 @@ __global__ __launch_bounds__(256) void sept_conv1_fwd_kernel(const float* __rest
   }
 }
 
+// Forward on the exact-fp32 matrix pipe (v_mfma_f32_32x32x2_f32): per 32-pixel block a 32 x 26 x 32
+// product -- A = weights [channel][tap] (the 26th "tap" is the bias against a constant 1), B =
+// im2col of the staged fp32 rows [tap][pixel].  The 13 weight fragments of a lane never change,
+// so they stay in registers; B comes from LDS with one b32 read per MFMA (both wave halves read
+// the same row shifted by one tap, i.e. broadcasts, no bank conflicts).  Products are exact fp32
+// like the scalar form; the write of y (64 B per pixel) is what bounds the kernel.
+constexpr int kFwdRows = 16;  // output rows per workgroup
+__global__ __launch_bounds__(256) void sept_conv1_fwd_mfma_kernel(const float* __restrict__ x,
+                                                                  const float* __restrict__ wprep,
+                                                                  bf16* __restrict__ y, int B, int H, int W) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* tile = reinterpret_cast<float*>(smem);
+  const int W4 = W + 4;
+  const int b = blockIdx.y, h0 = blockIdx.x * kFwdRows;
+  const int nrows = min(kFwdRows, H - h0);
+  stage_x(x + size_t(b) * H * W, tile, h0, nrows + 4, H, W);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, c = lane & 31;
+  float wfrag[13];
+  int tapoff[13];
+#pragma unroll
+  for (int s = 0; s < 13; ++s) {
+    const int t = 2 * s + half;
+    wfrag[s] = t < kTaps ? wprep[t * kC + c] : wprep[kTaps * kC + c];  // t == 25: bias
+    tapoff[s] = t < kTaps ? (t / 5) * W4 + t % 5 : 0;
+  }
+  __syncthreads();
+  const int npx = nrows * W, nblk = (npx + 31) / 32;
+  bf16* yb = y + (size_t(b) * H + h0) * W * kC;
+  for (int blk = wave; blk < nblk; blk += 4) {
+    const int q = blk * 32 + c;
+    const int qc = min(q, npx - 1);
+    const int hh = qc / W, ww = qc - hh * W;
+    const float* tp = tile + hh * W4 + ww;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 13; ++s) {
+      const float xv = (s == 12 && half) ? 1.0f : tp[tapoff[s]];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wfrag[s], xv, acc, 0, 0, 0);
+    }
+    // acc[4j + i] = channel 8j + 4*half + i of pixel q.  Swap halves (v_permlane32_swap) so the
+    // lower lane of a pixel holds channels 0..15 and the upper one 16..31: two 16-byte stores each.
+    unsigned pk[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        bf16x2 t;
+        t[0] = (bf16)acc[4 * j + 2 * d];
+        t[1] = (bf16)acc[4 * j + 2 * d + 1];
+        pk[j][d] = __builtin_bit_cast(unsigned, t);
+      }
+    uint4 out[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {   // (j, j+2) pairs: lanes < 32 keep j, lanes >= 32 keep j+2
+      const auto r0 = __builtin_amdgcn_permlane32_swap(pk[u][0], pk[u + 2][0], false, false);
+      const auto r1 = __builtin_amdgcn_permlane32_swap(pk[u][1], pk[u + 2][1], false, false);
+      out[u] = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+    }
+    if (q < npx) {
+      uint4* yp = reinterpret_cast<uint4*>(yb + size_t(q) * kC + 16 * half);
+      yp[0] = out[0];
+      yp[1] = out[1];
+    }
+  }
+}
+
 // stage rows of dy (32 bf16 channels per pixel) with halo
 __device__ __forceinline__ void stage_dy(const bf16* dyb, unsigned char* tile, int h_first, int NR, int H, int W) {
   const int W4 = W + 4;
@@ -421,6 +489,13 @@ extern "C" int sept_conv1_forward(const float* x, const float* w, const float* b
   SEPT_REQUIRE(x && w && y && wprep, SEPT_ERR_INVALID, "sept_conv1_forward: null argument");
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(sept_conv1_prep_kernel, dim3((kTaps * kC + 255) / 256), dim3(256), 0, st, w, bias, wprep);
+  const size_t smem_m = sizeof(float) * size_t(kFwdRows + 4) * (W + 4);
+  static const bool scalar_fwd = getenv("SEPT_CONV1_SCALAR") != nullptr;
+  if (smem_m <= 64 * 1024 && !scalar_fwd) {
+    hipLaunchKernelGGL(sept_conv1_fwd_mfma_kernel, dim3((H + kFwdRows - 1) / kFwdRows, B), dim3(256), smem_m, st, x,
+                       static_cast<const float*>(wprep), static_cast<bf16*>(y), B, H, W);
+    return sept::launch_check("sept_conv1_fwd_mfma_kernel");
+  }
   const size_t smem = sizeof(float) * size_t(nr_max(W)) * (W + 4);
   SEPT_HIP(sept::allow_max_lds(reinterpret_cast<const void*>(&sept_conv1_fwd_kernel)));
   hipLaunchKernelGGL(sept_conv1_fwd_kernel, dim3((H * W + kMT - 1) / kMT, B), dim3(256), smem, st, x,
