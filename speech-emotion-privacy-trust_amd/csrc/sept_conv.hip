@@ -73,8 +73,13 @@ __global__ __launch_bounds__(64 * WP * WN) void sept_conv5x5_mfma_kernel(ConvArg
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = (tid >> 6) % WP, nhalf = (tid >> 6) / WP;  // pixel group, output-channel slice
-  const int b = blockIdx.y;
-  const int q0 = blockIdx.x * MT;
+  // XCD-aware order: workgroup ids go round-robin over the 8 XCDs (each with its own L2), so
+  // every XCD is given whole images -- neighbouring tiles, which share 4 halo rows, then hit the
+  // same L2 instead of each fetching the halo from HBM.  grid.y is padded to a multiple of 8.
+  const int L = blockIdx.y * gridDim.x + blockIdx.x, slot = L >> 3;
+  const int b = (slot / int(gridDim.x)) * 8 + (L & 7);
+  if (b >= a.B) return;
+  const int q0 = (slot % int(gridDim.x)) * MT;
   const int h_first = q0 / W;
   const int h_last = min(q0 + MT - 1, HW - 1) / W;
   const int NR = h_last - h_first + 5;
@@ -257,7 +262,7 @@ extern "C" int sept_conv5x5_forward(const void* x, const void* wt, const float* 
   SEPT_REQUIRE(B >= 0 && H > 0 && W > 0, SEPT_ERR_INVALID, "sept_conv5x5_forward: B=%d H=%d W=%d", B, H, W);
   if (B == 0) return SEPT_OK;
   SEPT_REQUIRE(x && wt && y, SEPT_ERR_INVALID, "sept_conv5x5_forward: null argument");
-  SEPT_REQUIRE(B <= 65535, SEPT_ERR_UNSUPPORTED, "sept_conv5x5_forward: B=%d exceeds grid.y", B);
+  SEPT_REQUIRE(B <= 65528, SEPT_ERR_UNSUPPORTED, "sept_conv5x5_forward: B=%d exceeds grid.y", B);
   const ConvVariant* best = nullptr;
   size_t best_smem = 0;
   int best_score = -1;
@@ -299,7 +304,7 @@ extern "C" int sept_conv5x5_forward(const void* x, const void* wt, const float* 
   const int mt = 32 * best->pb * best->wp;
   a.nr_max = conv_nr_max(mt, W);
   SEPT_HIP(sept::allow_max_lds(best->fn));
-  dim3 grid((H * W + mt - 1) / mt, B), block(64 * best->wp * best->wn);
+  dim3 grid((H * W + mt - 1) / mt, (B + 7) / 8 * 8), block(64 * best->wp * best->wn);
   void* args[] = {&a};
   SEPT_HIP(hipLaunchKernel(best->fn, grid, block, args, best_smem, static_cast<hipStream_t>(stream)));
   return SEPT_OK;

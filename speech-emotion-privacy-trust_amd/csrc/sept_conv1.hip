@@ -234,7 +234,8 @@ __global__ __launch_bounds__(256) void sept_conv1_wgrad_partial_kernel(C1Args a)
   float acc[4] = {0, 0, 0, 0}, accb = 0.f;
   const int tiles_per_img = (HW + kMT - 1) / kMT;
   const long n_tiles = long(a.B) * tiles_per_img;
-  for (long tile_id = blockIdx.x; tile_id < n_tiles; tile_id += gridDim.x) {
+  // contiguous tile range per workgroup (consecutive tiles share halo rows through this XCD's L2)
+  for (long tile_id = n_tiles * blockIdx.x / gridDim.x; tile_id < n_tiles * (blockIdx.x + 1) / gridDim.x; ++tile_id) {
     const int b = tile_id / tiles_per_img, q0 = int(tile_id % tiles_per_img) * kMT;
     const int h_first = q0 / W, h_last = min(q0 + kMT - 1, HW - 1) / W;
     const int npx = min(kMT, HW - q0);
@@ -408,7 +409,8 @@ __global__ __launch_bounds__(256) void sept_conv1_wgrad_mfma_kernel(const float*
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int tiles_per_img = (HW + kMT - 1) / kMT;
   const long n_tiles = long(B) * tiles_per_img;
-  for (long tile_id = blockIdx.x; tile_id < n_tiles; tile_id += gridDim.x) {
+  // contiguous tile range per workgroup (consecutive tiles share halo rows through this XCD's L2)
+  for (long tile_id = n_tiles * blockIdx.x / gridDim.x; tile_id < n_tiles * (blockIdx.x + 1) / gridDim.x; ++tile_id) {
     const int b = tile_id / tiles_per_img, q0 = int(tile_id % tiles_per_img) * kMT;
     const int h_first = q0 / W, h_last = min(q0 + kMT - 1, HW - 1) / W;
     __syncthreads();

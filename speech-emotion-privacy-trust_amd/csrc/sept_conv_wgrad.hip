@@ -138,16 +138,19 @@ __global__ __launch_bounds__(256) void sept_conv5x5_wgrad_kernel(WgArgs a) {
     }
   };
 
-  long tile_id = blockIdx.x;
-  if (tile_id < n_tiles) {
+  // each workgroup walks a CONTIGUOUS range of tiles: consecutive tiles share their halo rows, which
+  // then come from this XCD's L2 instead of HBM
+  long tile_id = n_tiles * blockIdx.x / gridDim.x;
+  const long tile_end = n_tiles * (blockIdx.x + 1) / gridDim.x;
+  if (tile_id < tile_end) {
     gload(tile_id);
     lstore(tile_id, smem);
   }
   __syncthreads();
   int cur = 0;
-  for (; tile_id < n_tiles; tile_id += gridDim.x, cur ^= 1) {
-    const long next = tile_id + gridDim.x;
-    if (next < n_tiles) gload(next);  // in flight under the MFMAs below
+  for (; tile_id < tile_end; ++tile_id, cur ^= 1) {
+    const long next = tile_id + 1;
+    if (next < tile_end) gload(next);  // in flight under the MFMAs below
     int b, q0, h_first, NR;
     tile_geom(tile_id, b, q0, h_first, NR);
     const unsigned char* xt = smem + size_t(cur) * bufbytes;
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(256) void sept_conv5x5_wgrad_kernel(WgArgs a) {
         }
       }
     }
-    if (next < n_tiles) lstore(next, smem + size_t(cur ^ 1) * bufbytes);
+    if (next < tile_end) lstore(next, smem + size_t(cur ^ 1) * bufbytes);
     __syncthreads();
   }
 
