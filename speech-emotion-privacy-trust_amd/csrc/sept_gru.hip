@@ -7,9 +7,10 @@
 // where gi = x W_ih^T + b_ih comes from sept_gemm (one product for both directions).
 //
 // The 25 steps are inherently serial and tiny (64x192 per sample), so this is latency work,
-// not MFMA work: one workgroup owns 4 samples x one direction for the whole sequence; each
-// lane owns one hidden unit of one sample and keeps its three W_hh rows (192 floats) in
-// VGPRs for all steps; h (forward) / dgh (backward) are exchanged through LDS broadcast reads.
+// not MFMA work: one workgroup owns 2 samples x one direction for the whole sequence; each PAIR
+// of lanes owns one hidden unit of one sample -- each lane keeps half of the three W_hh rows
+// (96 floats) in VGPRs for all steps and the pair combines its partial dot products with one
+// DPP add; h (forward) / dgh (backward) are exchanged through LDS broadcast reads.
 // One launch per layer covers both directions and all time steps.
 #include "sept_common.h"
 
@@ -33,103 +34,156 @@ struct GruArgs {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
-__global__ __launch_bounds__(kBS * kH) void sept_gru_fwd_kernel(GruArgs a) {
+// sum of a value over the two lanes of a pair (lane ^ 1), by DPP quad_perm [1,0,3,2]
+__device__ __forceinline__ float pair_sum(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+
+constexpr int kHH = kH / 2;  // each hidden unit is owned by a PAIR of lanes, each with half of the k range
+
+__global__ __launch_bounds__(kBS * kH * 2) void sept_gru_fwd_kernel(GruArgs a) {
   __shared__ __attribute__((aligned(16))) float hs[kBS][kH];
-  const int s = threadIdx.x / kH, j = threadIdx.x % kH;
-  const int dir = blockIdx.y, b = blockIdx.x * kBS + s;
-  const bool ok = b < a.B;
-  float wr[kH], wz[kH], wn[kH];
-  const float* w = a.whh[dir];
+  const int s = threadIdx.x / (2 * kH), j = (threadIdx.x >> 1) % kH, half = threadIdx.x & 1;
+  // a sample index past the batch is clamped (the surplus lanes recompute and rewrite the last
+  // sample's values): the loop body then has no divergent branches, which lets the compiler
+  // count outstanding memory operations exactly instead of draining the stores every step
+  const int dir = blockIdx.y, b = min(blockIdx.x * kBS + s, a.B - 1);
+  float wr[kHH], wz[kHH], wn[kHH];
+  const float* w = a.whh[dir] + half * kHH;
 #pragma unroll
-  for (int k = 0; k < kH; ++k) {
+  for (int k = 0; k < kHH; ++k) {
     wr[k] = w[(0 * kH + j) * kH + k];
     wz[k] = w[(1 * kH + j) * kH + k];
     wn[k] = w[(2 * kH + j) * kH + k];
   }
-  const float br = a.bhh[dir][j], bz = a.bhh[dir][kH + j], bn = a.bhh[dir][2 * kH + j];
+  // the bias rides in the first lane of the pair so that the pair sum carries it once
+  const float br = half ? 0.f : a.bhh[dir][j], bz = half ? 0.f : a.bhh[dir][kH + j], bn = half ? 0.f : a.bhh[dir][2 * kH + j];
   float h = 0.f;
-  hs[s][j] = 0.f;
-  __syncthreads();
+  if (!half) hs[s][j] = 0.f;
+  // the input-projection terms of the NEXT step are fetched while this step's FMAs run
+  auto gi_at = [&](int step, float& gr, float& gz, float& gn) {
+    const int st = min(step, a.T - 1);
+    const int t = dir == 0 ? st : a.T - 1 - st;
+    const float* g = a.gi + ((size_t(b) * a.T + t) * 2 + dir) * 3 * kH;
+    gr = g[j]; gz = g[kH + j]; gn = g[2 * kH + j];
+  };
+  auto store_step = [&](int t, float v0, float v1, float v2) {
+    // five values per hidden unit, three unconditional stores per lane (the pair shares them;
+    // the second lane writes its second value twice)
+    float* gs = a.gates + ((size_t(b) * a.T + t) * 2 + dir) * 4 * kH;
+    float* p0 = half ? gs + 2 * kH + j : a.out + (size_t(b) * a.T + t) * 2 * kH + dir * kH + j;
+    float* p1 = half ? gs + 3 * kH + j : gs + j;
+    float* p2 = half ? gs + 3 * kH + j : gs + kH + j;
+    *p0 = v0;
+    *p1 = v1;
+    *p2 = v2;
+  };
+  float gr, gz, gn;
+  gi_at(0, gr, gz, gn);
+  // Placeholder stores to the first step's slots (overwritten by that step): the loop is then
+  // entered with the same queue of outstanding memory operations (3 loads, 3 stores) that its
+  // back edge carries, so the wait for the prefetched loads never includes draining the stores.
+  store_step(dir == 0 ? 0 : a.T - 1, 0.f, 0.f, 0.f);
+  sept::lds_barrier();
   for (int step = 0; step < a.T; ++step) {
     const int t = dir == 0 ? step : a.T - 1 - step;
+    float ngr, ngz, ngn;
+    gi_at(step + 1, ngr, ngz, ngn);
     float ar = br, az = bz, an = bn;
 #pragma unroll
-    for (int k = 0; k < kH; k += 4) {
-      const float4 hv = *reinterpret_cast<const float4*>(&hs[s][k]);
+    for (int k = 0; k < kHH; k += 4) {
+      const float4 hv = *reinterpret_cast<const float4*>(&hs[s][half * kHH + k]);
       ar = fmaf(wr[k], hv.x, ar); ar = fmaf(wr[k + 1], hv.y, ar); ar = fmaf(wr[k + 2], hv.z, ar); ar = fmaf(wr[k + 3], hv.w, ar);
       az = fmaf(wz[k], hv.x, az); az = fmaf(wz[k + 1], hv.y, az); az = fmaf(wz[k + 2], hv.z, az); az = fmaf(wz[k + 3], hv.w, az);
       an = fmaf(wn[k], hv.x, an); an = fmaf(wn[k + 1], hv.y, an); an = fmaf(wn[k + 2], hv.z, an); an = fmaf(wn[k + 3], hv.w, an);
     }
-    float gr = 0.f, gz = 0.f, gn = 0.f;
-    if (ok) {
-      const float* g = a.gi + ((size_t(b) * a.T + t) * 2 + dir) * 3 * kH;
-      gr = g[j]; gz = g[kH + j]; gn = g[2 * kH + j];
-    }
+    ar = pair_sum(ar); az = pair_sum(az); an = pair_sum(an);   // both lanes of the pair now hold the full sums
     const float r = sigmoidf_(gr + ar), z = sigmoidf_(gz + az);
     const float n = tanhf(gn + r * an);
     h = (1.f - z) * n + z * h;
-    __syncthreads();
-    hs[s][j] = h;
-    __syncthreads();
-    if (ok) {
-      a.out[(size_t(b) * a.T + t) * 2 * kH + dir * kH + j] = h;
-      float* gs = a.gates + ((size_t(b) * a.T + t) * 2 + dir) * 4 * kH;
-      gs[j] = r; gs[kH + j] = z; gs[2 * kH + j] = n; gs[3 * kH + j] = an;
-    }
+    sept::lds_barrier();   // LDS-only wait: global prefetches / stores stay in flight across the barrier
+    hs[s][j] = h;          // both lanes of the pair write the same value
+    sept::lds_barrier();
+    store_step(t, half ? n : h, half ? an : r, half ? an : z);
+    gr = ngr; gz = ngz; gn = ngn;
   }
 }
 
-__global__ __launch_bounds__(kBS * kH) void sept_gru_bwd_kernel(GruArgs a) {
+__global__ __launch_bounds__(kBS * kH * 2) void sept_gru_bwd_kernel(GruArgs a) {
   __shared__ __attribute__((aligned(16))) float ds[kBS][3 * kH];
-  const int s = threadIdx.x / kH, j = threadIdx.x % kH;
-  const int dir = blockIdx.y, b = blockIdx.x * kBS + s;
-  const bool ok = b < a.B;
-  // column j of W_hr, W_hz, W_hn: dh_prev[j] = sum_i W[i][j] * dgh[i]
-  float wr[kH], wz[kH], wn[kH];
+  const int s = threadIdx.x / (2 * kH), j = (threadIdx.x >> 1) % kH, half = threadIdx.x & 1;
+  const int dir = blockIdx.y, b = min(blockIdx.x * kBS + s, a.B - 1);   // clamped, see the forward kernel
+  // column j of W_hr, W_hz, W_hn: dh_prev[j] = sum_i W[i][j] * dgh[i]; each lane of the pair owns
+  // half of the i range
+  float wr[kHH], wz[kHH], wn[kHH];
   const float* w = a.whh[dir];
 #pragma unroll
-  for (int i = 0; i < kH; ++i) {
-    wr[i] = w[(0 * kH + i) * kH + j];
-    wz[i] = w[(1 * kH + i) * kH + j];
-    wn[i] = w[(2 * kH + i) * kH + j];
+  for (int i = 0; i < kHH; ++i) {
+    wr[i] = w[(0 * kH + half * kHH + i) * kH + j];
+    wz[i] = w[(1 * kH + half * kHH + i) * kH + j];
+    wn[i] = w[(2 * kH + half * kHH + i) * kH + j];
   }
   float dh = 0.f;
+  // per-step operands (gates, previous hidden state, incoming gradient) of the NEXT step are
+  // fetched while this step's FMAs run
+  struct StepIn { float r, z, n, hn, hp, dout; };
+  auto fetch = [&](int step) {
+    StepIn v;
+    const int st = max(step, 0);
+    const int t = dir == 0 ? st : a.T - 1 - st;
+    const int tp = dir == 0 ? t - 1 : t + 1;  // time index of the previous hidden state
+    const size_t bt = size_t(b) * a.T + t;
+    const float* gs = a.gates + (bt * 2 + dir) * 4 * kH;
+    v.r = gs[j]; v.z = gs[kH + j]; v.n = gs[2 * kH + j]; v.hn = gs[3 * kH + j];
+    const float hp = a.out[(size_t(b) * a.T + min(max(tp, 0), a.T - 1)) * 2 * kH + dir * kH + j];
+    v.hp = (tp >= 0 && tp < a.T) ? hp : 0.f;
+    v.dout = a.dout[bt * 2 * kH + dir * kH + j];
+    return v;
+  };
+  auto store_step = [&](int t, float v0, float v1, float v2, float v3) {
+    // seven values per hidden unit, four unconditional stores per lane (dr_pre goes out twice)
+    const size_t bt = size_t(b) * a.T + t;
+    float* o = a.dgi + (bt * 2 + dir) * 3 * kH;
+    float* o2 = a.dgh + (bt * 2 + dir) * 3 * kH;
+    float* p0 = half ? o2 + j : o + j;
+    float* p1 = half ? o2 + kH + j : o + kH + j;
+    float* p2 = half ? o2 + 2 * kH + j : o + 2 * kH + j;
+    float* p3 = half ? a.hprev + (bt * 2 + dir) * kH + j : o + j;
+    *p0 = v0;
+    *p1 = v1;
+    *p2 = v2;
+    *p3 = v3;
+  };
+  StepIn cur = fetch(a.T - 1);
+  // placeholder stores to the first processed step's slots (see the forward kernel)
+  store_step(dir == 0 ? a.T - 1 : 0, 0.f, 0.f, 0.f, 0.f);
   for (int step = a.T - 1; step >= 0; --step) {
     const int t = dir == 0 ? step : a.T - 1 - step;
-    const int tp = dir == 0 ? t - 1 : t + 1;  // time index of the previous hidden state
-    float dr_pre = 0.f, dz_pre = 0.f, dn_pre = 0.f, dhn = 0.f, carry = 0.f;
-    if (ok) {
-      const size_t bt = size_t(b) * a.T + t;
-      const float* gs = a.gates + (bt * 2 + dir) * 4 * kH;
-      const float r = gs[j], z = gs[kH + j], n = gs[2 * kH + j], hn = gs[3 * kH + j];
-      const float hp = (tp >= 0 && tp < a.T) ? a.out[(size_t(b) * a.T + tp) * 2 * kH + dir * kH + j] : 0.f;
-      const float dht = a.dout[bt * 2 * kH + dir * kH + j] + dh;
-      const float dn = dht * (1.f - z), dz = dht * (hp - n);
-      carry = dht * z;
-      dn_pre = dn * (1.f - n * n);
-      dhn = dn_pre * r;
-      dr_pre = dn_pre * hn * r * (1.f - r);
-      dz_pre = dz * z * (1.f - z);
-      float* o = a.dgi + (bt * 2 + dir) * 3 * kH;
-      o[j] = dr_pre; o[kH + j] = dz_pre; o[2 * kH + j] = dn_pre;
-      float* o2 = a.dgh + (bt * 2 + dir) * 3 * kH;
-      o2[j] = dr_pre; o2[kH + j] = dz_pre; o2[2 * kH + j] = dhn;
-      a.hprev[(bt * 2 + dir) * kH + j] = hp;
-    }
-    __syncthreads();
-    ds[s][j] = dr_pre; ds[s][kH + j] = dz_pre; ds[s][2 * kH + j] = dhn;
-    __syncthreads();
-    float acc = carry;
+    const StepIn nxt = fetch(step - 1);
+    const float r = cur.r, z = cur.z, n = cur.n, hn = cur.hn, hp = cur.hp;
+    const float dht = cur.dout + dh;
+    const float dn = dht * (1.f - z), dz = dht * (hp - n);
+    const float carry = dht * z;
+    const float dn_pre = dn * (1.f - n * n);
+    const float dhn = dn_pre * r;
+    const float dr_pre = dn_pre * hn * r * (1.f - r);
+    const float dz_pre = dz * z * (1.f - z);
+    store_step(t, dr_pre, dz_pre, half ? dhn : dn_pre, half ? hp : dr_pre);
+    sept::lds_barrier();   // LDS-only wait: global prefetches / stores stay in flight across the barrier
+    ds[s][j] = dr_pre; ds[s][kH + j] = dz_pre; ds[s][2 * kH + j] = dhn;   // same values from both lanes
+    sept::lds_barrier();
+    float acc = half ? 0.f : carry;
 #pragma unroll
-    for (int i = 0; i < kH; i += 4) {
-      const float4 vr = *reinterpret_cast<const float4*>(&ds[s][i]);
-      const float4 vz = *reinterpret_cast<const float4*>(&ds[s][kH + i]);
-      const float4 vn = *reinterpret_cast<const float4*>(&ds[s][2 * kH + i]);
+    for (int i = 0; i < kHH; i += 4) {
+      const float4 vr = *reinterpret_cast<const float4*>(&ds[s][half * kHH + i]);
+      const float4 vz = *reinterpret_cast<const float4*>(&ds[s][kH + half * kHH + i]);
+      const float4 vn = *reinterpret_cast<const float4*>(&ds[s][2 * kH + half * kHH + i]);
       acc = fmaf(wr[i], vr.x, acc); acc = fmaf(wr[i + 1], vr.y, acc); acc = fmaf(wr[i + 2], vr.z, acc); acc = fmaf(wr[i + 3], vr.w, acc);
       acc = fmaf(wz[i], vz.x, acc); acc = fmaf(wz[i + 1], vz.y, acc); acc = fmaf(wz[i + 2], vz.z, acc); acc = fmaf(wz[i + 3], vz.w, acc);
       acc = fmaf(wn[i], vn.x, acc); acc = fmaf(wn[i + 1], vn.y, acc); acc = fmaf(wn[i + 2], vn.z, acc); acc = fmaf(wn[i + 3], vn.w, acc);
     }
-    dh = acc;
+    dh = pair_sum(acc);
+    cur = nxt;
   }
 }
 
@@ -145,7 +199,7 @@ extern "C" int sept_gru_forward(const float* gi, const float* whh_fwd, const flo
   GruArgs a{};
   a.gi = gi; a.whh[0] = whh_fwd; a.whh[1] = whh_rev; a.bhh[0] = bhh_fwd; a.bhh[1] = bhh_rev;
   a.out = out; a.gates = gates; a.B = B; a.T = T;
-  hipLaunchKernelGGL(sept_gru_fwd_kernel, dim3((B + kBS - 1) / kBS, 2), dim3(kBS * kH), 0,
+  hipLaunchKernelGGL(sept_gru_fwd_kernel, dim3((B + kBS - 1) / kBS, 2), dim3(kBS * kH * 2), 0,
                      static_cast<hipStream_t>(stream), a);
   return sept::launch_check("sept_gru_fwd_kernel");
 }
@@ -162,7 +216,7 @@ extern "C" int sept_gru_backward(const float* dout, const float* out, const floa
   a.dout = dout; a.out = const_cast<float*>(out); a.gates = const_cast<float*>(gates);
   a.whh[0] = whh_fwd; a.whh[1] = whh_rev;
   a.dgi = dgi; a.dgh = dgh; a.hprev = hprev; a.B = B; a.T = T;
-  hipLaunchKernelGGL(sept_gru_bwd_kernel, dim3((B + kBS - 1) / kBS, 2), dim3(kBS * kH), 0,
+  hipLaunchKernelGGL(sept_gru_bwd_kernel, dim3((B + kBS - 1) / kBS, 2), dim3(kBS * kH * 2), 0,
                      static_cast<hipStream_t>(stream), a);
   return sept::launch_check("sept_gru_bwd_kernel");
 }

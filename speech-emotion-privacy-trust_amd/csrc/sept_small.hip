@@ -52,24 +52,41 @@ __global__ void cloak_scale_mean_kernel(const float* rhos, float smin, float sma
 //            - scale_lambda * dscale/drho / (n * mean(scales))      [d/drho of -lambda*log(mean(scales))]
 // with g = dxa + gscale_b * dxb (dxb optional): the two branches' input gradients, the second
 // one through the gradient-reversal layer (gscale_b = -grl_lambda).
-__global__ void cloak_bwd_kernel(const float* dxa, const float* dxb, float gscale_b, const float* rhos,
-                                 const float* eps, const float* mask, float smin, float smax, float scale_lambda,
-                                 const float* scale_mean, int B, long n_per, float* dlocs, float* drhos) {
-  GRID_STRIDE(k, n_per) {
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) {
-      float g = dxa[size_t(b) * n_per + k];
-      if (dxb) g = fmaf(gscale_b, dxb[size_t(b) * n_per + k], g);
-      s += g;
-    }
-    const float th = tanhf(rhos[k]);
-    const float dsc = (1.0f - th * th) * 0.5f * (smax - smin);
-    const float m = mask ? mask[k] : 1.0f;
-    float dr = s * eps[k] * m * dsc;
-    if (scale_lambda != 0.f) dr -= scale_lambda * dsc / (float(n_per) * *scale_mean);
-    if (dlocs) dlocs[k] = s;
-    if (drhos) drhos[k] = dr;
+// One workgroup per 64 elements k; wave j sums the batch items j, j+4, ... (four loads in flight)
+// and the four wave sums are combined in wave order through LDS: deterministic.
+__global__ __launch_bounds__(256) void cloak_bwd_kernel(const float* dxa, const float* dxb, float gscale_b,
+                                                        const float* rhos, const float* eps, const float* mask,
+                                                        float smin, float smax, float scale_lambda,
+                                                        const float* scale_mean, int B, long n_per, float* dlocs,
+                                                        float* drhos) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long k = long(blockIdx.x) * 64 + lane;
+  const long kc = min(k, n_per - 1);
+  auto item = [&](int b) {
+    float g = dxa[size_t(b) * n_per + kc];
+    if (dxb) g = fmaf(gscale_b, dxb[size_t(b) * n_per + kc], g);
+    return g;
+  };
+  float s0 = 0.f, s1 = 0.f;
+  int b = wave;
+  for (; b + 12 < B; b += 16) {
+    const float g0 = item(b), g1 = item(b + 4), g2 = item(b + 8), g3 = item(b + 12);
+    s0 += g0 + g1;
+    s1 += g2 + g3;
   }
+  for (; b < B; b += 4) s0 += item(b);
+  part[wave][lane] = s0 + s1;
+  __syncthreads();
+  if (wave != 0 || k >= n_per) return;
+  const float s = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+  const float th = tanhf(rhos[k]);
+  const float dsc = (1.0f - th * th) * 0.5f * (smax - smin);
+  const float m = mask ? mask[k] : 1.0f;
+  float dr = s * eps[k] * m * dsc;
+  if (scale_lambda != 0.f) dr -= scale_lambda * dsc / (float(n_per) * *scale_mean);
+  if (dlocs) dlocs[k] = s;
+  if (drhos) drhos[k] = dr;
 }
 
 // ---------------- generic elementwise ----------------
@@ -465,7 +482,7 @@ extern "C" int sept_cloak_backward(const float* dxa, const float* dxb, float gsc
                                    long n_per, void* stream) {
   SEPT_REQUIRE(dxa && rhos && eps && B > 0 && n_per > 0, SEPT_ERR_INVALID, "sept_cloak_backward: bad argument");
   SEPT_REQUIRE(scale_lambda == 0.f || scale_mean, SEPT_ERR_INVALID, "sept_cloak_backward: scale_mean required");
-  hipLaunchKernelGGL(cloak_bwd_kernel, dim3(blocks_for(n_per)), dim3(kThreads), 0, ST(stream), dxa, dxb, gscale_b,
+  hipLaunchKernelGGL(cloak_bwd_kernel, dim3(int((n_per + 63) / 64)), dim3(256), 0, ST(stream), dxa, dxb, gscale_b,
                      rhos, eps, mask, min_scale, max_scale, scale_lambda, scale_mean, B, n_per, dlocs, drhos);
   return sept::launch_check("cloak_bwd_kernel");
 }
