@@ -247,6 +247,18 @@ int sept_dropout_mask(float* out, long n, float p, unsigned long long seed, cons
 int sept_normal(float* out, long n, float mean, float stdv, unsigned long long seed, const long long* offset_dev,
                 unsigned long long offset, void* stream);
 int sept_counter_add(long long* counter, long long inc, void* stream);
+/* Multi-head self-attention pooling of two_d_cnn_lstm with att='self_att' (baseline_models.py:233-242,
+ * cloak_models.py:178-186): scores (B, T, NH) = att_linear2(tanh(att_linear1(x))) come from sept_gemm +
+ * sept_tanh_forward; sept_att_pool_forward takes the softmax over T per head (probs, kept for the backward
+ * pass) and z[b] = mean_h sum_t probs[b][t][h] x[b][t][:];  the backward entry returns the direct term of
+ * dx and dscores.  T <= 1024. */
+int sept_tanh_forward(const float* x, float* y, long n, void* stream);
+int sept_tanh_backward(const float* dy, const float* y, float* dx, long n, void* stream);
+int sept_att_pool_forward(const float* scores, const float* x, float* probs, float* z, int B, int T, int NH,
+                          int D, void* stream);
+int sept_att_pool_backward(const float* dz, const float* x, const float* probs, float* dx, float* dscores,
+                           int B, int T, int NH, int D, void* stream);
+
 /* MFCC pieces (audio_feature_extraction.py:15-26: torchaudio MFCC(16000, n_mfcc=40) on the audio and
  * on numpy.gradient(audio) with spacing 1 and 2): the mel front end is sept_mel_forward with
  * (n_fft 400, hop 200, 128 mels); sept_topdb_clamp applies AmplitudeToDB's top_db = 80 per clip

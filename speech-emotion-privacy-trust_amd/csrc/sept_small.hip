@@ -421,6 +421,73 @@ __global__ void transpose_last2_kernel(const float* in, float* out, int B, int R
   }
 }
 
+// ---------------- multi-head self-attention pooling (baseline_models.py:233-242) ----------------
+// scores (B, T, NH) = att_linear2(tanh(att_linear1(x)));  P = softmax over T per head;
+// z[b] = mean_h sum_t P[b][t][h] x[b][t][:]  = sum_t wbar[b][t] x[b][t][:].   One workgroup per sample.
+__global__ void tanh_fwd_kernel(const float* x, float* y, long n) { GRID_STRIDE(i, n) y[i] = tanhf(x[i]); }
+__global__ void tanh_bwd_kernel(const float* dy, const float* y, float* dx, long n) {
+  GRID_STRIDE(i, n) dx[i] = dy[i] * (1.0f - y[i] * y[i]);
+}
+
+constexpr int kAttMaxT = 1024;
+__global__ __launch_bounds__(256) void att_pool_fwd_kernel(const float* scores, const float* x, float* P, float* z, int T,
+                                                           int NH, int D) {
+  __shared__ float wbar[kAttMaxT];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* sb = scores + size_t(b) * T * NH;
+  float* Pb = P + size_t(b) * T * NH;
+  for (int h = tid; h < NH; h += blockDim.x) {   // one lane per head: T is small (25 on the path)
+    float m = -INFINITY;
+    for (int t = 0; t < T; ++t) m = fmaxf(m, sb[t * NH + h]);
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += __expf(sb[t * NH + h] - m);
+    const float inv = 1.0f / s;
+    for (int t = 0; t < T; ++t) Pb[t * NH + h] = __expf(sb[t * NH + h] - m) * inv;
+  }
+  __syncthreads();
+  for (int t = tid; t < T; t += blockDim.x) {
+    float s = 0.f;
+    for (int h = 0; h < NH; ++h) s += Pb[t * NH + h];
+    wbar[t] = s / float(NH);
+  }
+  __syncthreads();
+  const float* xb = x + size_t(b) * T * D;
+  for (int d = tid; d < D; d += blockDim.x) {
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s = fmaf(wbar[t], xb[size_t(t) * D + d], s);
+    z[size_t(b) * D + d] = s;
+  }
+}
+
+// dx[b][t][:] = wbar[b][t] dz[b][:];  g[b][t] = dz[b] . x[b][t] / NH;
+// dS[b][t][h] = P[b][t][h] (g[b][t] - sum_t' P[b][t'][h] g[b][t'])
+__global__ __launch_bounds__(256) void att_pool_bwd_kernel(const float* dz, const float* x, const float* P, float* dx,
+                                                           float* dS, int T, int NH, int D) {
+  __shared__ float wbar[kAttMaxT], g[kAttMaxT];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* Pb = P + size_t(b) * T * NH;
+  const float* xb = x + size_t(b) * T * D;
+  const float* dzb = dz + size_t(b) * D;
+  for (int t = wave; t < T; t += 4) {   // one wave per time step: dot over D, fixed lane order
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) s = fmaf(dzb[d], xb[size_t(t) * D + d], s);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    float w = 0.f;
+    for (int h = 0; h < NH; ++h) w += Pb[t * NH + h];
+    if (lane == 0) {
+      g[t] = s / float(NH);
+      wbar[t] = w / float(NH);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < T * D; i += blockDim.x) dx[size_t(b) * T * D + i] = wbar[i / D] * dzb[i % D];
+  for (int h = tid; h < NH; h += blockDim.x) {
+    float c = 0.f;
+    for (int t = 0; t < T; ++t) c = fmaf(Pb[t * NH + h], g[t], c);
+    for (int t = 0; t < T; ++t) dS[(size_t(b) * T + t) * NH + h] = Pb[t * NH + h] * (g[t] - c);
+  }
+}
+
 // ---------------- optimisers (training_cloak_with_grl.py:416-421) ----------------
 // torch.optim.SGD(momentum, weight_decay, dampening 0, nesterov False)
 __global__ void sgd_kernel(float* p, const float* g, float* buf, long n, float lr, float momentum, float wd,
@@ -671,6 +738,38 @@ extern "C" int sept_transpose_last2(const float* in, float* out, int B, int R, i
   SEPT_REQUIRE(in && out && B > 0 && R > 0 && C > 0, SEPT_ERR_INVALID, "sept_transpose_last2: bad argument");
   hipLaunchKernelGGL(transpose_last2_kernel, dim3(blocks_for(long(B) * R * C)), dim3(kThreads), 0, ST(stream), in, out, B, R, C);
   return sept::launch_check("transpose_last2_kernel");
+}
+
+extern "C" int sept_tanh_forward(const float* x, float* y, long n, void* stream) {
+  if (n == 0) return SEPT_OK;
+  SEPT_REQUIRE(x && y && n > 0, SEPT_ERR_INVALID, "sept_tanh_forward: bad argument");
+  hipLaunchKernelGGL(tanh_fwd_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, ST(stream), x, y, n);
+  return sept::launch_check("tanh_fwd_kernel");
+}
+
+extern "C" int sept_tanh_backward(const float* dy, const float* y, float* dx, long n, void* stream) {
+  if (n == 0) return SEPT_OK;
+  SEPT_REQUIRE(dy && y && dx && n > 0, SEPT_ERR_INVALID, "sept_tanh_backward: bad argument");
+  hipLaunchKernelGGL(tanh_bwd_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, ST(stream), dy, y, dx, n);
+  return sept::launch_check("tanh_bwd_kernel");
+}
+
+extern "C" int sept_att_pool_forward(const float* scores, const float* x, float* probs, float* z, int B, int T, int NH,
+                                     int D, void* stream) {
+  if (B == 0) return SEPT_OK;
+  SEPT_REQUIRE(scores && x && probs && z && B > 0 && T > 0 && T <= kAttMaxT && NH > 0 && D > 0, SEPT_ERR_INVALID,
+               "sept_att_pool_forward: B=%d T=%d NH=%d D=%d (T <= %d)", B, T, NH, D, kAttMaxT);
+  hipLaunchKernelGGL(att_pool_fwd_kernel, dim3(B), dim3(256), 0, ST(stream), scores, x, probs, z, T, NH, D);
+  return sept::launch_check("att_pool_fwd_kernel");
+}
+
+extern "C" int sept_att_pool_backward(const float* dz, const float* x, const float* probs, float* dx, float* dscores,
+                                      int B, int T, int NH, int D, void* stream) {
+  if (B == 0) return SEPT_OK;
+  SEPT_REQUIRE(dz && x && probs && dx && dscores && B > 0 && T > 0 && T <= kAttMaxT && NH > 0 && D > 0,
+               SEPT_ERR_INVALID, "sept_att_pool_backward: B=%d T=%d NH=%d D=%d (T <= %d)", B, T, NH, D, kAttMaxT);
+  hipLaunchKernelGGL(att_pool_bwd_kernel, dim3(B), dim3(256), 0, ST(stream), dz, x, probs, dx, dscores, T, NH, D);
+  return sept::launch_check("att_pool_bwd_kernel");
 }
 
 extern "C" int sept_sgd_step(float* p, const float* g, float* momentum_buf, long n, float lr, float momentum,

@@ -7,7 +7,7 @@ kernels of libsept_hip (NHWC bf16 MFMA convs, fused BatchNorm/ReLU/pool/dropout,
 The torch sub-modules held here (`conv`, `rnn`, `dense1`, ...) are parameter containers:
 their own forward is never called and there is no eager/CPU fallback.
 
-Scope: att=None, rnn_cell='gru', hidden 64, global_feature concat
+Scope: att None / 'self_att', rnn_cell='gru', hidden 64, global_feature concat
 not supported on the HIP path.
 """
 try:
@@ -92,22 +92,25 @@ class _TwoD(nn.Module):
         # carry.  Kept as a no-op for the same effect.
         return None
 
-    def hip_logits(self, x, head, pooling, injected=None):
-        """Run the HIP trunk on x (B, 1, T, F) / (B, T, F) and apply `head`'s prediction layer."""
+    def hip_logits(self, x, head, pooling, injected=None, global_feature=None, att="model"):
+        """Run the HIP trunk on x (B, 1, T, F) / (B, T, F) and apply `head`'s prediction layer
+        ('multitask': both, side by side as (B, 4 + 2))."""
         x = x.float()
         if x.dim() == 4:
             if x.shape[1] != 1:
                 raise ValueError("the conv stack takes one input channel")
             x = x[:, 0]
-        return SF.run_trunk(self, x, head, pooling, injected)
+        return SF.run_trunk(self, x, head, pooling, injected, gfeat=global_feature, att=att)
 
     def forward(self, input_var, global_feature=None):
-        if global_feature is not None:
-            raise NotImplementedError("global_feature concat (openSMILE functionals) is outside the HIP path")
+        # reference :222-260 (deep variant :347-385): mean over time (flatten for the deep model) or
+        # 'self_att' pooling, optional concat of the utterance-level functionals, dense1, head(s)
         pooling = "flatten" if self._deep else "mean"
         if self.pred == 'multitask':
-            raise NotImplementedError("pred='multitask' is not used by any trainer and is not on the HIP path")
-        return self.hip_logits(input_var, 'emotion' if self.pred == 'emotion' else 'gender', pooling)
+            both = self.hip_logits(input_var, 'multitask', pooling, global_feature=global_feature)
+            return both[:, :self.num_emo_classes], both[:, self.num_emo_classes:]
+        return self.hip_logits(input_var, 'emotion' if self.pred == 'emotion' else 'gender', pooling,
+                               global_feature=global_feature)
 
 
 class two_d_cnn_lstm(_TwoD):

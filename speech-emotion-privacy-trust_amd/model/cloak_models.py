@@ -81,15 +81,15 @@ class two_d_cnn_lstm_syn(nn.Module):
         _freeze(self.original_model)
 
     def forward(self, input_var, global_feature=None, mask=None, pooling=None):
-        if global_feature is not None:
-            raise NotImplementedError("global_feature concat is outside the HIP path")
         x = input_var.float()
         x = self.intermed(x) if mask is None else self.intermed(x, mask)
         noisy = x.detach()
         m = self.original_model
-        if m.pred == 'multitask':
-            raise NotImplementedError("pred='multitask' is not on the HIP path")
-        preds = m.hip_logits(x, 'emotion' if m.pred == 'emotion' else 'gender', _pool_arg(pooling))
+        if m.pred == 'multitask':   # reference :122-125
+            both = m.hip_logits(x, 'multitask', _pool_arg(pooling), global_feature=global_feature)
+            return (both[:, :m.num_emo_classes], both[:, m.num_emo_classes:]), noisy
+        preds = m.hip_logits(x, 'emotion' if m.pred == 'emotion' else 'gender', _pool_arg(pooling),
+                             global_feature=global_feature)
         return preds, noisy
 
 
@@ -104,14 +104,13 @@ class two_d_cnn_lstm_syn_with_grl(nn.Module):
         self.gender_model.conv = nn.Sequential(GradientReversal(grl_lambda), gender_model.conv)
 
     def forward(self, input_var, global_feature=None, mask=None, grl=False, pooling=None):
-        if global_feature is not None:
-            raise NotImplementedError("global_feature concat is outside the HIP path")
         x = input_var.float()
         x = self.intermed(x) if mask is None else self.intermed(x, mask)
         noisy = x.detach()
         pool = _pool_arg(pooling)
-        preds1 = self.original_model.hip_logits(x, 'emotion', pool)
+        att = self.original_model.att   # the reference keys BOTH branches on the emotion model's flag (:171, :208)
+        preds1 = self.original_model.hip_logits(x, 'emotion', pool, global_feature=global_feature, att=att)
         # gender branch: the GradientReversal module sits in front of its conv stack
         xr = self.gender_model.conv[0](x)
-        preds2 = self.gender_model.hip_logits(xr, 'gender', pool)
+        preds2 = self.gender_model.hip_logits(xr, 'gender', pool, global_feature=global_feature, att=att)
         return preds1, preds2, noisy

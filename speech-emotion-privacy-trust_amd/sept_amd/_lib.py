@@ -85,6 +85,11 @@ SIGNATURES = {
     "sept_dropout_mask": (c_int, [c_void_p, c_long, c_float, c_ulonglong, c_void_p, c_ulonglong, c_void_p]),
     "sept_normal": (c_int, [c_void_p, c_long, c_float, c_float, c_ulonglong, c_void_p, c_ulonglong, c_void_p]),
     "sept_counter_add": (c_int, [c_void_p, c_long, c_void_p]),
+    "sept_tanh_forward": (c_int, [c_void_p, c_void_p, c_long, c_void_p]),
+    "sept_tanh_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
+    "sept_att_pool_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "sept_att_pool_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                       c_void_p]),
     "sept_gru_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                               c_void_p, c_void_p]),
     "sept_topdb_clamp": (c_int, [c_void_p, c_int, c_long, c_float, c_void_p]),

@@ -75,9 +75,11 @@ def _nt_ok(K):
 # ---------------------------------------------------------------------------------------------
 # parameter view of a two_d_cnn_lstm / deep_two_d_cnn_lstm module
 # ---------------------------------------------------------------------------------------------
-def trunk_params(model, head: str):
+def trunk_params(model, head: str, att="model"):
     """Collect the tensors the HIP trunk reads from a (reference-layout) module.  `head` is
-    'emotion' or 'gender' (which prediction layer the caller applies)."""
+    'emotion', 'gender' or 'multitask' (which prediction layer(s) the caller applies); `att` is the
+    attention mode ('model' = the module's own `att`; the cloak wrappers pass the emotion model's
+    setting for both branches, as cloak_models.py:171/208 do)."""
     conv = model.conv
     if len(conv) == 2 and not isinstance(conv[0], torch.nn.Conv2d):  # Sequential(GradientReversal, conv)
         conv = conv[1]
@@ -100,11 +102,14 @@ def trunk_params(model, head: str):
         raise NotImplementedError("only rnn_cell='gru' is implemented on the HIP path")
     if rnn.hidden_size != 64 or rnn.num_layers != 2 or not rnn.bidirectional:
         raise NotImplementedError("HIP GRU supports hidden 64, 2 layers, bidirectional (the trainer's config)")
-    if model.att is not None:
-        raise NotImplementedError("att='self_att' is outside the HIP path (SURVEY.md section 8f)")
+    att = model.att if att == "model" else att
+    if att not in (None, "self_att"):
+        raise ValueError(f"unknown attention mode {att!r}")
+    heads = {"emotion": [model.pred_emotion_layer], "gender": [model.pred_gender_layer],
+             "multitask": [model.pred_emotion_layer, model.pred_gender_layer]}[head]
     return SimpleNamespace(convs=convs, bns=bns, pools=pools, drop_ps=drop_ps, dense_p=model.dropout.p, rnn=rnn,
-                           dense1=model.dense1,
-                           head=model.pred_emotion_layer if head == "emotion" else model.pred_gender_layer,
+                           dense1=model.dense1, heads=heads, att=att,
+                           att1=model.att_linear1 if att else None, att2=model.att_linear2 if att else None,
                            training=model.training)
 
 
@@ -131,7 +136,7 @@ def _drop_masks(device, specs):
     return out
 
 
-def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None):
+def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None, gfeat=None):
     """x (B, H, W) fp32 CUDA -> logits (B, C).  Returns (logits, saved) where `saved` holds
     what trunk_backward needs.  BatchNorm uses batch statistics (and updates the running
     buffers) when the module is in train mode -- also for a frozen model (SURVEY.md F8);
@@ -207,14 +212,33 @@ def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None):
             layer_in = nxt
         S.gru.append(G)
     out1 = S.gru[1].out
-    z = ops.mean_t_forward(out1) if pooling == "mean" else out1.view(B, T * 128)
+    S.att = None
+    if P.att == "self_att":   # baseline_models.py:233-242: 16-head additive attention over time
+        x2 = out1.view(B * T, 128)
+        a1t = ops.tanh_forward(ops.linear_forward(x2, P.att1.weight, P.att1.bias))
+        scores = ops.linear_forward(a1t, P.att2.weight, P.att2.bias)
+        z, probs = ops.att_pool_forward(scores.view(B, T, -1), out1)
+        S.att = SimpleNamespace(a1t=a1t, probs=probs)
+    else:
+        z = ops.mean_t_forward(out1) if pooling == "mean" else out1.view(B, T * 128)
+    S.zdim = z.shape[1]
+    if gfeat is not None:     # :244-245: utterance-level functionals appended to the pooled vector
+        z = torch.cat((z, gfeat.detach().to(z.dtype).view(B, -1)), 1)
+    if z.shape[1] != P.dense1.weight.shape[1]:
+        raise SeptError(f"dense1 expects {P.dense1.weight.shape[1]} features, the pooled vector has {z.shape[1]} "
+                        "(global_feature given / constructor's global_feature flag / pooling mismatch)")
     d1 = ops.linear_forward(z, P.dense1.weight, P.dense1.bias)
     dmask = None
     if train and (P.dense_p > 0 or "dense" in inj):
         m = inj.get("dense")
         dmask = m if m is not None else masks["dense"]
     d1a = ops.relu_dropout_forward(d1, dmask)
-    logits = ops.linear_forward(d1a, P.head.weight, P.head.bias)
+    ncls = [h.weight.shape[0] for h in P.heads]
+    logits = torch.empty((B, sum(ncls)), dtype=torch.float32, device=dev)   # heads side by side
+    c0 = 0
+    for h, n in zip(P.heads, ncls):
+        ops.linear_forward(d1a, h.weight, h.bias, out=logits[:, c0:c0 + n])
+        c0 += n
     S.z, S.d1, S.dmask, S.d1a = z, d1, dmask, d1a
     return logits, (S if need_grad else None)
 
@@ -230,16 +254,43 @@ def trunk_backward(S, P, dlogits, need_wgrad=True, need_dx=True):
             grads[param] = g
 
     dlogits = dlogits.contiguous()
-    d_d1a = ops.linear_backward_input(dlogits, P.head.weight)
-    if need_wgrad:
-        put(P.head.weight, ops.linear_backward_weight(dlogits, S.d1a))
-        put(P.head.bias, ops.colsum(dlogits))
+    d_d1a, c0 = None, 0
+    for h in P.heads:
+        n = h.weight.shape[0]
+        dl = dlogits[:, c0:c0 + n]
+        c0 += n
+        if d_d1a is None:
+            d_d1a = ops.linear_backward_input(dl, h.weight)
+        else:   # second head of pred='multitask': accumulate
+            ops.gemm_raw(dl, dl.stride(0), 1, h.weight, h.weight.shape[1], 1, d_d1a, d_d1a.stride(0), B,
+                         h.weight.shape[1], n, beta=1.0)
+        if need_wgrad:
+            put(h.weight, ops.linear_backward_weight(dl, S.d1a))
+            put(h.bias, ops.colsum(dl))
     d_d1 = ops.relu_dropout_backward(d_d1a, S.d1, S.dmask)
     dz = ops.linear_backward_input(d_d1, P.dense1.weight)
     if need_wgrad:
         put(P.dense1.weight, ops.linear_backward_weight(d_d1, S.z))
         put(P.dense1.bias, ops.colsum(d_d1))
-    dout = ops.mean_t_backward(dz, T) if S.pooling == "mean" else dz.view(B, T, 128)
+    if dz.shape[1] != S.zdim:   # the appended global features are inputs: no gradient needed
+        dz = dz[:, :S.zdim].contiguous()
+    if S.att is not None:
+        out1 = S.gru[1].out
+        x2 = out1.view(B * T, 128)
+        dout, dscores = ops.att_pool_backward(dz, out1, S.att.probs)
+        ds2 = dscores.view(B * T, -1)
+        d_a1 = ops.tanh_backward(ops.linear_backward_input(ds2, P.att2.weight), S.att.a1t)
+        if need_wgrad:
+            put(P.att2.weight, ops.linear_backward_weight(ds2, S.att.a1t))
+            put(P.att1.weight, ops.linear_backward_weight(d_a1, x2))
+            if P.att2.bias is not None:   # deep variant: Linear with bias
+                put(P.att2.bias, ops.colsum(ds2))
+            if P.att1.bias is not None:
+                put(P.att1.bias, ops.colsum(d_a1))
+        w1 = P.att1.weight
+        ops.gemm_raw(d_a1, d_a1.stride(0), 1, w1, w1.shape[1], 1, dout, 128, B * T, 128, w1.shape[0], beta=1.0)
+    else:
+        dout = ops.mean_t_backward(dz, T) if S.pooling == "mean" else dz.view(B, T, 128)
     r = P.rnn
     dseq = None
     for layer in (1, 0):
@@ -308,18 +359,22 @@ def _param_list(P):
     for cv, bn in zip(P.convs, P.bns):
         ps += [cv.weight, cv.bias, bn.weight, bn.bias]
     ps += list(P.rnn.parameters())
-    ps += [P.dense1.weight, P.dense1.bias, P.head.weight, P.head.bias]
+    ps += [P.dense1.weight, P.dense1.bias]
+    for h in P.heads:
+        ps += [h.weight, h.bias]
+    if P.att:
+        ps += [p for p in (P.att1.weight, P.att1.bias, P.att2.weight, P.att2.bias) if p is not None]
     return ps
 
 
 class TrunkFn(torch.autograd.Function):
-    """logits = trunk(x; params).  forward(ctx, x, P, pooling, injected, *params)."""
+    """logits = trunk(x; params).  forward(ctx, x, P, pooling, injected, gfeat, *params)."""
 
     @staticmethod
-    def forward(ctx, x, P, pooling, injected, *params):
+    def forward(ctx, x, P, pooling, injected, gfeat, *params):
         need = any(ctx.needs_input_grad)
         logits, S = trunk_forward(x.detach().contiguous().view(x.shape[0], x.shape[-2], x.shape[-1]), P, pooling,
-                                  need_grad=need, injected=injected)
+                                  need_grad=need, injected=injected, gfeat=gfeat)
         ctx.S, ctx.P, ctx.params, ctx.xshape = S, P, params, x.shape
         ctx.need_dx = x.requires_grad
         ctx.need_w = any(p.requires_grad for p in params)
@@ -330,12 +385,13 @@ class TrunkFn(torch.autograd.Function):
         dx, grads = trunk_backward(ctx.S, ctx.P, dlogits, need_wgrad=ctx.need_w, need_dx=ctx.need_dx)
         ctx.S = None
         gp = tuple(grads.get(p) if p.requires_grad else None for p in ctx.params)
-        return (dx.view(ctx.xshape) if dx is not None else None, None, None, None) + gp
+        return (dx.view(ctx.xshape) if dx is not None else None, None, None, None, None) + gp
 
 
-def run_trunk(model, x, head, pooling="mean", injected=None):
-    P = trunk_params(model, head)
-    return TrunkFn.apply(x, P, pooling, injected, *_param_list(P))
+def run_trunk(model, x, head, pooling="mean", injected=None, gfeat=None, att="model"):
+    """head 'multitask' returns the (B, 4 + 2) logits of both prediction layers side by side."""
+    P = trunk_params(model, head, att)
+    return TrunkFn.apply(x, P, pooling, injected, gfeat, *_param_list(P))
 
 
 class GradientReversalFunction(torch.autograd.Function):

@@ -377,6 +377,40 @@ def loss_sub_log(loss, mean, lam):
     check(lib.sept_loss_sub_log(loss.data_ptr(), mean.data_ptr(), float(lam), _s(loss)), "sept_loss_sub_log")
 
 
+def tanh_forward(x):
+    y = torch.empty_like(x)
+    check(lib.sept_tanh_forward(x.data_ptr(), y.data_ptr(), x.numel(), _s(x)), "sept_tanh_forward")
+    return y
+
+
+def tanh_backward(dy, y):
+    dx = torch.empty_like(y)
+    check(lib.sept_tanh_backward(dy.data_ptr(), y.data_ptr(), dx.data_ptr(), y.numel(), _s(y)), "sept_tanh_backward")
+    return dx
+
+
+def att_pool_forward(scores, x):
+    """scores (B, T, NH), x (B, T, D) fp32 -> (z (B, D), probs (B, T, NH))."""
+    B, T, NH = scores.shape
+    D = x.shape[2]
+    probs = torch.empty_like(scores)
+    z = torch.empty((B, D), dtype=torch.float32, device=x.device)
+    check(lib.sept_att_pool_forward(scores.data_ptr(), x.data_ptr(), probs.data_ptr(), z.data_ptr(), B, T, NH, D,
+                                    _s(x)), "sept_att_pool_forward")
+    return z, probs
+
+
+def att_pool_backward(dz, x, probs):
+    """-> (direct part of dx (B, T, D), dscores (B, T, NH))."""
+    B, T, NH = probs.shape
+    D = x.shape[2]
+    dx = torch.empty_like(x)
+    dscores = torch.empty_like(probs)
+    check(lib.sept_att_pool_backward(dz.data_ptr(), x.data_ptr(), probs.data_ptr(), dx.data_ptr(), dscores.data_ptr(),
+                                     B, T, NH, D, _s(x)), "sept_att_pool_backward")
+    return dx, dscores
+
+
 def permute_cols(src, C, Wd, inverse=False, out=None):
     N = src.shape[0]
     dst = torch.empty_like(src) if out is None else out

@@ -126,13 +126,14 @@ class GrlTrainer:
                           self.weight_decay, self.steps, gscale)
         SF.invalidate_weight_cache()  # parameters changed through raw pointers
 
-    def train_step(self, features, labels_emo, labels_gen, weights=None, mask=None, pooling="mean"):
+    def train_step(self, features, labels_emo, labels_gen, weights=None, mask=None, pooling="mean",
+                   global_feature=None):
         """One iteration of the batch loop (:122-169) on this rank's shard.  Returns
         (loss, preds, preds_grl); loss is a 0-dim device tensor (no host sync here)."""
         self.model.train()
         self.flat.zero_grad()
         _advance_rng(features.device)
-        preds, preds_grl, _ = self.model(features, mask=mask, grl=False, pooling=pooling)
+        preds, preds_grl, _ = self.model(features, global_feature=global_feature, mask=mask, grl=False, pooling=pooling)
         loss = self.loss(preds, preds_grl, labels_emo, labels_gen, weights, training=True)
         loss.backward()
         self.flat.gather_grads()
@@ -144,9 +145,9 @@ class GrlTrainer:
         return loss.detach(), preds.detach(), preds_grl.detach()
 
     @torch.no_grad()
-    def eval_step(self, features, labels_emo, labels_gen, mask=None, pooling="mean"):
+    def eval_step(self, features, labels_emo, labels_gen, mask=None, pooling="mean", global_feature=None):
         self.model.eval()
-        preds, preds_grl, _ = self.model(features, mask=mask, grl=False, pooling=pooling)
+        preds, preds_grl, _ = self.model(features, global_feature=global_feature, mask=mask, grl=False, pooling=pooling)
         return self.loss(preds, preds_grl, labels_emo, labels_gen, None, training=False), preds, preds_grl
 
 

@@ -61,6 +61,13 @@ def closed_form_mask(W: int, F: int) -> torch.Tensor:
     return ((i * 7 + (i // F)) % 5 != 0).float()
 
 
+def closed_form_gfeat(B: int, n: int = 88) -> torch.Tensor:
+    """Stand-in for the 88 utterance-level functionals appended when global_feature is given."""
+    b = torch.arange(B, dtype=torch.float64).view(B, 1)
+    j = torch.arange(n, dtype=torch.float64).view(1, n)
+    return (0.5 * torch.sin(0.7 * j + 0.9 * b) + 0.2 * torch.cos(0.13 * j * (b + 1))).float()
+
+
 def closed_form_labels(B: int):
     i = torch.arange(B)
     return ((i * 3 + 1) % 4).view(B, 1), ((i * 5 + i // 3) % 2).view(B, 1), (1.0 + 0.25 * (i % 3)).float()

@@ -381,3 +381,96 @@ def test_baseline_trainer_step_matches_torch_sgd():
         assert torch.allclose(got[n].detach().cpu(), p.detach(), rtol=1e-5, atol=1e-7), n
         if n not in used:
             assert torch.equal(p.detach(), before[n]) and torch.equal(got[n].detach().cpu(), before[n]), n
+
+
+# ---- optional branches of two_d_cnn_lstm: attention pooling, global features, multitask ----
+@pytest.fixture(scope="module")
+def GA(golden_dir):
+    return np.load(os.path.join(golden_dir, "model_golden_att.npz"))
+
+
+def _mk_opt(pred, att, gflag, prefix, oracle=False, F=80):
+    if oracle:
+        cls = mo.two_d_cnn_lstm
+    else:
+        from model import baseline_models as bm
+        cls = bm.two_d_cnn_lstm
+    m = cls(1, F, 64, lstm_hidden_size=64, num_layers_lstm=2, pred=pred, attention_size=128, att=att,
+            global_feature=gflag)
+    m.load_state_dict(closed_form_state(m, prefix=prefix))
+    return m if oracle else m.cuda()
+
+
+def test_attention_global_feature_multitask_vs_reference(GA):
+    """att='self_att' (16-head pooling), global_feature concat and pred='multitask'
+    (baseline_models.py:233-258): eval logits against goldens recorded from the REFERENCE."""
+    from tests.closed_form import closed_form_gfeat
+    F = 80
+    x, gf = closed_form_input(B, W, F).cuda(), closed_form_gfeat(B).cuda()
+    with torch.no_grad():
+        close_logits(_mk_opt("emotion", "self_att", 1, "attg.").eval()(x, gf), GA["att_gf_eval_logits"])
+        close_logits(_mk_opt("gender", "self_att", 0, "att.").eval()(x), GA["att_eval_logits"])
+        p1, p2 = _mk_opt("multitask", None, 1, "multi.").eval()(x, gf)
+        close_logits(p1, GA["multi_gf_eval_emo"])
+        close_logits(p2, GA["multi_gf_eval_gen"])
+    with pytest.raises(Exception):        # dense1 was built for 128 + 88 inputs
+        _mk_opt("emotion", None, 1, "attg.").eval()(x)
+
+
+def test_grl_step_with_attention_vs_reference(GA):
+    """GRL wrapper with attention in both branches (cloak_models.py:178-186, 215-223): train-mode
+    logits / loss against the REFERENCE goldens, gradients against the reference-pinned oracle
+    (attention, dense and GRU parameters tightly; conv stack as in test_grl_train_step_vs_reference)."""
+    from model import cloak_models as cm
+    from sept_amd import functional as SF
+    F = 80
+    x = closed_form_input(B, W, F)
+    le, lg, wts = closed_form_labels(B)
+
+    def build(oracle):
+        emo = _mk_opt("emotion", "self_att", 0, "emotion.", oracle)
+        gen = _mk_opt("gender", "self_att", 0, "gender.", oracle)
+        mod = mo if oracle else cm
+        dev = "cpu" if oracle else "cuda"
+        noise = mod.cloak_noise(torch.zeros(1, W, F), torch.ones(1, W, F), torch.tensor(0.01), torch.tensor(10.0), dev)
+        noise.load_state_dict(closed_form_state(noise, prefix="noise."))
+        noise.eps = closed_form_eps(W, F).to(dev)
+        m = mod.two_d_cnn_lstm_syn_with_grl(emo, gen, noise, 0.1).to(dev).train()
+        zero_dropout(m)
+        return m
+
+    grl, ref = build(False), build(True)
+    p1, p2, _ = grl(x.cuda(), mask=None, grl=False, pooling="mean")
+    loss = SF.GrlStepLossFn.apply(p1, p2, le.cuda(), lg.cuda(), wts.cuda(), 0.1, 0.05, grl.intermed.rhos, 0.01, 10.0)
+    loss.backward()
+    close_logits(p1, GA["grl_att_train_emo"])
+    close_logits(p2, GA["grl_att_train_gen"])
+    assert loss.item() == pytest.approx(float(GA["grl_att_train_loss"]), abs=2e-2)
+    q1, q2, _ = ref(x, mask=None, grl=False, pooling="mean")
+    mo.grl_step_loss(q1, q2, le, lg, wts, 0.1, 0.05, ref).backward()
+    rep = _grad_report(grl, ref)
+    assert "gender_model.att_linear1.weight" in rep and "gender_model.att_linear2.weight" in rep
+    for name, (c, rel) in rep.items():
+        if _is_conv_stack(name):
+            assert c > 0.8, (name, c, rel)
+        else:
+            assert c > 0.999 and rel < 0.03, (name, c, rel)
+
+
+def test_multitask_backward_matches_oracle():
+    """pred='multitask': both heads' gradients flow through the shared trunk (fp32 part compared tightly)."""
+    from tests.closed_form import closed_form_gfeat
+    F = 80
+    x, gf = closed_form_input(B, W, F), closed_form_gfeat(B)
+    le, lg, _ = closed_form_labels(B)
+    m, ref = _mk_opt("multitask", None, 1, "multi.").train(), _mk_opt("multitask", None, 1, "multi.", oracle=True).train()
+    zero_dropout(m), zero_dropout(ref)
+    p1, p2 = m(x.cuda(), gf.cuda())
+    (torch.nn.functional.cross_entropy(p1, le.view(-1).cuda()) + torch.nn.functional.cross_entropy(p2, lg.view(-1).cuda())).backward()
+    q1, q2 = ref(x, gf)
+    (torch.nn.functional.cross_entropy(q1, le.view(-1)) + torch.nn.functional.cross_entropy(q2, lg.view(-1))).backward()
+    got = dict(m.named_parameters())
+    for name in ("pred_emotion_layer.weight", "pred_gender_layer.weight", "pred_gender_layer.bias", "dense1.weight",
+                 "rnn.weight_hh_l1", "rnn.weight_ih_l1_reverse"):
+        g, w = got[name].grad.cpu(), dict(ref.named_parameters())[name].grad
+        assert _cos(g, w) > 0.999 and float((g - w).norm() / w.norm()) < 0.03, name

@@ -121,3 +121,53 @@ def test_grl_known_answer(G):
     (y * torch.arange(1.0, 7.0).reshape(2, 3)).sum().backward()
     np.testing.assert_allclose(z.grad.numpy(), G["grl_kat_grad"])
     np.testing.assert_allclose(z.grad.numpy(), -0.1 * np.arange(1.0, 7.0).reshape(2, 3), rtol=1e-6)
+
+
+# ---- optional branches of two_d_cnn_lstm: attention pooling, global features, multitask ----
+@pytest.fixture(scope="module")
+def GA(golden_dir):
+    return np.load(os.path.join(golden_dir, "model_golden_att.npz"))
+
+
+def mk_opt(pred, att, gflag, prefix, F=80):
+    m = mo.two_d_cnn_lstm(1, F, 64, lstm_hidden_size=64, num_layers_lstm=2, pred=pred, attention_size=128, att=att,
+                          global_feature=gflag)
+    m.load_state_dict(closed_form_state(m, prefix=prefix))
+    return m
+
+
+def test_oracle_attention_global_feature_multitask_vs_reference(GA):
+    """baseline_models.py:233-258 (self_att pooling, functionals concat, two heads) and the GRL
+    wrapper with attention (cloak_models.py:178-186, 215-223): oracle == reference goldens."""
+    from tests.closed_form import closed_form_gfeat
+    F = 80
+    x, gf = closed_form_input(B, W, F), closed_form_gfeat(B)
+    le, lg, wts = closed_form_labels(B)
+    with torch.no_grad():
+        np.testing.assert_allclose(mk_opt("emotion", "self_att", 1, "attg.").eval()(x, gf).numpy(),
+                                   GA["att_gf_eval_logits"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(mk_opt("gender", "self_att", 0, "att.").eval()(x).numpy(), GA["att_eval_logits"],
+                                   rtol=1e-4, atol=1e-5)
+        p1, p2 = mk_opt("multitask", None, 1, "multi.").eval()(x, gf)
+        np.testing.assert_allclose(p1.numpy(), GA["multi_gf_eval_emo"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(p2.numpy(), GA["multi_gf_eval_gen"], rtol=1e-4, atol=1e-5)
+    emo, gen = mk_opt("emotion", "self_att", 0, "emotion."), mk_opt("gender", "self_att", 0, "gender.")
+    noise = mo.cloak_noise(torch.zeros(1, W, F), torch.ones(1, W, F), torch.tensor(0.01), torch.tensor(10.0), "cpu")
+    noise.load_state_dict(closed_form_state(noise, prefix="noise."))
+    noise.eps = closed_form_eps(W, F)
+    grl = mo.two_d_cnn_lstm_syn_with_grl(emo, gen, noise, 0.1)
+    grl.train()
+    zero_dropout(grl)
+    p1, p2, _ = grl(x, mask=None, grl=False, pooling="mean")
+    loss = mo.grl_step_loss(p1, p2, le, lg, wts, 0.1, 0.05, grl)
+    loss.backward()
+    np.testing.assert_allclose(p1.detach().numpy(), GA["grl_att_train_emo"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(p2.detach().numpy(), GA["grl_att_train_gen"], rtol=1e-4, atol=1e-5)
+    assert float(loss) == pytest.approx(float(GA["grl_att_train_loss"]), rel=1e-5)
+    assert float(grl.intermed.locs.grad.double().norm()) == pytest.approx(float(GA["grl_att_grad_locs_norm"]), rel=1e-3)
+    gp = dict(grl.gender_model.named_parameters())
+    for name in ("att_linear1.weight", "att_linear2.weight", "dense1.weight", "rnn.weight_hh_l1"):
+        g = gp[name].grad
+        want = GA["grl_att_grad_" + name]
+        np.testing.assert_allclose(g.reshape(-1)[:want.size].double().numpy(), want, rtol=2e-3,
+                                   atol=2e-3 * float(GA["grl_att_gradnorm_" + name]) / want.size ** 0.5)
