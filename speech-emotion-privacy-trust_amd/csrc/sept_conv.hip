@@ -85,13 +85,16 @@ __global__ __launch_bounds__(64 * WP * WN) void sept_conv5x5_mfma_kernel(ConvArg
   const int NR = h_last - h_first + 5;
 
   int c0 = 0;  // first input channel of the current slice
+  // Weight-tile loads are UNCONDITIONAL (chunk index clamped; surplus lanes re-read the last chunk
+  // and simply do not store it): a predicated load inside the tap loop makes the compiler drain
+  // every outstanding load (s_waitcnt vmcnt(0)) instead of counting them.
   auto wload = [&](int g, uint4 (&r)[WCH]) {  // group g = taps [g*TG, min(25, (g+1)*TG)), contiguous in wt
     const bf16* wsrc = a.wt + size_t(g) * TG * COUT * CINF + c0;
     const int n = min(TG, kTaps - g * TG) * COUT * CPP;
 #pragma unroll
     for (int j = 0; j < WCH; ++j) {
-      const int i = tid + NTHR * j;
-      if (i < n) r[j] = *reinterpret_cast<const uint4*>(wsrc + size_t(i / CPP) * CINF + (i % CPP) * 8);
+      const int i = min(tid + NTHR * j, n - 1);
+      r[j] = *reinterpret_cast<const uint4*>(wsrc + size_t(i / CPP) * CINF + (i % CPP) * 8);
     }
   };
   auto wstore = [&](int g, const uint4 (&r)[WCH]) {
@@ -143,16 +146,14 @@ __global__ __launch_bounds__(64 * WP * WN) void sept_conv5x5_mfma_kernel(ConvArg
     wstore(0, r);
   }
   __syncthreads();
-  for (int g = 0; g < NG; ++g) {
-    uint4 wreg[WCH];
-    if (g + 1 < NG) wload(g + 1, wreg);  // in flight under this group's MFMAs
+  auto compute = [&](int g, int buf) {   // the MFMAs of tap group g; its weights sit in LDS buffer `buf`
 #pragma unroll
     for (int tl = 0; tl < TG; ++tl) {
       const int tap = g * TG + tl;
       if (tap >= kTaps) break;
       const int kh = tap / 5, kw = tap - kh * 5;
       const int tapoff = (kh * W4 + kw) * PS;
-      const unsigned char* wb = wbuf + size_t(DBUF ? (g & 1) : tl) * COUT * PSW;
+      const unsigned char* wb = wbuf + size_t(DBUF ? buf : tl) * COUT * PSW;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         bf16x8 bfrag[PB], afrag[NB];
@@ -169,13 +170,34 @@ __global__ __launch_bounds__(64 * WP * WN) void sept_conv5x5_mfma_kernel(ConvArg
             acc[pb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[nb], bfrag[pb], acc[pb][nb], 0, 0, 0);
       }
     }
-    if constexpr (DBUF) {
-      if (g + 1 < NG) wstore(g + 1, wreg);  // other buffer: nobody reads it during this interval
-      __syncthreads();
-    } else if (g + 1 < NG) {
-      __syncthreads();  // every wave is done reading this group's weights
-      wstore(g + 1, wreg);
-      __syncthreads();
+  };
+  if constexpr (DBUF) {
+    // Two register sets: the weights of tap g + 2 are requested while tap g is computed and are
+    // written to LDS one interval later, so a load has a whole interval (and an LDS-only barrier
+    // that does not drain it) to land.  Taps past the end re-load the last tile (never stored).
+    uint4 wa[WCH], wb2[WCH];
+    wload(min(1, NG - 1), wa);
+    for (int g = 0; g < NG; g += 2) {
+      wload(min(g + 2, NG - 1), wb2);
+      compute(g, 0);
+      if (g + 1 < NG) wstore(g + 1, wa);      // LDS buffer 1: nobody reads it during this interval
+      sept::lds_barrier();
+      if (g + 1 >= NG) break;
+      wload(min(g + 3, NG - 1), wa);
+      compute(g + 1, 1);
+      if (g + 2 < NG) wstore(g + 2, wb2);     // LDS buffer 0
+      sept::lds_barrier();
+    }
+  } else {
+    for (int g = 0; g < NG; ++g) {
+      uint4 wreg[WCH];
+      if (g + 1 < NG) wload(g + 1, wreg);  // in flight under this group's MFMAs
+      compute(g, 0);
+      if (g + 1 < NG) {
+        __syncthreads();  // every wave is done reading this group's weights
+        wstore(g + 1, wreg);
+        __syncthreads();
+      }
     }
   }
   }  // channel slices

@@ -317,33 +317,41 @@ __global__ __launch_bounds__(256) void sept_conv1_dgrad_stream_kernel(const bf16
   // row loader: chunk i of a dy row = 16 bytes = 8 channels of pixel i/4.  Rows are fetched TWO
   // steps ahead into alternating register sets, so a global load has a full step to land.
   const int nchunks = W * 4;
+  // Loads are UNCONDITIONAL (row and chunk indices clamped into the image; rows outside it are
+  // zeroed when they are written to LDS): with predicated loads the compiler cannot count the
+  // outstanding memory operations and drains them all (s_waitcnt vmcnt(0)) at every step.
   auto gload = [&](int y, uint4 (&pre)[2]) {
+    const bf16* row = dyb + size_t(min(max(y, 0), H - 1)) * W * kC;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int i = tid + 256 * j;
-      pre[j] = make_uint4(0, 0, 0, 0);
-      if (i < nchunks && y >= 0 && y < H) pre[j] = *reinterpret_cast<const uint4*>(dyb + (size_t(y) * W) * kC + size_t(i) * 8);
-    }
+    for (int j = 0; j < 2; ++j) pre[j] = *reinterpret_cast<const uint4*>(row + size_t(min(tid + 256 * j, nchunks - 1)) * 8);
   };
-  auto lstore = [&](int buf, const uint4 (&pre)[2]) {
+  auto lstore = [&](int buf, int y, const uint4 (&pre)[2]) {
+    const bool inside = y >= 0 && y < H;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int i = tid + 256 * j;
       if (i < nchunks)
-        *reinterpret_cast<uint4*>(dyrow + size_t(buf) * NP * kDyPS + size_t((i >> 2) + 2) * kDyPS + (i & 3) * 16) = pre[j];
+        *reinterpret_cast<uint4*>(dyrow + size_t(buf) * NP * kDyPS + size_t((i >> 2) + 2) * kDyPS + (i & 3) * 16) =
+            inside ? pre[j] : make_uint4(0, 0, 0, 0);
     }
   };
-  uint4 preA[2], preB[2];
+  // Four register sets: the row transformed at step s + 1 was requested at step s - 3, so a global
+  // load has three full steps to land (one step was not enough to cover the HBM latency).
+  uint4 pre0[2], pre1[2], pre2[2], pre3[2];
   __syncthreads();
-  gload(r0 - 2, preA);
-  lstore(0, preA);
-  gload(r0 - 1, preB);  // row of step 1, stored at the end of step 0
+  gload(r0 - 2, pre0);
+  gload(r0 - 1, pre1);
+  gload(r0, pre2);
+  gload(r0 + 1, pre3);
+  lstore(0, r0 - 2, pre0);
   __syncthreads();
 
   const int nsteps = (r1 - r0) + 5;  // rows r0-2 .. r1+1 are transformed, plus one flush step
-  auto step = [&](int s, uint4 (&pre_next2)[2], const uint4 (&pre_next1)[2]) {
+  // step s: transform dy row y = r0 - 2 + s (LDS buffer s & 1); request row y + 4 into the register
+  // set that held row y (already in LDS); store row y + 1 (requested three steps ago) for the next step
+  auto step = [&](int s, uint4 (&pre_req)[2], const uint4 (&pre_next1)[2]) {
     const int y = r0 - 2 + s;        // dy row transformed in this step (zeros outside the image)
-    gload(y + 2, pre_next2);         // two rows ahead
+    gload(y + 4, pre_req);
     // ---- Z row of dy row y: waves take 32-pixel blocks ----
     const unsigned char* cur = dyrow + size_t(s & 1) * NP * kDyPS;
     float* zrow = zring + size_t(s % kRing) * NP * kZS;
@@ -377,12 +385,14 @@ __global__ __launch_bounds__(256) void sept_conv1_dgrad_stream_kernel(const bf16
       }
       dx[(size_t(b) * H + r) * W + tid] = sum;
     }
-    lstore((s + 1) & 1, pre_next1);  // row y + 1, requested one step ago
-    sept::lds_barrier();             // LDS-only barrier: the row requested above stays in flight
+    lstore((s + 1) & 1, y + 1, pre_next1);  // row y + 1
+    sept::lds_barrier();             // LDS-only barrier: the rows requested above stay in flight
   };
-  for (int s = 0; s < nsteps; s += 2) {
-    step(s, preA, preB);
-    if (s + 1 < nsteps) step(s + 1, preB, preA);
+  for (int s = 0; s < nsteps; s += 4) {
+    step(s, pre0, pre1);
+    if (s + 1 < nsteps) step(s + 1, pre1, pre2);
+    if (s + 2 < nsteps) step(s + 2, pre2, pre3);
+    if (s + 3 < nsteps) step(s + 3, pre3, pre0);
   }
 }
 
@@ -516,8 +526,10 @@ extern "C" int sept_conv1_backward_data(const void* dy, const float* w, float* w
   if (W * 4 <= 512 && H >= 1) {  // streaming MFMA form: a dy row fits two 16-byte chunks per lane
     const int NP = (W + 4 + 31) / 32 * 32;
     const size_t smem_s = size_t(2) * NP * kDyPS + size_t(kRing) * NP * kZS * sizeof(float);
-    // enough row chunks to give every CU about two workgroups, but at least 16 rows per chunk
-    int chunks = std::max(1, std::min((H + 15) / 16, (512 + B - 1) / B));
+    // Two workgroups fit on a CU (LDS), i.e. 512 at a time: as many row chunks as keep the whole
+    // grid resident in ONE round (a second, partly filled round costs a full pass), at least 16
+    // rows per chunk
+    int chunks = std::max(1, std::min((H + 15) / 16, 512 / std::max(B, 1)));
     const int rows = (H + chunks - 1) / chunks;
     chunks = (H + rows - 1) / rows;
     SEPT_HIP(sept::allow_max_lds(reinterpret_cast<const void*>(&sept_conv1_dgrad_stream_kernel)));
