@@ -274,6 +274,21 @@ int sept_transpose_last2(const float* in, float* out, int B, int R, int C, void*
  * (preprocess_adversary_data.py:30-35,131,377-378; training_cloak_with_grl.py:71). */
 int sept_window_norm(const float* mel_btf, const float* mean, const float* stdv, float* out, int B, int T, int F,
                      int win, int shift, int nwin, void* stream);
+/* Per-speaker normalisation and class-balance augmentation of the preprocessing step
+ * (preprocess_adversary_data.py:356-423).  sept_speaker_stats: stats (S, 4, F) = {mean, std (population),
+ * min, max} per mel bin over ALL frames of the clips of each speaker (spk (B) int32, NULL = one speaker),
+ * accumulated in float64 like numpy; ws = sept_speaker_stats_workspace_doubles(B, F) doubles.
+ * sept_window_norm_spk: windows of clip b normalised with the statistics of spk[b]; mode 0:
+ * (x - mean) / (std + 1e-5), mode 1: (x - min) / (max - min) * 2 - 1; frames past T are zero BEFORE the
+ * normalisation, as the reference pads.  sept_add_normal: out = x + Normal(0, stdv) (Philox), the
+ * augmentation noise of :416-417. */
+size_t sept_speaker_stats_workspace_doubles(int B, int F);
+int sept_speaker_stats(const float* mel_btf, const int* spk, int B, int T, int F, int S, double* ws,
+                       float* stats, void* stream);
+int sept_window_norm_spk(const float* mel_btf, const float* stats, const int* spk, int mode, float* out,
+                         int B, int T, int F, int win, int shift, int nwin, void* stream);
+int sept_add_normal(const float* x, float* out, long n, float stdv, unsigned long long seed,
+                    const long long* offset_dev, unsigned long long offset, void* stream);
 /* torch.optim.SGD(momentum, weight_decay) / torch.optim.Adam(betas, eps, weight_decay) on a flat
  * parameter buffer (training_cloak_with_grl.py:416-421); grad_scale multiplies g first (1/world
  * for averaged data-parallel gradients).  Adam `step` counts from 1. */

@@ -488,6 +488,86 @@ __global__ __launch_bounds__(256) void att_pool_bwd_kernel(const float* dz, cons
   }
 }
 
+// ---------------- per-speaker statistics, min-max / z normalisation, Gaussian augmentation ----------------
+// preprocess_adversary_data.py:356-390 (np.nanmean / nanstd / nanmin / nanmax over ALL frames of a
+// speaker, per mel bin; z-norm or min-max -> [-1, 1]) and :392-423 (x + Normal(0, 0.05) copies of
+// minority-class windows).  Statistics are accumulated in float64 like numpy does.
+// stage 1: one thread per (clip, mel bin) walks the clip's frames -> ws[b][f] = {sum, sumsq, min, max}
+__global__ void clip_stats_kernel(const float* mel, int B, int T, int F, double* ws) {
+  GRID_STRIDE(i, long(B) * F) {
+    const int f = i % F;
+    const long b = i / F;
+    const float* p = mel + b * T * F + f;
+    double s = 0.0, ss = 0.0, mn = INFINITY, mx = -INFINITY;
+    for (int t = 0; t < T; ++t) {
+      const double v = p[size_t(t) * F];
+      s += v;
+      ss += v * v;
+      mn = fmin(mn, v);
+      mx = fmax(mx, v);
+    }
+    double* o = ws + i * 4;
+    o[0] = s; o[1] = ss; o[2] = mn; o[3] = mx;
+  }
+}
+// stage 2: one thread per (speaker, mel bin) combines its clips in clip order -> stats[s][{mean,std,min,max}][f]
+__global__ void speaker_stats_kernel(const double* ws, const int* spk, int B, int T, int F, int S, float* stats) {
+  GRID_STRIDE(i, long(S) * F) {
+    const int f = i % F, sp = i / F;
+    double s = 0.0, ss = 0.0, mn = INFINITY, mx = -INFINITY;
+    long n = 0;
+    for (int b = 0; b < B; ++b) {
+      if ((spk ? spk[b] : 0) != sp) continue;
+      const double* o = ws + (size_t(b) * F + f) * 4;
+      s += o[0]; ss += o[1]; mn = fmin(mn, o[2]); mx = fmax(mx, o[3]);
+      n += T;
+    }
+    float* out = stats + size_t(sp) * 4 * F;
+    if (n == 0) {   // speaker without clips in this batch: identity statistics
+      out[f] = 0.f; out[F + f] = 1.f; out[2 * F + f] = 0.f; out[3 * F + f] = 1.f;
+      continue;
+    }
+    const double m = s / double(n);
+    double var = ss / double(n) - m * m;
+    var = var < 0 ? 0 : var;
+    out[f] = float(m); out[F + f] = float(sqrt(var)); out[2 * F + f] = float(mn); out[3 * F + f] = float(mx);
+  }
+}
+// windows of clip b normalised with ITS speaker's statistics: mode 0 (x - mean) / (std + 1e-5),
+// mode 1 (x - min) / (max - min) * 2 - 1; frames past T are zeros BEFORE normalisation (:30-35)
+__global__ void window_norm_spk_kernel(const float* mel, const float* stats, const int* spk, int mode, float* out, int B,
+                                       int T, int F, int win, int shift, int nwin) {
+  const long total = long(B) * nwin * win * F;
+  GRID_STRIDE(i, total) {
+    const int f = i % F;
+    const int t = (i / F) % win;
+    const long bw = i / (long(F) * win);
+    const int wi = bw % nwin;
+    const long b = bw / nwin;
+    const int src_t = wi * shift + t;
+    const float v = src_t < T ? mel[(b * T + src_t) * F + f] : 0.f;
+    const float* st = stats + size_t(spk ? spk[b] : 0) * 4 * F;
+    out[i] = mode == 0 ? (v - st[f]) / (st[F + f] + 1e-5f) : (v - st[2 * F + f]) / (st[3 * F + f] - st[2 * F + f]) * 2.0f - 1.0f;
+  }
+}
+// out = x + Normal(0, stdv)  (Box-Muller on Philox, as normal_kernel)
+__global__ void add_normal_kernel(const float* x, float* out, long n, float stdv, unsigned long long seed,
+                                  const long long* offset_dev, unsigned long long offset) {
+  const unsigned long long off = offset + (offset_dev ? (unsigned long long)(*offset_dev) : 0ull);
+  GRID_STRIDE(q, (n + 3) / 4) {
+    const uint4 r = philox4x32(make_uint4(unsigned(q), unsigned(q >> 32), unsigned(off), unsigned(off >> 32)),
+                               make_uint2(unsigned(seed), unsigned(seed >> 32)));
+    const float r0 = sqrtf(-2.0f * logf(u01(r.x))), r1 = sqrtf(-2.0f * logf(u01(r.z)));
+    float s0, c0, s1, c1;
+    sincosf(6.28318530718f * u01(r.y), &s0, &c0);
+    sincosf(6.28318530718f * u01(r.w), &s1, &c1);
+    const float z[4] = {r0 * c0, r0 * s0, r1 * c1, r1 * s1};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (4 * q + k < n) out[4 * q + k] = x[4 * q + k] + stdv * z[k];
+  }
+}
+
 // ---------------- optimisers (training_cloak_with_grl.py:416-421) ----------------
 // torch.optim.SGD(momentum, weight_decay, dampening 0, nesterov False)
 __global__ void sgd_kernel(float* p, const float* g, float* buf, long n, float lr, float momentum, float wd,
@@ -770,6 +850,38 @@ extern "C" int sept_att_pool_backward(const float* dz, const float* x, const flo
                SEPT_ERR_INVALID, "sept_att_pool_backward: B=%d T=%d NH=%d D=%d (T <= %d)", B, T, NH, D, kAttMaxT);
   hipLaunchKernelGGL(att_pool_bwd_kernel, dim3(B), dim3(256), 0, ST(stream), dz, x, probs, dx, dscores, T, NH, D);
   return sept::launch_check("att_pool_bwd_kernel");
+}
+
+extern "C" size_t sept_speaker_stats_workspace_doubles(int B, int F) { return size_t(B) * size_t(F) * 4; }
+
+extern "C" int sept_speaker_stats(const float* mel_btf, const int* spk, int B, int T, int F, int S, double* ws,
+                                  float* stats, void* stream) {
+  SEPT_REQUIRE(mel_btf && ws && stats && B > 0 && T > 0 && F > 0 && S > 0, SEPT_ERR_INVALID,
+               "sept_speaker_stats: bad argument");
+  hipLaunchKernelGGL(clip_stats_kernel, dim3(blocks_for(long(B) * F)), dim3(kThreads), 0, ST(stream), mel_btf, B, T, F, ws);
+  hipLaunchKernelGGL(speaker_stats_kernel, dim3(blocks_for(long(S) * F)), dim3(kThreads), 0, ST(stream), ws, spk, B, T, F,
+                     S, stats);
+  return sept::launch_check("speaker_stats_kernel");
+}
+
+extern "C" int sept_window_norm_spk(const float* mel_btf, const float* stats, const int* spk, int mode, float* out,
+                                    int B, int T, int F, int win, int shift, int nwin, void* stream) {
+  if (B == 0) return SEPT_OK;
+  SEPT_REQUIRE(mel_btf && stats && out && B > 0 && T > 0 && F > 0 && win > 0 && shift > 0 && nwin > 0 &&
+                   (mode == 0 || mode == 1), SEPT_ERR_INVALID, "sept_window_norm_spk: bad argument");
+  const long total = long(B) * nwin * win * F;
+  hipLaunchKernelGGL(window_norm_spk_kernel, dim3(blocks_for(total)), dim3(kThreads), 0, ST(stream), mel_btf, stats, spk,
+                     mode, out, B, T, F, win, shift, nwin);
+  return sept::launch_check("window_norm_spk_kernel");
+}
+
+extern "C" int sept_add_normal(const float* x, float* out, long n, float stdv, unsigned long long seed,
+                               const long long* offset_dev, unsigned long long offset, void* stream) {
+  if (n == 0) return SEPT_OK;
+  SEPT_REQUIRE(x && out && n > 0, SEPT_ERR_INVALID, "sept_add_normal: bad argument");
+  hipLaunchKernelGGL(add_normal_kernel, dim3(blocks_for((n + 3) / 4)), dim3(kThreads), 0, ST(stream), x, out, n, stdv,
+                     seed, offset_dev, offset);
+  return sept::launch_check("add_normal_kernel");
 }
 
 extern "C" int sept_sgd_step(float* p, const float* g, float* momentum_buf, long n, float lr, float momentum,

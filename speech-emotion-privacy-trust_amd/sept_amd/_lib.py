@@ -90,6 +90,11 @@ SIGNATURES = {
     "sept_att_pool_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "sept_att_pool_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                        c_void_p]),
+    "sept_speaker_stats_workspace_doubles": (c_size_t, [c_int, c_int]),
+    "sept_speaker_stats": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "sept_window_norm_spk": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                     c_int, c_void_p]),
+    "sept_add_normal": (c_int, [c_void_p, c_void_p, c_long, c_float, c_ulonglong, c_void_p, c_ulonglong, c_void_p]),
     "sept_gru_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                               c_void_p, c_void_p]),
     "sept_topdb_clamp": (c_int, [c_void_p, c_int, c_long, c_float, c_void_p]),

@@ -240,3 +240,46 @@ def test_philox_dropout_and_normal_statistics():
     r2.begin_step()                      # next step: fresh numbers
     assert not torch.equal(r2.dropout_mask((1000, 1000), 0.2), m)
     assert not torch.equal(ops.Rng(99, "cuda").dropout_mask((1000, 1000), 0.2), m)
+
+
+def test_preprocess_speaker_stats_window_norm_and_augmentation():
+    """Device side of preprocess_adversary_data.py:356-423 against numpy: per-speaker nanmean / nanstd /
+    nanmin / nanmax, z-norm and min-max windows (also a short, zero-padded clip) and the Gaussian
+    class-balance augmentation."""
+    import numpy as np
+    from sept_amd import preprocess as pp
+    g = torch.Generator().manual_seed(11)
+    B, T, F, S = 6, 301, 40, 3
+    mel = torch.randn(B, T, F, generator=g) * 9 - 30
+    spk = torch.tensor([0, 2, 0, 1, 2, 2], dtype=torch.int32)
+    stats = pp.speaker_stats(mel.cuda(), spk.cuda(), S).cpu().numpy()
+    m = mel.double().numpy()
+    for s_ in range(S):
+        rows = m[(spk == s_).numpy()].reshape(-1, F)
+        np.testing.assert_allclose(stats[s_, 0], rows.mean(0), rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(stats[s_, 1], rows.std(0), rtol=1e-5)
+        np.testing.assert_allclose(stats[s_, 2], rows.min(0), rtol=1e-6)
+        np.testing.assert_allclose(stats[s_, 3], rows.max(0), rtol=1e-6)
+    st = torch.from_numpy(stats).cuda()
+    for norm in ("znorm", "min_max"):
+        w = pp.window_normalize(mel.cuda(), st, spk.cuda(), norm).cpu().numpy()
+        assert w.shape == (B * 3, 200, F)                      # int((301 - 200) / 50) + 1 = 3 windows
+        for b in (0, 3, 5):
+            for i in range(3):
+                x = m[b, 50 * i:50 * i + 200]
+                s_ = int(spk[b])
+                want = (x - stats[s_, 0]) / (stats[s_, 1] + 1e-5) if norm == "znorm" else \
+                    (x - stats[s_, 2]) / (stats[s_, 3] - stats[s_, 2]) * 2 - 1
+                np.testing.assert_allclose(w[b * 3 + i], want, rtol=2e-4, atol=2e-4)
+    short = pp.window_normalize(mel[:1, :120].contiguous().cuda(), st[:1], None, "znorm").cpu().numpy()
+    assert short.shape == (1, 200, F)
+    np.testing.assert_allclose(short[0, 120:], np.broadcast_to((0 - stats[0, 0]) / (stats[0, 1] + 1e-5), (80, F)),
+                               rtol=1e-4, atol=1e-4)             # padded with zeros BEFORE the normalisation
+    # augmentation: noise statistics and class balance
+    x = torch.zeros(64, 200, F).cuda()
+    noise = pp.add_gaussian(x, 0.05)
+    assert abs(float(noise.mean())) < 1e-3 and float(noise.std()) == pytest.approx(0.05, rel=2e-2)
+    labels = torch.tensor([0] * 40 + [1] * 14 + [2] * 10)
+    xa, la = pp.balance_by_augmentation(x, labels, generator=torch.Generator().manual_seed(1))
+    assert xa.shape[0] == 120 and torch.bincount(la.cpu()).tolist() == [40, 40, 40]
+    assert float(xa[:64].abs().max()) == 0.0 and float(xa[64:].std()) == pytest.approx(0.05, rel=5e-2)
