@@ -274,6 +274,12 @@ int sept_transpose_last2(const float* in, float* out, int B, int R, int C, void*
  * (preprocess_adversary_data.py:30-35,131,377-378; training_cloak_with_grl.py:71). */
 int sept_window_norm(const float* mel_btf, const float* mean, const float* stdv, float* out, int B, int T, int F,
                      int win, int shift, int nwin, void* stream);
+/* torchaudio.transforms.Resample(orig, new) as used for MSP-Improv (audio_feature_extraction.py:139-141):
+ * polyphase windowed-sinc FIR.  orig / newf are the two rates divided by their gcd; ker (newf, 2*width + orig)
+ * is the host-built table (sept_amd/resample.py restates torchaudio's _get_sinc_resample_kernel);
+ * out (B, target), target = ceil(L * newf / orig). */
+int sept_resample_forward(const float* x, const float* ker, float* out, int B, long L, int orig, int newf,
+                          int width, long target, void* stream);
 /* Per-speaker normalisation and class-balance augmentation of the preprocessing step
  * (preprocess_adversary_data.py:356-423).  sept_speaker_stats: stats (S, 4, F) = {mean, std (population),
  * min, max} per mel bin over ALL frames of the clips of each speaker (spk (B) int32, NULL = one speaker),

@@ -136,3 +136,36 @@ def mfcc_with_deltas_f64(audio: np.ndarray) -> np.ndarray:
     d1 = np.gradient(x[0])[None]
     d2 = np.gradient(x[0], 2)[None]
     return np.concatenate((mfcc_f64(x), mfcc_f64(d1), mfcc_f64(d2)), axis=1)
+
+
+# ----------------------------------------------------------------------------------------
+# Resample: audio_feature_extraction.py:139-141 -> torchaudio.transforms.Resample(sample_rate, 16000)
+# with its defaults (sinc_interpolation, lowpass_filter_width 6, rolloff 0.99).  Restated from
+# torchaudio.functional.resample (_get_sinc_resample_kernel + _apply_sinc_resample_kernel):
+# zero padding (width, width + orig), conv1d with stride orig, crop to ceil(new * L / orig).
+# PARITY UNPINNED (torchaudio absent); pinned by DC gain / tone-preservation checks.
+# ----------------------------------------------------------------------------------------
+def resample_torch(waveform: torch.Tensor, orig_freq: int, new_freq: int, lowpass_filter_width: int = 6,
+                   rolloff: float = 0.99) -> torch.Tensor:
+    if orig_freq == new_freq:
+        return waveform
+    g = math.gcd(int(orig_freq), int(new_freq))
+    orig, new = int(orig_freq) // g, int(new_freq) // g
+    base_freq = min(orig, new) * rolloff
+    width = math.ceil(lowpass_filter_width * orig / base_freq)
+    idx = torch.arange(-width, width + orig, dtype=torch.float64)[None, None] / orig
+    t = torch.arange(0, -new, -1, dtype=torch.float64)[:, None, None] / new + idx
+    t *= base_freq
+    t = t.clamp_(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t *= math.pi
+    kernels = torch.where(t == 0, torch.tensor(1.0, dtype=torch.float64), t.sin() / t) * window * (base_freq / orig)
+    kernels = kernels.to(torch.float32)
+    shape = waveform.shape
+    x = waveform.float().reshape(-1, shape[-1])
+    n, length = x.shape
+    x = torch.nn.functional.pad(x, (width, width + orig))
+    y = torch.nn.functional.conv1d(x[:, None], kernels, stride=orig)
+    y = y.transpose(1, 2).reshape(n, -1)
+    target = int(math.ceil(new * length / orig))
+    return y[..., :target].reshape(shape[:-1] + (target,))

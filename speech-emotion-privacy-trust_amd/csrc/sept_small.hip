@@ -568,6 +568,28 @@ __global__ void add_normal_kernel(const float* x, float* out, long n, float stdv
   }
 }
 
+// ---------------- polyphase sinc resampling (torchaudio.transforms.Resample, audio_feature_extraction.py:139-141) ----------------
+// out[b][n * nf + p] = sum_k ker[p][k] * xpad[b][n * of + k],  xpad = x padded with `width` zeros on the
+// left and width + of on the right; of / nf = orig / new frequency divided by their gcd; ker (nf, K),
+// K = 2 * width + of, is the windowed-sinc table built on the host.
+__global__ void resample_kernel(const float* x, const float* ker, float* out, int B, long L, int of, int nf, int width,
+                                long target) {
+  const int K = 2 * width + of;
+  GRID_STRIDE(i, long(B) * target) {
+    const long o = i % target, b = i / target;
+    const long n = o / nf;
+    const int p = o % nf;
+    const float* kp = ker + size_t(p) * K;
+    const float* xb = x + b * L;
+    const long base = n * of - width;
+    const int k0 = base < 0 ? int(-base) : 0;
+    const int k1 = int(min(long(K), L - base));
+    float acc = 0.f;
+    for (int k = k0; k < k1; ++k) acc = fmaf(kp[k], xb[base + k], acc);
+    out[i] = acc;
+  }
+}
+
 // ---------------- optimisers (training_cloak_with_grl.py:416-421) ----------------
 // torch.optim.SGD(momentum, weight_decay, dampening 0, nesterov False)
 __global__ void sgd_kernel(float* p, const float* g, float* buf, long n, float lr, float momentum, float wd,
@@ -882,6 +904,18 @@ extern "C" int sept_add_normal(const float* x, float* out, long n, float stdv, u
   hipLaunchKernelGGL(add_normal_kernel, dim3(blocks_for((n + 3) / 4)), dim3(kThreads), 0, ST(stream), x, out, n, stdv,
                      seed, offset_dev, offset);
   return sept::launch_check("add_normal_kernel");
+}
+
+extern "C" int sept_resample_forward(const float* x, const float* ker, float* out, int B, long L, int orig, int newf,
+                                     int width, long target, void* stream) {
+  if (B == 0 || target == 0) return SEPT_OK;
+  SEPT_REQUIRE(x && ker && out && B > 0 && L > 0 && orig > 0 && newf > 0 && width >= 0 && target > 0, SEPT_ERR_INVALID,
+               "sept_resample_forward: bad argument");
+  SEPT_REQUIRE(target <= (L * newf + orig - 1) / orig, SEPT_ERR_INVALID, "sept_resample_forward: target=%ld exceeds ceil(L*new/orig)",
+               target);
+  hipLaunchKernelGGL(resample_kernel, dim3(blocks_for(long(B) * target)), dim3(kThreads), 0, ST(stream), x, ker, out, B, L,
+                     orig, newf, width, target);
+  return sept::launch_check("resample_kernel");
 }
 
 extern "C" int sept_sgd_step(float* p, const float* g, float* momentum_buf, long n, float lr, float momentum,

@@ -22,6 +22,7 @@ if _PKG not in sys.path:
 
 from sept_amd.mel import LAYOUT_BFT, LAYOUT_BTF, get_mel_plan  # noqa: E402
 from sept_amd.mfcc import mfcc_with_deltas  # noqa: E402
+from sept_amd.resample import Resample  # noqa: E402,F401  (torchaudio.transforms.Resample stand-in, reference :139-141)
 
 
 def mfcc(audio):

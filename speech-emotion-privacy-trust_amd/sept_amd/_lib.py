@@ -95,6 +95,7 @@ SIGNATURES = {
     "sept_window_norm_spk": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                      c_int, c_void_p]),
     "sept_add_normal": (c_int, [c_void_p, c_void_p, c_long, c_float, c_ulonglong, c_void_p, c_ulonglong, c_void_p]),
+    "sept_resample_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_int, c_long, c_void_p]),
     "sept_gru_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                               c_void_p, c_void_p]),
     "sept_topdb_clamp": (c_int, [c_void_p, c_int, c_long, c_float, c_void_p]),

@@ -160,3 +160,16 @@ def test_mfcc_with_deltas_vs_oracle():
     full = mfcc_batched(xb.cuda())
     for i in range(3):
         assert torch.allclose(mfcc_batched(xb[i:i + 1].cuda()), full[i:i + 1], atol=1e-4)
+
+
+@pytest.mark.parametrize("orig,new,L", [(44100, 16000, 66150), (48000, 16000, 4801), (22050, 16000, 10000)])
+def test_resample_vs_oracle(orig, new, L):
+    """sept_resample_forward (polyphase sinc FIR) vs the torchaudio restatement (conv1d with stride)."""
+    from feature_extraction.audio_feature_extraction import Resample
+    torch.manual_seed(orig)
+    x = torch.randn(2, L) * 0.3
+    got = Resample(orig, new)(x.cuda()).cpu()
+    want = mo.resample_torch(x, orig, new)
+    assert got.shape == want.shape
+    assert float((got - want).abs().max()) < 2e-5
+    assert Resample(16000, 16000)(x.cuda()).data_ptr() is not None

@@ -1,6 +1,7 @@
 """CPU tests pinning the feature ORACLE (oracle/mel_oracle.py): analytic known answers,
 float32-vs-float64 agreement, filterbank structure and the committed golden slices.
 The reference ships no tests for this path, so these are the pins."""
+import math
 import os
 
 import numpy as np
@@ -124,3 +125,20 @@ def test_mfcc_oracle_identities():
     assert full.shape == (1, 120, 41)
     np.testing.assert_allclose(full[:, :40], m)
     np.testing.assert_allclose(full[:, 80:], mo.mfcc_f64(np.gradient(x[0], 2)[None]))
+
+
+def test_resample_oracle_properties():
+    """Resample restatement (audio_feature_extraction.py:139-141): length rule, DC gain ~ 1, an in-band
+    tone keeps its frequency and amplitude, a tone above the new Nyquist is removed."""
+    sr, new = 44100, 16000
+    n = 44100
+    t = torch.arange(n, dtype=torch.float64) / sr
+    y = mo.resample_torch(torch.ones(1, n), sr, new)
+    assert y.shape == (1, 16000) and abs(float(y[0, 200:-200].mean()) - 1.0) < 2e-3
+    tone = torch.sin(2 * math.pi * 1000.0 * t).float()[None]
+    y = mo.resample_torch(tone, sr, new)[0, 400:-400]
+    want = torch.sin(2 * math.pi * 1000.0 * torch.arange(16000, dtype=torch.float64) / new)[400:-400]
+    assert float((y.double() - want).abs().max()) < 2e-2
+    high = torch.sin(2 * math.pi * 12000.0 * t).float()[None]
+    assert float(mo.resample_torch(high, sr, new)[0, 400:-400].abs().max()) < 2e-2
+    assert mo.resample_torch(torch.ones(2, 3, 301), 48000, 16000).shape == (2, 3, 101)
