@@ -129,6 +129,26 @@ int sept_bn_relu_pool_backward(const void* dy_bf16, const void* x_bf16, const fl
                                void* dx_bf16, float* dgamma, float* dbeta, int B, int H, int W, int C, int pool,
                                void* stream);
 
+/* Sync-BN pieces (statistics over the GLOBAL batch of a data-parallel step; off by default).  The two
+ * fused entries above split where the per-channel sums exist so the caller can all-reduce them:
+ *   forward:  sept_bn_partial_sums -> sums (2C doubles: sum, sum of squares) of this rank's rows;
+ *             [all-reduce SUM];  sept_bn_stats_from_sums(sums, n_total rows over all ranks, ...)
+ *   backward: sept_bn_relu_pool_backward_reduce -> sums (2C floats: sum dy, sum dy*xhat; dgamma / dbeta are
+ *             the LOCAL sums, the data-parallel gradient average does the rest);  [all-reduce SUM];
+ *             sept_bn_relu_pool_backward_apply(..., sums, n_total elements per channel over all ranks, dx). */
+int sept_bn_partial_sums(const void* x, long n_rows, int C, float* ws, double* sums, void* stream);
+int sept_bn_stats_from_sums(const double* sums, double n_total, int C, float* mean, float* invstd,
+                            float* running_mean, float* running_var, long long* num_batches_tracked,
+                            float momentum, float eps, void* stream);
+int sept_bn_relu_pool_backward_reduce(const void* dy, const void* x, const float* mean, const float* invstd,
+                                      const float* gamma, const float* beta, const float* dropscale,
+                                      float* ws, float* sums, float* dgamma, float* dbeta, int B, int H,
+                                      int W, int C, int pool, void* stream);
+int sept_bn_relu_pool_backward_apply(const void* dy, const void* x, const float* mean, const float* invstd,
+                                     const float* gamma, const float* beta, const float* dropscale,
+                                     const float* sums, double n_total, void* dx, int B, int H, int W,
+                                     int C, int pool, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Linear layers / GRU projections: C[M][N] = alpha * A(M,K) B(K,N) (+ bias[N]) (+ beta * C)
  * on the exact-fp32 MFMA.  A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn] (element

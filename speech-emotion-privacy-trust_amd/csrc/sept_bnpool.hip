@@ -97,6 +97,35 @@ __global__ void sept_bn_stats_finalize_kernel(const float* ws, int nparts, int C
   }
 }
 
+// sync-BN pieces: float64 per-channel (sum, sum of squares) of this rank's shard, and the statistics
+// from sums that were added up over the ranks
+__global__ void sept_bn_sums_kernel(const float* ws, int nparts, int C, double* sums) {
+  const int c = blockIdx.x;
+  const double s = sept::wave_sum_partials(ws, nparts, size_t(2) * C, c);
+  const double ss = sept::wave_sum_partials(ws, nparts, size_t(2) * C, size_t(C) + c);
+  if (threadIdx.x == 0) {
+    sums[c] = s;
+    sums[C + c] = ss;
+  }
+}
+__global__ void sept_bn_from_sums_kernel(const double* sums, int C, double n, float* mean, float* invstd,
+                                         float* running_mean, float* running_var, long long* nbt, float momentum,
+                                         float eps) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  if (c == 0 && nbt) *nbt += 1;
+  const double m = sums[c] / n;
+  double var = sums[C + c] / n - m * m;
+  var = var < 0 ? 0 : var;
+  mean[c] = float(m);
+  invstd[c] = float(1.0 / sqrt(var + double(eps)));
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * float(m);
+  if (running_var) {
+    const double unbiased = n > 1 ? var * n / (n - 1) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * float(unbiased);
+  }
+}
+
 __global__ void sept_bn_eval_stats_kernel(const float* rm, const float* rv, int C, float eps, float* mean,
                                           float* invstd) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -147,6 +176,8 @@ struct BnBwdArgs {
   float* ws;        // partials [kParts][2C], then sums at ws + kParts*2C
   bf16* dx;         // [B][H][W][C]
   int B, H, W, C, pool;
+  const float* sums;  // [2C] sum dy, sum dy*xhat used by the apply pass (the local ones in ws, or all-reduced ones)
+  float inv_n;        // 1 / (elements per channel the sums cover): local B*H*W, or the global count under sync-BN
 };
 
 // For one pooled position: the gradient reaching the pre-BN tensor is non-zero at one
@@ -211,7 +242,7 @@ __global__ __launch_bounds__(256) void sept_bn_bwd_reduce_kernel(BnBwdArgs a) {
   block_reduce_2c<CPP>(s1, s2, a.ws + size_t(blockIdx.x) * 2 * CPP * 8, lds);
 }
 
-__global__ void sept_bn_bwd_finalize_kernel(float* ws, int nparts, int C, float* dgamma, float* dbeta) {
+__global__ void sept_bn_bwd_finalize_kernel(float* ws, int nparts, int C, float* dgamma, float* dbeta, float* sums_out) {
   const int c = blockIdx.x;  // one wave per channel
   const double s1 = sept::wave_sum_partials(ws, nparts, size_t(2) * C, c);
   const double s2 = sept::wave_sum_partials(ws, nparts, size_t(2) * C, size_t(C) + c);
@@ -221,6 +252,10 @@ __global__ void sept_bn_bwd_finalize_kernel(float* ws, int nparts, int C, float*
   sums[C + c] = float(s2);  // sum dy*xhat (= dgamma)
   if (dbeta) dbeta[c] = float(s1);
   if (dgamma) dgamma[c] = float(s2);
+  if (sums_out) {
+    sums_out[c] = float(s1);
+    sums_out[C + c] = float(s2);
+  }
 }
 
 template <int CPP, int P>
@@ -232,8 +267,8 @@ __global__ __launch_bounds__(256) void sept_bn_bwd_apply_kernel(BnBwdArgs a) {
   const f32x8 mu = loadf8(a.mean + chunk * 8), is = loadf8(a.invstd + chunk * 8);
   const f32x8 ga = loadf8(a.gamma + chunk * 8), be = loadf8(a.beta + chunk * 8);
   const f32x8 sc = ga * is, sh = be - mu * ga * is;
-  const float* sums = a.ws + size_t(kParts) * 2 * C;
-  const float inv_n = 1.0f / (float(a.B) * a.H * a.W);
+  const float* sums = a.sums;
+  const float inv_n = a.inv_n;
   const f32x8 m1 = loadf8(sums + chunk * 8) * inv_n, m2 = loadf8(sums + C + chunk * 8) * inv_n;
   for (long i = long(blockIdx.x) * 256 + threadIdx.x; i < n_items; i += long(gridDim.x) * 256) {
     const long px = i / CPP;
@@ -322,6 +357,32 @@ extern "C" int sept_bn_relu_pool_forward(const void* x, const float* mean, const
   return sept::launch_check("sept_bn_relu_pool_fwd_kernel");
 }
 
+namespace {
+int bn_bwd_launch_reduce(BnBwdArgs& a, float* dgamma, float* dbeta, float* sums_out, hipStream_t st) {
+  const int C = a.C, pool = a.pool;
+  const long items = long(a.B) * (a.H / pool) * (a.W / pool) * (C / 8);
+  const int grid = grid_for(items);
+  if (pool == 2) {
+    SEPT_CPP_DISPATCH(C, hipLaunchKernelGGL((sept_bn_bwd_reduce_kernel<CPP, 2>), dim3(grid), dim3(256), 0, st, a));
+  } else {
+    SEPT_CPP_DISPATCH(C, hipLaunchKernelGGL((sept_bn_bwd_reduce_kernel<CPP, 1>), dim3(grid), dim3(256), 0, st, a));
+  }
+  hipLaunchKernelGGL(sept_bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, a.ws, grid, C, dgamma, dbeta, sums_out);
+  return SEPT_OK;
+}
+int bn_bwd_launch_apply(BnBwdArgs& a, hipStream_t st) {
+  const int C = a.C, pool = a.pool;
+  const long items = long(a.B) * (a.H / pool) * (a.W / pool) * (C / 8);
+  const int grid2 = int(std::min<long>((items + 255) / 256, 4096));
+  if (pool == 2) {
+    SEPT_CPP_DISPATCH(C, hipLaunchKernelGGL((sept_bn_bwd_apply_kernel<CPP, 2>), dim3(grid2), dim3(256), 0, st, a));
+  } else {
+    SEPT_CPP_DISPATCH(C, hipLaunchKernelGGL((sept_bn_bwd_apply_kernel<CPP, 1>), dim3(grid2), dim3(256), 0, st, a));
+  }
+  return SEPT_OK;
+}
+}  // namespace
+
 extern "C" int sept_bn_relu_pool_backward(const void* dy, const void* x, const float* mean, const float* invstd,
                                           const float* gamma, const float* beta, const float* dropscale,
                                           float* ws, void* dx, float* dgamma, float* dbeta, int B, int H, int W,
@@ -333,20 +394,59 @@ extern "C" int sept_bn_relu_pool_backward(const void* dy, const void* x, const f
                "sept_bn_relu_pool_backward: null argument");
   hipStream_t st = static_cast<hipStream_t>(stream);
   BnBwdArgs a{static_cast<const bf16*>(dy), static_cast<const bf16*>(x), mean, invstd, gamma, beta, dropscale,
-              ws, static_cast<bf16*>(dx), B, H, W, C, pool};
-  const long items = long(B) * (H / pool) * (W / pool) * (C / 8);
-  const int grid = grid_for(items);
-  if (pool == 2) {
-    SEPT_CPP_DISPATCH(C, hipLaunchKernelGGL((sept_bn_bwd_reduce_kernel<CPP, 2>), dim3(grid), dim3(256), 0, st, a));
-  } else {
-    SEPT_CPP_DISPATCH(C, hipLaunchKernelGGL((sept_bn_bwd_reduce_kernel<CPP, 1>), dim3(grid), dim3(256), 0, st, a));
-  }
-  hipLaunchKernelGGL(sept_bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, ws, grid, C, dgamma, dbeta);
-  const int grid2 = int(std::min<long>((items + 255) / 256, 4096));
-  if (pool == 2) {
-    SEPT_CPP_DISPATCH(C, hipLaunchKernelGGL((sept_bn_bwd_apply_kernel<CPP, 2>), dim3(grid2), dim3(256), 0, st, a));
-  } else {
-    SEPT_CPP_DISPATCH(C, hipLaunchKernelGGL((sept_bn_bwd_apply_kernel<CPP, 1>), dim3(grid2), dim3(256), 0, st, a));
-  }
+              ws, static_cast<bf16*>(dx), B, H, W, C, pool, ws + size_t(kParts) * 2 * C,
+              1.0f / (float(B) * H * W)};
+  if (int e = bn_bwd_launch_reduce(a, dgamma, dbeta, nullptr, st)) return e;
+  if (int e = bn_bwd_launch_apply(a, st)) return e;
   return sept::launch_check("sept_bn_relu_pool_backward");
+}
+
+// ---- sync-BN (statistics over all ranks; SURVEY.md section 8e option 1): the fused entry points split
+// at the point where the per-channel sums exist, so the caller can all-reduce them in between ----
+extern "C" int sept_bn_partial_sums(const void* x, long n_rows, int C, float* ws, double* sums, void* stream) {
+  SEPT_REQUIRE(x && ws && sums && n_rows > 0, SEPT_ERR_INVALID, "sept_bn_partial_sums: bad argument");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const long items = n_rows * (C / 8);
+  const int grid = grid_for(items);
+  SEPT_CPP_DISPATCH(C, hipLaunchKernelGGL(sept_bn_stats_partial_kernel<CPP>, dim3(grid), dim3(256), 0, st,
+                                          static_cast<const bf16*>(x), items, ws));
+  hipLaunchKernelGGL(sept_bn_sums_kernel, dim3(C), dim3(64), 0, st, ws, grid, C, sums);
+  return sept::launch_check("sept_bn_partial_sums");
+}
+
+extern "C" int sept_bn_stats_from_sums(const double* sums, double n_total, int C, float* mean, float* invstd,
+                                       float* running_mean, float* running_var, long long* num_batches_tracked,
+                                       float momentum, float eps, void* stream) {
+  SEPT_REQUIRE(sums && mean && invstd && n_total > 0 && C > 0, SEPT_ERR_INVALID, "sept_bn_stats_from_sums: bad argument");
+  hipLaunchKernelGGL(sept_bn_from_sums_kernel, dim3((C + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), sums, C,
+                     n_total, mean, invstd, running_mean, running_var, num_batches_tracked, momentum, eps);
+  return sept::launch_check("sept_bn_stats_from_sums");
+}
+
+extern "C" int sept_bn_relu_pool_backward_reduce(const void* dy, const void* x, const float* mean, const float* invstd,
+                                                 const float* gamma, const float* beta, const float* dropscale,
+                                                 float* ws, float* sums, float* dgamma, float* dbeta, int B, int H,
+                                                 int W, int C, int pool, void* stream) {
+  SEPT_REQUIRE(B > 0 && H > 0 && W > 0 && (pool == 1 || pool == 2), SEPT_ERR_INVALID,
+               "sept_bn_relu_pool_backward_reduce: B=%d H=%d W=%d pool=%d", B, H, W, pool);
+  SEPT_REQUIRE(dy && x && mean && invstd && gamma && beta && ws && sums, SEPT_ERR_INVALID,
+               "sept_bn_relu_pool_backward_reduce: null argument");
+  BnBwdArgs a{static_cast<const bf16*>(dy), static_cast<const bf16*>(x), mean, invstd, gamma, beta, dropscale,
+              ws, nullptr, B, H, W, C, pool, nullptr, 0.f};
+  if (int e = bn_bwd_launch_reduce(a, dgamma, dbeta, sums, static_cast<hipStream_t>(stream))) return e;
+  return sept::launch_check("sept_bn_relu_pool_backward_reduce");
+}
+
+extern "C" int sept_bn_relu_pool_backward_apply(const void* dy, const void* x, const float* mean, const float* invstd,
+                                                const float* gamma, const float* beta, const float* dropscale,
+                                                const float* sums, double n_total, void* dx, int B, int H, int W,
+                                                int C, int pool, void* stream) {
+  SEPT_REQUIRE(B > 0 && H > 0 && W > 0 && (pool == 1 || pool == 2) && n_total > 0, SEPT_ERR_INVALID,
+               "sept_bn_relu_pool_backward_apply: B=%d H=%d W=%d pool=%d", B, H, W, pool);
+  SEPT_REQUIRE(dy && x && mean && invstd && gamma && beta && sums && dx, SEPT_ERR_INVALID,
+               "sept_bn_relu_pool_backward_apply: null argument");
+  BnBwdArgs a{static_cast<const bf16*>(dy), static_cast<const bf16*>(x), mean, invstd, gamma, beta, dropscale,
+              nullptr, static_cast<bf16*>(dx), B, H, W, C, pool, sums, float(1.0 / n_total)};
+  if (int e = bn_bwd_launch_apply(a, static_cast<hipStream_t>(stream))) return e;
+  return sept::launch_check("sept_bn_relu_pool_backward_apply");
 }

@@ -2,7 +2,7 @@
 library has not been built: the product path never falls back to CPU/eager code."""
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int, c_long, c_size_t, c_ulonglong, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_long, c_size_t, c_ulonglong, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "..", "csrc", "libsept_hip.so")
@@ -96,6 +96,11 @@ SIGNATURES = {
                                      c_int, c_void_p]),
     "sept_add_normal": (c_int, [c_void_p, c_void_p, c_long, c_float, c_ulonglong, c_void_p, c_ulonglong, c_void_p]),
     "sept_resample_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_int, c_long, c_void_p]),
+    "sept_bn_partial_sums": (c_int, [c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p]),
+    "sept_bn_stats_from_sums": (c_int, [c_void_p, c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_float, c_float, c_void_p]),
+    "sept_bn_relu_pool_backward_reduce": (c_int, [c_void_p] * 11 + [c_int] * 5 + [c_void_p]),
+    "sept_bn_relu_pool_backward_apply": (c_int, [c_void_p] * 8 + [c_double, c_void_p] + [c_int] * 5 + [c_void_p]),
     "sept_gru_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                               c_void_p, c_void_p]),
     "sept_topdb_clamp": (c_int, [c_void_p, c_int, c_long, c_float, c_void_p]),

@@ -118,6 +118,17 @@ def _drop_mask(shape, device, p=DROP_P):
     return ops.rng(device, "dropout").dropout_mask(shape, p)
 
 
+# sync-BN (option 1): when enabled, BatchNorm statistics and the two backward
+# sums are all-reduced over the process group, so a data-parallel step sees the statistics of the
+# global batch.  Off by default (per-rank statistics, option 2).
+_SYNC_BN = {"on": False, "group": None}
+
+
+def set_sync_bn(enabled: bool, group=None):
+    _SYNC_BN["on"] = bool(enabled) and torch.distributed.is_available() and torch.distributed.is_initialized()
+    _SYNC_BN["group"] = group
+
+
 def _drop_masks(device, specs):
     """All dropout scale masks of one forward in one launch per distinct p: `specs` is a list of
     (key, shape, p); returns {key: mask} for the entries with p > 0."""
@@ -171,7 +182,8 @@ def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None, gfeat=Non
             pre = ops.conv5x5(act, wt, cv.bias)
         if bn.training:
             mean, invstd = ops.bn_stats(pre, bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                                        bn.momentum if bn.momentum is not None else 0.1, bn.eps)
+                                        bn.momentum if bn.momentum is not None else 0.1, bn.eps,
+                                        sync_group=_SYNC_BN["group"], sync=_SYNC_BN["on"])
         else:
             mean, invstd = ops.bn_eval_stats(bn.running_mean, bn.running_var, bn.eps)
         drop = None
@@ -180,7 +192,7 @@ def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None, gfeat=Non
             drop = d2[li] if d2 is not None else masks[("c", li)]
         out = ops.bn_relu_pool_forward(pre, mean, invstd, bn.weight, bn.bias, drop, pool)
         S.blocks.append(SimpleNamespace(inp=act, pre=pre, mean=mean, invstd=invstd, drop=drop, pool=pool, h=h, w=w,
-                                        bn_train=bn.training))
+                                        bn_train=bn.training, sync=_SYNC_BN["on"] and bn.training))
         act = out
         h, w = h // pool, w // pool
     # ---- GRU: (B, T=h, D = w*C) with NHWC feature order (w, c) ----
@@ -329,7 +341,8 @@ def trunk_backward(S, P, dlogits, need_wgrad=True, need_dx=True):
             raise SeptError("backward through an eval-mode BatchNorm is not implemented on the HIP path")
         want_bn = need_wgrad and bn.weight.requires_grad
         dpre, dgamma, dbeta = ops.bn_relu_pool_backward(dact, blk.pre, blk.mean, blk.invstd, bn.weight, bn.bias,
-                                                        blk.drop, blk.pool, need_param_grads=want_bn)
+                                                        blk.drop, blk.pool, need_param_grads=want_bn,
+                                                        sync_group=_SYNC_BN["group"], sync=blk.sync)
         if want_bn:
             put(bn.weight, dgamma)
             put(bn.bias, dbeta)

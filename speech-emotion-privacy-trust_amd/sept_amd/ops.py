@@ -120,14 +120,30 @@ def conv1_backward_weight(x, dy, need_bias=True):
     return dw, db
 
 
-def bn_stats(x, running_mean=None, running_var=None, num_batches_tracked=None, momentum=0.1, eps=1e-5):
-    """x (..., C) bf16 -> (mean, invstd) fp32 [C]; updates the running buffers in place."""
+def _allreduce_sum(t, group):
+    torch.distributed.all_reduce(t, group=group)
+    return torch.distributed.get_world_size(group)
+
+
+def bn_stats(x, running_mean=None, running_var=None, num_batches_tracked=None, momentum=0.1, eps=1e-5, sync_group=None,
+             sync=False):
+    """x (..., C) bf16 -> (mean, invstd) fp32 [C]; updates the running buffers in place.  With
+    sync=True the per-channel float64 sums are all-reduced over `sync_group` first (sync-BN:
+    statistics of the global batch, equal shards)."""
     require_cuda(x)
     C = x.shape[-1]
     n = x.numel() // C
     ws = workspace("bn", lib.sept_bn_workspace_floats(C), x.device)
     mean = torch.empty(C, dtype=torch.float32, device=x.device)
     invstd = torch.empty_like(mean)
+    if sync:
+        sums = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+        check(lib.sept_bn_partial_sums(x.data_ptr(), n, C, ws.data_ptr(), sums.data_ptr(), _s(x)), "sept_bn_partial_sums")
+        world = _allreduce_sum(sums, sync_group)
+        check(lib.sept_bn_stats_from_sums(sums.data_ptr(), float(n) * world, C, mean.data_ptr(), invstd.data_ptr(),
+                                          _p(running_mean), _p(running_var), _p(num_batches_tracked), float(momentum),
+                                          float(eps), _s(x)), "sept_bn_stats_from_sums")
+        return mean, invstd
     check(lib.sept_bn_stats(x.data_ptr(), n, C, ws.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _p(running_mean),
                             _p(running_var), _p(num_batches_tracked), float(momentum), float(eps), _s(x)),
           "sept_bn_stats")
@@ -153,13 +169,28 @@ def bn_relu_pool_forward(x, mean, invstd, gamma, beta, dropscale=None, pool=2):
     return y
 
 
-def bn_relu_pool_backward(dy, x, mean, invstd, gamma, beta, dropscale=None, pool=2, need_param_grads=True):
+def bn_relu_pool_backward(dy, x, mean, invstd, gamma, beta, dropscale=None, pool=2, need_param_grads=True,
+                          sync_group=None, sync=False):
+    """With sync=True the (sum dy, sum dy*xhat) pair is all-reduced between the reduce and the apply pass
+    (sync-BN); dgamma / dbeta stay the local sums -- the data-parallel gradient average finishes them."""
     require_cuda(dy, x)
     B, H, W, C = x.shape
     ws = workspace("bn", lib.sept_bn_workspace_floats(C), x.device)
     dx = torch.empty_like(x)
     dgamma = torch.empty(C, dtype=torch.float32, device=x.device) if need_param_grads else None
     dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if need_param_grads else None
+    if sync:
+        sums = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+        check(lib.sept_bn_relu_pool_backward_reduce(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                                    gamma.data_ptr(), beta.data_ptr(), _p(dropscale), ws.data_ptr(),
+                                                    sums.data_ptr(), _p(dgamma), _p(dbeta), B, H, W, C, pool, _s(x)),
+              "sept_bn_relu_pool_backward_reduce")
+        world = _allreduce_sum(sums, sync_group)
+        check(lib.sept_bn_relu_pool_backward_apply(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                                   gamma.data_ptr(), beta.data_ptr(), _p(dropscale), sums.data_ptr(),
+                                                   float(B) * H * W * world, dx.data_ptr(), B, H, W, C, pool, _s(x)),
+              "sept_bn_relu_pool_backward_apply")
+        return dx, dgamma, dbeta
     check(lib.sept_bn_relu_pool_backward(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
                                          gamma.data_ptr(), beta.data_ptr(), _p(dropscale), ws.data_ptr(),
                                          dx.data_ptr(), _p(dgamma), _p(dbeta), B, H, W, C, pool, _s(x)),

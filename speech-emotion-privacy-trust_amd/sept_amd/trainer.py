@@ -83,8 +83,9 @@ class FlatParams:
 
 class GrlTrainer:
     def __init__(self, cloak_model, optimizer="sgd", lr=None, momentum=0.9, weight_decay=1e-4, betas=(0.9, 0.98),
-                 eps=1e-9, gender_lambda=0.1, scale_lamda=0.0, suppression=False, process_group=None):
+                 eps=1e-9, gender_lambda=0.1, scale_lamda=0.0, suppression=False, process_group=None, sync_bn=False):
         self.model = cloak_model
+        self.sync_bn = sync_bn   # BatchNorm statistics of the GLOBAL batch (extra tiny all-reduces); default: per rank
         self.flat = FlatParams(cloak_model.parameters())  # filter(requires_grad), as :417/:420
         self.kind = optimizer
         if optimizer == "sgd":       # :417  SGD(lr=0.001, momentum=0.9, weight_decay=1e-4)
@@ -133,6 +134,7 @@ class GrlTrainer:
         self.model.train()
         self.flat.zero_grad()
         _advance_rng(features.device)
+        SF.set_sync_bn(self.sync_bn and self.world > 1, self.pg)
         preds, preds_grl, _ = self.model(features, global_feature=global_feature, mask=mask, grl=False, pooling=pooling)
         loss = self.loss(preds, preds_grl, labels_emo, labels_gen, weights, training=True)
         loss.backward()

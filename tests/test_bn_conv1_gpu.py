@@ -92,3 +92,52 @@ def test_bn_eval_stats():
     rm, rv = torch.randn(64).cuda(), (torch.rand(64) + 0.5).cuda()
     mean, invstd = ops.bn_eval_stats(rm, rv)
     assert torch.equal(mean, rm) and torch.allclose(invstd, (rv + 1e-5).rsqrt(), rtol=1e-6)
+
+
+def test_sync_bn_split_entries_equal_global_batch():
+    """Sync-BN entry points (SURVEY.md 8e option 1): two 'ranks' = two halves of a batch on one GPU.
+    Summing their per-channel sums (what the all-reduce does) must reproduce the statistics, dx and
+    parameter gradients of the fused single-process pass over the whole batch."""
+    from sept_amd import ops
+    from sept_amd._lib import lib, check
+    g = torch.Generator().manual_seed(21)
+    B, H, W, C, pool = 4, 20, 12, 64, 2
+    x = (torch.randn(B, H, W, C, generator=g) * 1.5 + 0.3).bfloat16().cuda()
+    dy = torch.randn(B, H // pool, W // pool, C, generator=g).bfloat16().cuda()
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.1).cuda()
+    drop = (torch.rand(B, C, generator=g) > 0.2).float().cuda() * 1.25
+    s = torch.cuda.current_stream().cuda_stream
+    ws = ops.workspace("bn", lib.sept_bn_workspace_floats(C), x.device)
+    mean_f, invstd_f = ops.bn_stats(x)
+    halves = [slice(0, 2), slice(2, 4)]
+    tot = torch.zeros(2 * C, dtype=torch.float64, device="cuda")
+    for h in halves:
+        xs = x[h].contiguous()
+        sums = torch.empty(2 * C, dtype=torch.float64, device="cuda")
+        check(lib.sept_bn_partial_sums(xs.data_ptr(), xs.numel() // C, C, ws.data_ptr(), sums.data_ptr(), s), "sums")
+        tot += sums
+    mean, invstd = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    check(lib.sept_bn_stats_from_sums(tot.data_ptr(), float(B * H * W), C, mean.data_ptr(), invstd.data_ptr(), None, None,
+                                      None, 0.1, 1e-5, s), "from_sums")
+    assert torch.allclose(mean, mean_f, rtol=1e-6, atol=1e-6) and torch.allclose(invstd, invstd_f, rtol=1e-6)
+    dx_f, dg_f, db_f = ops.bn_relu_pool_backward(dy, x, mean_f, invstd_f, gamma, beta, drop, pool)
+    parts, tot_b = [], torch.zeros(2 * C, device="cuda")
+    for h in halves:
+        xs, dys, dr = x[h].contiguous(), dy[h].contiguous(), drop[h].contiguous()
+        sums, dg, db = torch.empty(2 * C, device="cuda"), torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+        check(lib.sept_bn_relu_pool_backward_reduce(dys.data_ptr(), xs.data_ptr(), mean_f.data_ptr(), invstd_f.data_ptr(),
+                                                    gamma.data_ptr(), beta.data_ptr(), dr.data_ptr(), ws.data_ptr(),
+                                                    sums.data_ptr(), dg.data_ptr(), db.data_ptr(), 2, H, W, C, pool, s), "red")
+        parts.append((xs, dys, dr, dg, db))
+        tot_b += sums
+    dxs = []
+    for xs, dys, dr, dg, db in parts:
+        dx = torch.empty_like(xs)
+        check(lib.sept_bn_relu_pool_backward_apply(dys.data_ptr(), xs.data_ptr(), mean_f.data_ptr(), invstd_f.data_ptr(),
+                                                   gamma.data_ptr(), beta.data_ptr(), dr.data_ptr(), tot_b.data_ptr(),
+                                                   float(B * H * W), dx.data_ptr(), 2, H, W, C, pool, s), "apply")
+        dxs.append(dx)
+    assert torch.allclose(torch.cat(dxs).float(), dx_f.float(), rtol=2e-2, atol=1e-3)
+    assert (torch.cat(dxs).float() - dx_f.float()).abs().mean() < 1e-5
+    assert torch.allclose(parts[0][3] + parts[1][3], dg_f, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(parts[0][4] + parts[1][4], db_f, rtol=1e-4, atol=1e-4)

@@ -1,0 +1,83 @@
+"""Two data-parallel ranks on ONE GPU (gloo carries the CUDA tensors): the sharded GRL step with
+sync-BN must reproduce the single-process step on the global batch -- gradient averaging over the
+flat buffer, one shared cloak epsilon, BatchNorm statistics and backward sums all-reduced
+(SURVEY.md section 8e).  Dropout is switched off so the two runs are comparable."""
+import os
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from tests.closed_form import closed_form_eps, closed_form_input, closed_form_labels, closed_form_state
+
+pytestmark = pytest.mark.gpu
+B, W, F = 8, 200, 80
+
+
+def _build():
+    import torch.nn as nn
+    from model import baseline_models as bm, cloak_models as cm
+    kw = dict(lstm_hidden_size=64, num_layers_lstm=2, attention_size=128, att=None, global_feature=0)
+    emo, gen = bm.two_d_cnn_lstm(1, F, 64, pred="emotion", **kw), bm.two_d_cnn_lstm(1, F, 64, pred="gender", **kw)
+    emo.load_state_dict(closed_form_state(emo, prefix="emotion."))
+    gen.load_state_dict(closed_form_state(gen, prefix="gender."))
+    noise = cm.cloak_noise(torch.zeros(1, W, F), torch.ones(1, W, F), torch.tensor(0.01), torch.tensor(10.0), "cuda")
+    noise.load_state_dict(closed_form_state(noise, prefix="noise."))
+    noise.eps = closed_form_eps(W, F).cuda()
+    m = cm.two_d_cnn_lstm_syn_with_grl(emo.cuda(), gen.cuda(), noise.cuda(), 0.1).cuda()
+    for mod in m.modules():
+        if isinstance(mod, (nn.Dropout, nn.Dropout2d)):
+            mod.p = 0.0
+        if isinstance(mod, nn.GRU):
+            mod.dropout = 0.0
+    return m
+
+
+def _step(model, sl, world_group=None, sync_bn=False):
+    from sept_amd.trainer import GrlTrainer
+    x = closed_form_input(B, W, F)[sl].cuda()
+    le, lg, w = closed_form_labels(B)
+    tr = GrlTrainer(model, optimizer="sgd", lr=0.05, gender_lambda=0.1, scale_lamda=0.05, sync_bn=sync_bn)
+    loss, _, _ = tr.train_step(x, le[sl].cuda(), lg[sl].cuda(), w[sl].cuda())
+    torch.cuda.synchronize()
+    return float(loss), {n: p.detach().float().cpu().clone() for n, p in model.named_parameters() if p.requires_grad}
+
+
+def _worker(rank, world, port, ret):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    per = B // world
+    loss, params = _step(_build(), slice(rank * per, (rank + 1) * per), sync_bn=True)
+    ret[rank] = (loss, params if rank == 0 else None)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_with_sync_bn_equal_global_batch_step():
+    before = {n: p.detach().float().cpu().clone() for n, p in _build().named_parameters() if p.requires_grad}
+    loss_full, full = _step(_build(), slice(0, B))
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    loss_dp = 0.5 * (ret[0][0] + ret[1][0])
+    # each rank's loss is a mean over its shard (+ the batch-independent scale term): the average is the global loss
+    assert loss_dp == pytest.approx(loss_full, rel=2e-3)
+    dp = ret[0][1]
+    worst = 0.0
+    for n in full:
+        d_full, d_dp = full[n] - before[n], dp[n] - before[n]
+        if float(d_full.norm()) < 1e-9:
+            assert float(d_dp.norm()) < 1e-6, n
+            continue
+        rel = float((d_dp - d_full).norm() / d_full.norm())
+        worst = max(worst, rel)
+        assert rel < 3e-2, (n, rel)     # the same update up to bf16 / summation-order noise
+    assert worst > 0.0                   # and the two code paths really are different computations
