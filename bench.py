@@ -204,11 +204,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    # rehearsal aids for a one-GPU box: SEPT_BENCH_DEVICE pins every rank to one device and
+    # SEPT_BENCH_BACKEND=gloo carries the collectives (RCCL refuses two ranks on one GPU)
+    if os.environ.get("SEPT_BENCH_DEVICE") is not None:
+        local = int(os.environ["SEPT_BENCH_DEVICE"])
+    backend = os.environ.get("SEPT_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend, rank=rank, world_size=world)
 
     import sept_amd
     from sept_amd import ops
