@@ -100,6 +100,13 @@ int sept_conv5x5_backward_weight(const void* x_bf16, const void* dy_bf16, float*
 size_t sept_conv1_prep_floats(void);
 int sept_conv1_forward(const float* x, const float* w, const float* bias, float* wprep, void* y_bf16, int B,
                        int H, int W, void* stream);
+/* The same forward that also leaves the BatchNorm statistics partials of its output (the nn.BatchNorm2d
+ * of baseline_models.py:173 then needs no pass of its own over the tensor): stats = [sept_conv1_stats_parts(B, H)]
+ * [64] floats (32 sums, 32 sums of squares of the bf16-rounded outputs per workgroup), finished by
+ * sept_bn_stats_from_partials. */
+int sept_conv1_stats_parts(int B, int H);
+int sept_conv1_forward_stats(const float* x, const float* w, const float* bias, float* wprep, void* y_bf16,
+                             float* stats, int B, int H, int W, void* stream);
 int sept_conv1_backward_data(const void* dy_bf16, const float* w, float* wprep, float* dx, int B, int H, int W,
                              void* stream);
 size_t sept_conv1_workspace_floats(void);
@@ -119,6 +126,9 @@ size_t sept_bn_workspace_floats(int C);
 int sept_bn_stats(const void* x_bf16, long n_rows, int C, float* ws, float* mean, float* invstd,
                   float* running_mean, float* running_var, long long* num_batches_tracked, float momentum,
                   float eps, void* stream);
+int sept_bn_stats_from_partials(const float* partials, int nparts, long n_rows, int C, float* mean,
+                                float* invstd, float* running_mean, float* running_var,
+                                long long* num_batches_tracked, float momentum, float eps, void* stream);
 int sept_bn_eval_stats(const float* running_mean, const float* running_var, int C, float eps, float* mean,
                        float* invstd, void* stream);
 int sept_bn_relu_pool_forward(const void* x_bf16, const float* mean, const float* invstd, const float* gamma,

@@ -331,6 +331,17 @@ extern "C" int sept_bn_stats(const void* x, long n_rows, int C, float* ws, float
   return sept::launch_check("sept_bn_stats");
 }
 
+// statistics from per-workgroup partials [nparts][2C] left by a producer kernel (sept_conv1_forward_stats)
+extern "C" int sept_bn_stats_from_partials(const float* partials, int nparts, long n_rows, int C, float* mean,
+                                           float* invstd, float* running_mean, float* running_var,
+                                           long long* num_batches_tracked, float momentum, float eps, void* stream) {
+  SEPT_REQUIRE(partials && mean && invstd && nparts > 0 && n_rows > 0 && C > 0, SEPT_ERR_INVALID,
+               "sept_bn_stats_from_partials: bad argument");
+  hipLaunchKernelGGL(sept_bn_stats_finalize_kernel, dim3(C), dim3(64), 0, static_cast<hipStream_t>(stream), partials, nparts,
+                     C, double(n_rows), mean, invstd, running_mean, running_var, num_batches_tracked, momentum, eps);
+  return sept::launch_check("sept_bn_stats_from_partials");
+}
+
 extern "C" int sept_bn_eval_stats(const float* running_mean, const float* running_var, int C, float eps,
                                   float* mean, float* invstd, void* stream) {
   SEPT_REQUIRE(running_mean && running_var && mean && invstd && C > 0, SEPT_ERR_INVALID,

@@ -103,9 +103,16 @@ __global__ __launch_bounds__(256) void sept_conv1_fwd_kernel(const float* __rest
 // the same row shifted by one tap, i.e. broadcasts, no bank conflicts).  Products are exact fp32
 // like the scalar form; the write of y (64 B per pixel) is what bounds the kernel.
 constexpr int kFwdRows = 16;  // output rows per workgroup
+constexpr int kStatLd = 33;   // floats per lane in the statistics exchange (odd: conflict-free)
+// STATS: the kernel also leaves this workgroup's per-channel (sum, sum of squares) of the bf16-rounded
+// outputs in stats[workgroup][64] -- the BatchNorm that follows (baseline_models.py:173) then needs
+// no pass of its own over the 64 B/pixel tensor.  Each lane keeps running sums of its 16 channels
+// over its blocks; they meet once per workgroup in LDS, added in a fixed order.
+template <bool STATS>
 __global__ __launch_bounds__(256) void sept_conv1_fwd_mfma_kernel(const float* __restrict__ x,
                                                                   const float* __restrict__ wprep,
-                                                                  bf16* __restrict__ y, int B, int H, int W) {
+                                                                  bf16* __restrict__ y, float* __restrict__ stats,
+                                                                  int B, int H, int W) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* tile = reinterpret_cast<float*>(smem);
   const int W4 = W + 4;
@@ -124,6 +131,11 @@ __global__ __launch_bounds__(256) void sept_conv1_fwd_mfma_kernel(const float* _
   __syncthreads();
   const int npx = nrows * W, nblk = (npx + 31) / 32;
   bf16* yb = y + (size_t(b) * H + h0) * W * kC;
+  float rs[STATS ? 16 : 1], rss[STATS ? 16 : 1];
+  if constexpr (STATS) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rs[r] = rss[r] = 0.f;
+  }
   for (int blk = wave; blk < nblk; blk += 4) {
     const int q = blk * 32 + c;
     const int qc = min(q, npx - 1);
@@ -148,6 +160,13 @@ __global__ __launch_bounds__(256) void sept_conv1_fwd_mfma_kernel(const float* _
         t[0] = (bf16)acc[4 * j + 2 * d];
         t[1] = (bf16)acc[4 * j + 2 * d + 1];
         pk[j][d] = __builtin_bit_cast(unsigned, t);
+        if constexpr (STATS) {   // statistics of what is stored (the rounded values), pixels past the end excluded
+          const float v0 = q < npx ? float(t[0]) : 0.f, v1 = q < npx ? float(t[1]) : 0.f;
+          rs[4 * j + 2 * d] += v0;
+          rss[4 * j + 2 * d] = fmaf(v0, v0, rss[4 * j + 2 * d]);
+          rs[4 * j + 2 * d + 1] += v1;
+          rss[4 * j + 2 * d + 1] = fmaf(v1, v1, rss[4 * j + 2 * d + 1]);
+        }
       }
     uint4 out[2];
 #pragma unroll
@@ -160,6 +179,25 @@ __global__ __launch_bounds__(256) void sept_conv1_fwd_mfma_kernel(const float* _
       uint4* yp = reinterpret_cast<uint4*>(yb + size_t(q) * kC + 16 * half);
       yp[0] = out[0];
       yp[1] = out[1];
+    }
+  }
+  if constexpr (STATS) {
+    __syncthreads();   // the staged rows are no longer needed: the exchange reuses their LDS
+    float* ex = reinterpret_cast<float*>(smem);   // [256 lanes][kStatLd]: 16 sums, 16 sums of squares
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      ex[threadIdx.x * kStatLd + r] = rs[r];
+      ex[threadIdx.x * kStatLd + 16 + r] = rss[r];
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * kC) {
+      // thread = (which statistic, channel); channel 8j + 4*hf + i lives in register 4j + i of the lanes with half hf
+      const int which = threadIdx.x / kC, ch = threadIdx.x % kC;
+      const int j = ch >> 3, hf = (ch >> 2) & 1, i = ch & 3;
+      float t = 0.f;
+      for (int w = 0; w < 4; ++w)
+        for (int l = 0; l < 32; ++l) t += ex[(w * 64 + hf * 32 + l) * kStatLd + which * 16 + 4 * j + i];
+      stats[(size_t(blockIdx.y) * gridDim.x + blockIdx.x) * (2 * kC) + threadIdx.x] = t;
     }
   }
 }
@@ -494,25 +532,48 @@ static int conv1_check(const char* what, int B, int H, int W) {
 
 extern "C" size_t sept_conv1_prep_floats(void) { return kPrepFloats; }
 
-extern "C" int sept_conv1_forward(const float* x, const float* w, const float* bias, float* wprep, void* y, int B,
-                                  int H, int W, void* stream) {
-  if (int e = conv1_check("sept_conv1_forward", B, H, W)) return e;
-  if (B == 0) return SEPT_OK;
-  SEPT_REQUIRE(x && w && y && wprep, SEPT_ERR_INVALID, "sept_conv1_forward: null argument");
-  hipStream_t st = static_cast<hipStream_t>(stream);
+namespace {
+int conv1_forward_impl(const float* x, const float* w, const float* bias, float* wprep, void* y, float* stats, int B,
+                       int H, int W, hipStream_t st) {
   hipLaunchKernelGGL(sept_conv1_prep_kernel, dim3((kTaps * kC + 255) / 256), dim3(256), 0, st, w, bias, wprep);
-  const size_t smem_m = sizeof(float) * size_t(kFwdRows + 4) * (W + 4);
+  const size_t smem_m = std::max(sizeof(float) * size_t(kFwdRows + 4) * (W + 4), stats ? sizeof(float) * 256 * kStatLd : 0);
   static const bool scalar_fwd = getenv("SEPT_CONV1_SCALAR") != nullptr;
-  if (smem_m <= 64 * 1024 && !scalar_fwd) {
-    hipLaunchKernelGGL(sept_conv1_fwd_mfma_kernel, dim3((H + kFwdRows - 1) / kFwdRows, B), dim3(256), smem_m, st, x,
-                       static_cast<const float*>(wprep), static_cast<bf16*>(y), B, H, W);
+  if (smem_m <= 64 * 1024 && (!scalar_fwd || stats)) {
+    const dim3 grid((H + kFwdRows - 1) / kFwdRows, B);
+    if (stats)
+      hipLaunchKernelGGL(sept_conv1_fwd_mfma_kernel<true>, grid, dim3(256), smem_m, st, x, static_cast<const float*>(wprep),
+                         static_cast<bf16*>(y), stats, B, H, W);
+    else
+      hipLaunchKernelGGL(sept_conv1_fwd_mfma_kernel<false>, grid, dim3(256), smem_m, st, x,
+                         static_cast<const float*>(wprep), static_cast<bf16*>(y), stats, B, H, W);
     return sept::launch_check("sept_conv1_fwd_mfma_kernel");
   }
+  SEPT_REQUIRE(!stats, SEPT_ERR_UNSUPPORTED, "sept_conv1_forward_stats: W=%d is too wide for the fused statistics", W);
   const size_t smem = sizeof(float) * size_t(nr_max(W)) * (W + 4);
   SEPT_HIP(sept::allow_max_lds(reinterpret_cast<const void*>(&sept_conv1_fwd_kernel)));
   hipLaunchKernelGGL(sept_conv1_fwd_kernel, dim3((H * W + kMT - 1) / kMT, B), dim3(256), smem, st, x,
                      static_cast<const float*>(wprep), static_cast<bf16*>(y), B, H, W);
   return sept::launch_check("sept_conv1_fwd_kernel");
+}
+}  // namespace
+
+extern "C" int sept_conv1_forward(const float* x, const float* w, const float* bias, float* wprep, void* y, int B, int H,
+                                  int W, void* stream) {
+  if (int e = conv1_check("sept_conv1_forward", B, H, W)) return e;
+  if (B == 0) return SEPT_OK;
+  SEPT_REQUIRE(x && w && y && wprep, SEPT_ERR_INVALID, "sept_conv1_forward: null argument");
+  return conv1_forward_impl(x, w, bias, wprep, y, nullptr, B, H, W, static_cast<hipStream_t>(stream));
+}
+
+// Forward + the BatchNorm statistics partials of the output: stats[sept_conv1_stats_parts(B, H)][64] floats
+// (per workgroup: 32 sums, 32 sums of squares), to be finished by sept_bn_stats_from_partials.
+extern "C" int sept_conv1_stats_parts(int B, int H) { return B * ((H + kFwdRows - 1) / kFwdRows); }
+
+extern "C" int sept_conv1_forward_stats(const float* x, const float* w, const float* bias, float* wprep, void* y,
+                                        float* stats, int B, int H, int W, void* stream) {
+  if (int e = conv1_check("sept_conv1_forward_stats", B, H, W)) return e;
+  SEPT_REQUIRE(B > 0 && x && w && y && wprep && stats, SEPT_ERR_INVALID, "sept_conv1_forward_stats: null argument / empty batch");
+  return conv1_forward_impl(x, w, bias, wprep, y, stats, B, H, W, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int sept_conv1_backward_data(const void* dy, const float* w, float* wprep, float* dx, int B, int H,

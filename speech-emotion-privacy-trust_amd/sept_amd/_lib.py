@@ -101,6 +101,11 @@ SIGNATURES = {
                                         c_float, c_float, c_void_p]),
     "sept_bn_relu_pool_backward_reduce": (c_int, [c_void_p] * 11 + [c_int] * 5 + [c_void_p]),
     "sept_bn_relu_pool_backward_apply": (c_int, [c_void_p] * 8 + [c_double, c_void_p] + [c_int] * 5 + [c_void_p]),
+    "sept_conv1_stats_parts": (c_int, [c_int, c_int]),
+    "sept_conv1_forward_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                         c_void_p]),
+    "sept_bn_stats_from_partials": (c_int, [c_void_p, c_int, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                            c_void_p, c_float, c_float, c_void_p]),
     "sept_gru_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                               c_void_p, c_void_p]),
     "sept_topdb_clamp": (c_int, [c_void_p, c_int, c_long, c_float, c_void_p]),

@@ -175,12 +175,19 @@ def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None, gfeat=Non
         masks = _drop_masks(dev, specs)
     for li, (cv, bn, pool) in enumerate(zip(P.convs, P.bns, P.pools)):
         cout = cv.weight.shape[0]
-        if li == 0:
+        fused_stats = li == 0 and bn.training and not _SYNC_BN["on"] and W + 4 <= 512
+        if fused_stats:   # conv1 leaves the statistics partials of its output: no BN pass over 64 B/pixel
+            pre, mean, invstd = ops.conv1_forward_stats(x, cv.weight, cv.bias, bn.running_mean, bn.running_var,
+                                                        bn.num_batches_tracked,
+                                                        bn.momentum if bn.momentum is not None else 0.1, bn.eps)
+        elif li == 0:
             pre = ops.conv1_forward(x, cv.weight, cv.bias)
         else:
             wt = _cached("convfwd", cv.weight, lambda: ops.conv5x5_prep_weights(cv.weight, 0))
             pre = ops.conv5x5(act, wt, cv.bias)
-        if bn.training:
+        if fused_stats:
+            pass
+        elif bn.training:
             mean, invstd = ops.bn_stats(pre, bn.running_mean, bn.running_var, bn.num_batches_tracked,
                                         bn.momentum if bn.momentum is not None else 0.1, bn.eps,
                                         sync_group=_SYNC_BN["group"], sync=_SYNC_BN["on"])

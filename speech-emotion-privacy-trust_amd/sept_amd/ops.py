@@ -99,6 +99,26 @@ def conv1_forward(x, w, bias=None):
     return y
 
 
+def conv1_forward_stats(x, w, bias, bn_running_mean=None, bn_running_var=None, bn_num_batches_tracked=None,
+                        momentum=0.1, eps=1e-5):
+    """conv1 forward that also yields the batch statistics of its output: (y bf16 (B,H,W,32), mean, invstd);
+    the following BatchNorm needs no statistics pass (and its running buffers are updated here)."""
+    require_cuda(x, w)
+    B, H, W = x.shape
+    y = torch.empty((B, H, W, 32), dtype=torch.bfloat16, device=x.device)
+    wp = workspace("conv1_prep_fwd", lib.sept_conv1_prep_floats(), x.device)
+    nparts = lib.sept_conv1_stats_parts(B, H)
+    parts = workspace("conv1_stats", nparts * 64, x.device)
+    check(lib.sept_conv1_forward_stats(x.data_ptr(), w.data_ptr(), _p(bias), wp.data_ptr(), y.data_ptr(), parts.data_ptr(),
+                                       B, H, W, _s(x)), "sept_conv1_forward_stats")
+    mean = torch.empty(32, dtype=torch.float32, device=x.device)
+    invstd = torch.empty_like(mean)
+    check(lib.sept_bn_stats_from_partials(parts.data_ptr(), nparts, B * H * W, 32, mean.data_ptr(), invstd.data_ptr(),
+                                          _p(bn_running_mean), _p(bn_running_var), _p(bn_num_batches_tracked),
+                                          float(momentum), float(eps), _s(x)), "sept_bn_stats_from_partials")
+    return y, mean, invstd
+
+
 def conv1_backward_data(dy, w):
     require_cuda(dy, w)
     B, H, W, _ = dy.shape

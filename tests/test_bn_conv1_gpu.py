@@ -141,3 +141,21 @@ def test_sync_bn_split_entries_equal_global_batch():
     assert (torch.cat(dxs).float() - dx_f.float()).abs().mean() < 1e-5
     assert torch.allclose(parts[0][3] + parts[1][3], dg_f, rtol=1e-4, atol=1e-4)
     assert torch.allclose(parts[0][4] + parts[1][4], db_f, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("B,H,W", [(3, 200, 80), (2, 37, 23), (1, 16, 128)])
+def test_conv1_forward_with_fused_bn_statistics(B, H, W):
+    """sept_conv1_forward_stats: same output as the plain forward, and the statistics it leaves equal a
+    BatchNorm statistics pass over that output (mean / invstd and the running buffers)."""
+    from sept_amd import ops
+    g = torch.Generator().manual_seed(W)
+    x = torch.randn(B, H, W, generator=g).cuda()
+    w = (torch.randn(32, 1, 5, 5, generator=g) * 0.2).cuda()
+    bias = (torch.randn(32, generator=g) * 0.1).cuda()
+    rm, rv, nb = torch.zeros(32).cuda(), torch.ones(32).cuda(), torch.zeros((), dtype=torch.int64).cuda()
+    y, mean, invstd = ops.conv1_forward_stats(x, w, bias, rm, rv, nb)
+    assert torch.equal(y, ops.conv1_forward(x, w, bias))
+    rm2, rv2, nb2 = torch.zeros(32).cuda(), torch.ones(32).cuda(), torch.zeros((), dtype=torch.int64).cuda()
+    mean2, invstd2 = ops.bn_stats(y, rm2, rv2, nb2)
+    assert torch.allclose(mean, mean2, rtol=1e-5, atol=1e-6) and torch.allclose(invstd, invstd2, rtol=1e-5)
+    assert torch.allclose(rm, rm2, rtol=1e-5, atol=1e-7) and torch.allclose(rv, rv2, rtol=1e-5) and int(nb) == 1
