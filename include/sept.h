@@ -101,9 +101,9 @@ size_t sept_conv1_prep_floats(void);
 int sept_conv1_forward(const float* x, const float* w, const float* bias, float* wprep, void* y_bf16, int B,
                        int H, int W, void* stream);
 /* The same forward that also leaves the BatchNorm statistics partials of its output (the nn.BatchNorm2d
- * of baseline_models.py:173 then needs no pass of its own over the tensor): stats = [sept_conv1_stats_parts(B, H)]
- * [64] floats (32 sums, 32 sums of squares of the bf16-rounded outputs per workgroup), finished by
- * sept_bn_stats_from_partials. */
+ * of baseline_models.py:173 then needs no pass of its own over the tensor): stats = [64][sept_conv1_stats_parts(B, H)]
+ * floats (32 sums then 32 sums of squares of the bf16-rounded outputs, one column per workgroup), finished by
+ * sept_bn_stats_from_partials (partials [2C][nparts]). */
 int sept_conv1_stats_parts(int B, int H);
 int sept_conv1_forward_stats(const float* x, const float* w, const float* bias, float* wprep, void* y_bf16,
                              float* stats, int B, int H, int W, void* stream);

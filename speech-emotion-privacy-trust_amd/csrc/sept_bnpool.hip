@@ -331,14 +331,45 @@ extern "C" int sept_bn_stats(const void* x, long n_rows, int C, float* ws, float
   return sept::launch_check("sept_bn_stats");
 }
 
-// statistics from per-workgroup partials [nparts][2C] left by a producer kernel (sept_conv1_forward_stats)
+// finalize over TRANSPOSED partials [2C][nparts] (one workgroup per channel; threads 0-127 add up the
+// sums, 128-255 the sums of squares, in float64 and in a fixed order)
+__global__ __launch_bounds__(256) void sept_bn_stats_finalize_t_kernel(const float* parts, int nparts, int C, double n,
+                                                                       float* mean, float* invstd, float* running_mean,
+                                                                       float* running_var, long long* nbt, float momentum,
+                                                                       float eps) {
+  __shared__ double red[256];
+  const int c = blockIdx.x, which = threadIdx.x >> 7, t = threadIdx.x & 127;
+  const float* p = parts + (size_t(which) * C + c) * nparts;
+  double acc = 0.0;
+  for (int i = t; i < nparts; i += 128) acc += double(p[i]);
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int k = 64; k > 0; k >>= 1) {
+    if (t < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  if (c == 0 && nbt) *nbt += 1;
+  const double m = red[0] / n;
+  double var = red[128] / n - m * m;
+  var = var < 0 ? 0 : var;
+  mean[c] = float(m);
+  invstd[c] = float(1.0 / sqrt(var + double(eps)));
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * float(m);
+  if (running_var) {
+    const double unbiased = n > 1 ? var * n / (n - 1) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * float(unbiased);
+  }
+}
+
+// statistics from per-workgroup partials, TRANSPOSED [2C][nparts], left by a producer kernel (sept_conv1_forward_stats)
 extern "C" int sept_bn_stats_from_partials(const float* partials, int nparts, long n_rows, int C, float* mean,
                                            float* invstd, float* running_mean, float* running_var,
                                            long long* num_batches_tracked, float momentum, float eps, void* stream) {
   SEPT_REQUIRE(partials && mean && invstd && nparts > 0 && n_rows > 0 && C > 0, SEPT_ERR_INVALID,
                "sept_bn_stats_from_partials: bad argument");
-  hipLaunchKernelGGL(sept_bn_stats_finalize_kernel, dim3(C), dim3(64), 0, static_cast<hipStream_t>(stream), partials, nparts,
-                     C, double(n_rows), mean, invstd, running_mean, running_var, num_batches_tracked, momentum, eps);
+  hipLaunchKernelGGL(sept_bn_stats_finalize_t_kernel, dim3(C), dim3(256), 0, static_cast<hipStream_t>(stream), partials,
+                     nparts, C, double(n_rows), mean, invstd, running_mean, running_var, num_batches_tracked, momentum, eps);
   return sept::launch_check("sept_bn_stats_from_partials");
 }
 

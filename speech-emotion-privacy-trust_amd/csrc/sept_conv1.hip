@@ -197,7 +197,8 @@ __global__ __launch_bounds__(256) void sept_conv1_fwd_mfma_kernel(const float* _
       float t = 0.f;
       for (int w = 0; w < 4; ++w)
         for (int l = 0; l < 32; ++l) t += ex[(w * 64 + hf * 32 + l) * kStatLd + which * 16 + 4 * j + i];
-      stats[(size_t(blockIdx.y) * gridDim.x + blockIdx.x) * (2 * kC) + threadIdx.x] = t;
+      // transposed partials [64][workgroups]: the finalize pass reads each statistic contiguously
+      stats[size_t(threadIdx.x) * (size_t(gridDim.x) * gridDim.y) + size_t(blockIdx.y) * gridDim.x + blockIdx.x] = t;
     }
   }
 }
@@ -565,8 +566,8 @@ extern "C" int sept_conv1_forward(const float* x, const float* w, const float* b
   return conv1_forward_impl(x, w, bias, wprep, y, nullptr, B, H, W, static_cast<hipStream_t>(stream));
 }
 
-// Forward + the BatchNorm statistics partials of the output: stats[sept_conv1_stats_parts(B, H)][64] floats
-// (per workgroup: 32 sums, 32 sums of squares), to be finished by sept_bn_stats_from_partials.
+// Forward + the BatchNorm statistics partials of the output: stats[64][sept_conv1_stats_parts(B, H)] floats
+// (32 sums then 32 sums of squares, one column per workgroup), to be finished by sept_bn_stats_from_partials.
 extern "C" int sept_conv1_stats_parts(int B, int H) { return B * ((H + kFwdRows - 1) / kFwdRows); }
 
 extern "C" int sept_conv1_forward_stats(const float* x, const float* w, const float* bias, float* wprep, void* y,
