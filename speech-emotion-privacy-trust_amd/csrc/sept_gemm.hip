@@ -562,21 +562,10 @@ extern "C" int sept_gemm_nt_split(const void* A, long lda, int a_is_bf16, const 
                K, lda, ldb, ldc);
   NtArgs g{A, B, C, bias, lda, ldb, ldc, M, N, K, c_is_bf16};
   hipStream_t st = static_cast<hipStream_t>(stream);
-  static const int force_bk = getenv("SEPT_NT_BK") ? atoi(getenv("SEPT_NT_BK")) : 0;
-  static const int force_mb = getenv("SEPT_NT_MB") ? atoi(getenv("SEPT_NT_MB")) : 0;
-  const int bk = (force_bk == 64 && K % 64 == 0) ? 64 : 32;
-  const int mb = force_mb == 2 ? 2 : 1;
-  if (a_is_bf16) {
-    if (bk == 64 && mb == 2) launch_nt<true, 2, 64>(g, st);
-    else if (bk == 64) launch_nt<true, 1, 64>(g, st);
-    else if (mb == 2) launch_nt<true, 2, 32>(g, st);
-    else launch_nt<true, 1, 32>(g, st);
-  } else {
-    if (bk == 64 && mb == 2) launch_nt<false, 2, 64>(g, st);
-    else if (bk == 64) launch_nt<false, 1, 64>(g, st);
-    else if (mb == 2) launch_nt<false, 2, 32>(g, st);
-    else launch_nt<false, 1, 32>(g, st);
-  }
+  // 64 x 64 tiles with K steps of 32: the larger shapes (128-row tiles, K steps of 64) were 1.3-2x slower
+  // in every A/B on MI355X -- fewer, fatter workgroups hide less of the L2 latency
+  if (a_is_bf16) launch_nt<true, 1, 32>(g, st);
+  else launch_nt<false, 1, 32>(g, st);
   return sept::launch_check("sept_gemm_nt_split_kernel");
 }
 
