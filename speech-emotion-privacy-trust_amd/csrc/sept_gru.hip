@@ -16,7 +16,6 @@
 
 namespace {
 
-constexpr int kH = 64;   // hidden size (trainer: lstm_hidden_size = 64)
 constexpr int kBS = 2;   // samples per workgroup (2 x 64 lanes: enough workgroups to cover 256 CUs at B = 224)
 
 struct GruArgs {
@@ -39,9 +38,12 @@ __device__ __forceinline__ float pair_sum(float v) {
   return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
 }
 
-constexpr int kHH = kH / 2;  // each hidden unit is owned by a PAIR of lanes, each with half of the k range
 
+// kH = hidden size (64: the trainer's lstm_hidden_size; 128: the class default); each hidden unit is owned by a
+// PAIR of lanes, each with half (kHH) of the k range
+template <int kH>
 __global__ __launch_bounds__(kBS * kH * 2) void sept_gru_fwd_kernel(GruArgs a) {
+  constexpr int kHH = kH / 2;
   __shared__ __attribute__((aligned(16))) float hs[kBS][kH];
   const int s = threadIdx.x / (2 * kH), j = (threadIdx.x >> 1) % kH, half = threadIdx.x & 1;
   // a sample index past the batch is clamped (the surplus lanes recompute and rewrite the last
@@ -109,7 +111,9 @@ __global__ __launch_bounds__(kBS * kH * 2) void sept_gru_fwd_kernel(GruArgs a) {
   }
 }
 
+template <int kH>
 __global__ __launch_bounds__(kBS * kH * 2) void sept_gru_bwd_kernel(GruArgs a) {
+  constexpr int kHH = kH / 2;
   __shared__ __attribute__((aligned(16))) float ds[kBS][3 * kH];
   const int s = threadIdx.x / (2 * kH), j = (threadIdx.x >> 1) % kH, half = threadIdx.x & 1;
   const int dir = blockIdx.y, b = min(blockIdx.x * kBS + s, a.B - 1);   // clamped, see the forward kernel
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(kBS * kH * 2) void sept_gru_bwd_kernel(GruArgs a) {
 
 extern "C" int sept_gru_forward(const float* gi, const float* whh_fwd, const float* whh_rev, const float* bhh_fwd,
                                 const float* bhh_rev, float* out, float* gates, int B, int T, int H, void* stream) {
-  SEPT_REQUIRE(H == kH, SEPT_ERR_UNSUPPORTED, "sept_gru_forward: hidden size %d (supported: %d)", H, kH);
+  SEPT_REQUIRE(H == 64 || H == 128, SEPT_ERR_UNSUPPORTED, "sept_gru_forward: hidden size %d (supported: 64, 128)", H);
   SEPT_REQUIRE(B >= 0 && T > 0, SEPT_ERR_INVALID, "sept_gru_forward: B=%d T=%d", B, T);
   if (B == 0) return SEPT_OK;
   SEPT_REQUIRE(gi && whh_fwd && whh_rev && bhh_fwd && bhh_rev && out && gates, SEPT_ERR_INVALID,
@@ -199,15 +203,19 @@ extern "C" int sept_gru_forward(const float* gi, const float* whh_fwd, const flo
   GruArgs a{};
   a.gi = gi; a.whh[0] = whh_fwd; a.whh[1] = whh_rev; a.bhh[0] = bhh_fwd; a.bhh[1] = bhh_rev;
   a.out = out; a.gates = gates; a.B = B; a.T = T;
-  hipLaunchKernelGGL(sept_gru_fwd_kernel, dim3((B + kBS - 1) / kBS, 2), dim3(kBS * kH * 2), 0,
-                     static_cast<hipStream_t>(stream), a);
+  if (H == 64)
+    hipLaunchKernelGGL(sept_gru_fwd_kernel<64>, dim3((B + kBS - 1) / kBS, 2), dim3(kBS * 64 * 2), 0,
+                       static_cast<hipStream_t>(stream), a);
+  else
+    hipLaunchKernelGGL(sept_gru_fwd_kernel<128>, dim3((B + kBS - 1) / kBS, 2), dim3(kBS * 128 * 2), 0,
+                       static_cast<hipStream_t>(stream), a);
   return sept::launch_check("sept_gru_fwd_kernel");
 }
 
 extern "C" int sept_gru_backward(const float* dout, const float* out, const float* gates, const float* whh_fwd,
                                  const float* whh_rev, float* dgi, float* dgh, float* hprev, int B, int T, int H,
                                  void* stream) {
-  SEPT_REQUIRE(H == kH, SEPT_ERR_UNSUPPORTED, "sept_gru_backward: hidden size %d (supported: %d)", H, kH);
+  SEPT_REQUIRE(H == 64 || H == 128, SEPT_ERR_UNSUPPORTED, "sept_gru_backward: hidden size %d (supported: 64, 128)", H);
   SEPT_REQUIRE(B >= 0 && T > 0, SEPT_ERR_INVALID, "sept_gru_backward: B=%d T=%d", B, T);
   if (B == 0) return SEPT_OK;
   SEPT_REQUIRE(dout && out && gates && whh_fwd && whh_rev && dgi && dgh && hprev, SEPT_ERR_INVALID,
@@ -216,7 +224,11 @@ extern "C" int sept_gru_backward(const float* dout, const float* out, const floa
   a.dout = dout; a.out = const_cast<float*>(out); a.gates = const_cast<float*>(gates);
   a.whh[0] = whh_fwd; a.whh[1] = whh_rev;
   a.dgi = dgi; a.dgh = dgh; a.hprev = hprev; a.B = B; a.T = T;
-  hipLaunchKernelGGL(sept_gru_bwd_kernel, dim3((B + kBS - 1) / kBS, 2), dim3(kBS * kH * 2), 0,
-                     static_cast<hipStream_t>(stream), a);
+  if (H == 64)
+    hipLaunchKernelGGL(sept_gru_bwd_kernel<64>, dim3((B + kBS - 1) / kBS, 2), dim3(kBS * 64 * 2), 0,
+                       static_cast<hipStream_t>(stream), a);
+  else
+    hipLaunchKernelGGL(sept_gru_bwd_kernel<128>, dim3((B + kBS - 1) / kBS, 2), dim3(kBS * 128 * 2), 0,
+                       static_cast<hipStream_t>(stream), a);
   return sept::launch_check("sept_gru_bwd_kernel");
 }

@@ -54,9 +54,9 @@ def _cached_pair(tag, t1, t2, fn):
 
 
 def _gru_cat_weights(wif, wir, bif, bir, layer, C, Wd):
-    """[W_ih forward; W_ih reverse] as ONE (384, K) operand (layer 0: columns permuted to the NHWC
-    feature order), its (K, 384) transpose (the k-contiguous operand of dx = dgi W) and the matching
-    (384,) bias, so both directions share one product per GEMM.  One launch (sept_gru_pack)."""
+    """[W_ih forward; W_ih reverse] as ONE (2G, K) operand (G = 3 * hidden; layer 0: columns permuted to
+    the NHWC feature order), its (K, 2G) transpose (the k-contiguous operand of dx = dgi W) and the
+    matching (2G,) bias, so both directions share one product per GEMM.  One launch (sept_gru_pack)."""
     G, K = wif.shape
     dev = wif.device
     wcat = torch.empty((2 * G, K), dtype=torch.float32, device=dev)
@@ -100,8 +100,9 @@ def trunk_params(model, head: str, att="model"):
     rnn = model.rnn
     if not isinstance(rnn, torch.nn.GRU):
         raise NotImplementedError("only rnn_cell='gru' is implemented on the HIP path")
-    if rnn.hidden_size != 64 or rnn.num_layers != 2 or not rnn.bidirectional:
-        raise NotImplementedError("HIP GRU supports hidden 64, 2 layers, bidirectional (the trainer's config)")
+    if rnn.hidden_size not in (64, 128) or rnn.num_layers != 2 or not rnn.bidirectional:
+        raise NotImplementedError("HIP GRU supports hidden 64 (the trainer's config) or 128 (the class default), "
+                                  "2 layers, bidirectional")
     att = model.att if att == "model" else att
     if att not in (None, "self_att"):
         raise ValueError(f"unknown attention mode {att!r}")
@@ -169,7 +170,7 @@ def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None, gfeat=Non
         specs = [(("c", li), (B, cv.weight.shape[0]), P.drop_ps[li]) for li, cv in enumerate(P.convs)
                  if "drop2d" not in inj]
         if "rnn" not in inj:
-            specs.append(("rnn", (B, t_out, 128), P.rnn.dropout))
+            specs.append(("rnn", (B, t_out, 2 * P.rnn.hidden_size), P.rnn.dropout))
         if "dense" not in inj:
             specs.append(("dense", (B, P.dense1.weight.shape[0]), P.dense_p))
         masks = _drop_masks(dev, specs)
@@ -208,6 +209,9 @@ def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None, gfeat=Non
     seq = act.view(B * T, D)
     r = P.rnn
     S.seq, S.T, S.D, S.C, S.Wd = seq, T, D, C, w
+    Hh = r.hidden_size            # hidden units per direction; H2 = GRU output width, G = 3 gates per direction
+    H2, G = 2 * Hh, 3 * Hh
+    S.Hh = Hh
     layer_in = seq
     S.gru = []
     for layer in range(2):
@@ -218,28 +222,28 @@ def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None, gfeat=Non
         wcat, bcat, wcatT = _cached_pair(f"wih_cat{layer}", wif, wir,
                                          lambda: _gru_cat_weights(wif, wir, bif, bir, layer, C, w))
         K = layer_in.shape[1]
-        # (B*T, 384): both directions in one product, on the split-bf16 matrix pipe when K allows
+        # (B*T, 2G): both directions in one product, on the split-bf16 matrix pipe when K allows
         gi = ops.linear_nt_split(layer_in, wcat, bcat) if _nt_ok(K) else ops.linear_forward(layer_in, wcat, bcat)
-        out, gates = ops.gru_forward(gi.view(B, T, 2, 192), whf, whr, bhf, bhr)
-        G = SimpleNamespace(inp=layer_in, out=out, gates=gates, wcat=wcat, wcatT=wcatT, whf=whf, whr=whr, mask=None)
+        out, gates = ops.gru_forward(gi.view(B, T, 2, G), whf, whr, bhf, bhr)
+        Gs = SimpleNamespace(inp=layer_in, out=out, gates=gates, wcat=wcat, wcatT=wcatT, whf=whf, whr=whr, mask=None)
         if layer == 0:
-            nxt = out.view(B * T, 128)
+            nxt = out.view(B * T, H2)
             if train and (r.dropout > 0 or "rnn" in inj):
                 m = inj.get("rnn")
-                G.mask = m if m is not None else masks["rnn"]
-                nxt = ops.mul(out, G.mask).view(B * T, 128)
+                Gs.mask = m if m is not None else masks["rnn"]
+                nxt = ops.mul(out, Gs.mask).view(B * T, H2)
             layer_in = nxt
-        S.gru.append(G)
+        S.gru.append(Gs)
     out1 = S.gru[1].out
     S.att = None
     if P.att == "self_att":   # baseline_models.py:233-242: 16-head additive attention over time
-        x2 = out1.view(B * T, 128)
+        x2 = out1.view(B * T, H2)
         a1t = ops.tanh_forward(ops.linear_forward(x2, P.att1.weight, P.att1.bias))
         scores = ops.linear_forward(a1t, P.att2.weight, P.att2.bias)
         z, probs = ops.att_pool_forward(scores.view(B, T, -1), out1)
         S.att = SimpleNamespace(a1t=a1t, probs=probs)
     else:
-        z = ops.mean_t_forward(out1) if pooling == "mean" else out1.view(B, T * 128)
+        z = ops.mean_t_forward(out1) if pooling == "mean" else out1.view(B, T * H2)
     S.zdim = z.shape[1]
     if gfeat is not None:     # :244-245: utterance-level functionals appended to the pooled vector
         z = torch.cat((z, gfeat.detach().to(z.dtype).view(B, -1)), 1)
@@ -293,9 +297,11 @@ def trunk_backward(S, P, dlogits, need_wgrad=True, need_dx=True):
         put(P.dense1.bias, ops.colsum(d_d1))
     if dz.shape[1] != S.zdim:   # the appended global features are inputs: no gradient needed
         dz = dz[:, :S.zdim].contiguous()
+    Hh = S.Hh
+    H2, G = 2 * Hh, 3 * Hh
     if S.att is not None:
         out1 = S.gru[1].out
-        x2 = out1.view(B * T, 128)
+        x2 = out1.view(B * T, H2)
         dout, dscores = ops.att_pool_backward(dz, out1, S.att.probs)
         ds2 = dscores.view(B * T, -1)
         d_a1 = ops.tanh_backward(ops.linear_backward_input(ds2, P.att2.weight), S.att.a1t)
@@ -307,34 +313,34 @@ def trunk_backward(S, P, dlogits, need_wgrad=True, need_dx=True):
             if P.att1.bias is not None:
                 put(P.att1.bias, ops.colsum(d_a1))
         w1 = P.att1.weight
-        ops.gemm_raw(d_a1, d_a1.stride(0), 1, w1, w1.shape[1], 1, dout, 128, B * T, 128, w1.shape[0], beta=1.0)
+        ops.gemm_raw(d_a1, d_a1.stride(0), 1, w1, w1.shape[1], 1, dout, H2, B * T, H2, w1.shape[0], beta=1.0)
     else:
-        dout = ops.mean_t_backward(dz, T) if S.pooling == "mean" else dz.view(B, T, 128)
+        dout = ops.mean_t_backward(dz, T) if S.pooling == "mean" else dz.view(B, T, H2)
     r = P.rnn
     dseq = None
     for layer in (1, 0):
-        G = S.gru[layer]
+        Gs = S.gru[layer]
         sfx = f"_l{layer}"
-        dgi, dgh, hprev = ops.gru_backward(dout.contiguous(), G.out, G.gates, G.whf, G.whr)
-        dgi2, dgh2, hp2 = dgi.view(B * T, 384), dgh.view(B * T, 384), hprev.view(B * T, 128)
-        K = G.inp.shape[1]
+        dgi, dgh, hprev = ops.gru_backward(dout.contiguous(), Gs.out, Gs.gates, Gs.whf, Gs.whr)
+        dgi2, dgh2, hp2 = dgi.view(B * T, 2 * G), dgh.view(B * T, 2 * G), hprev.view(B * T, H2)
+        K = Gs.inp.shape[1]
         if need_wgrad:
-            dwcat = ops.linear_backward_weight(dgi2, G.inp)      # (384, K): both directions in one product
+            dwcat = ops.linear_backward_weight(dgi2, Gs.inp)      # (2G, K): both directions in one product
             dbih, dbhh = ops.colsum(dgi2), ops.colsum(dgh2)
             for d, tag in ((0, ""), (1, "_reverse")):
-                gh = dgh2[:, d * 192:(d + 1) * 192]
-                dwih = dwcat[d * 192:(d + 1) * 192]
+                gh = dgh2[:, d * G:(d + 1) * G]
+                dwih = dwcat[d * G:(d + 1) * G]
                 if layer == 0:
                     dwih = ops.permute_cols(dwih, S.C, S.Wd, inverse=True)
                 put(getattr(r, "weight_ih" + sfx + tag), dwih)
-                put(getattr(r, "weight_hh" + sfx + tag), ops.linear_backward_weight(gh, hp2[:, d * 64:(d + 1) * 64]))
-                put(getattr(r, "bias_ih" + sfx + tag), dbih[d * 192:(d + 1) * 192])
-                put(getattr(r, "bias_hh" + sfx + tag), dbhh[d * 192:(d + 1) * 192])
-        # gradient wrt the layer input: dgi [W_if; W_ir]  (one product, K = 384)
+                put(getattr(r, "weight_hh" + sfx + tag), ops.linear_backward_weight(gh, hp2[:, d * Hh:(d + 1) * Hh]))
+                put(getattr(r, "bias_ih" + sfx + tag), dbih[d * G:(d + 1) * G])
+                put(getattr(r, "bias_hh" + sfx + tag), dbhh[d * G:(d + 1) * G])
+        # gradient wrt the layer input: dgi [W_if; W_ir]  (one product, reduction length 2G)
         odt = torch.float32 if layer == 1 else torch.bfloat16
-        din = ops.linear_nt_split(dgi2, G.wcatT, None, out_dtype=odt)   # reduction length 384
+        din = ops.linear_nt_split(dgi2, Gs.wcatT, None, out_dtype=odt)
         if layer == 1:
-            dout = din.view(B, T, 128)
+            dout = din.view(B, T, H2)
             if S.gru[0].mask is not None:
                 dout = ops.mul(dout, S.gru[0].mask)
         else:

@@ -415,6 +415,33 @@ def test_attention_global_feature_multitask_vs_reference(GA):
         close_logits(p2, GA["multi_gf_eval_gen"])
     with pytest.raises(Exception):        # dense1 was built for 128 + 88 inputs
         _mk_opt("emotion", None, 1, "attg.").eval()(x)
+    # the class-default constructor (hidden 128, global_feature=1) runs on the HIP path too
+    from model import baseline_models as bm
+    m = bm.two_d_cnn_lstm(1, F, 64)
+    m.load_state_dict(closed_form_state(m, prefix="defaults."))
+    with torch.no_grad():
+        close_logits(m.cuda().eval()(x, gf), GA["defaults_eval_logits"])
+
+
+def test_hidden_128_backward_matches_oracle():
+    """lstm_hidden_size=128 (the class default): gradients of the fp32 part against the oracle."""
+    F = 80
+    x = closed_form_input(B, W, F)
+    le, _, _ = closed_form_labels(B)
+    kw = dict(lstm_hidden_size=128, num_layers_lstm=2, pred="emotion", attention_size=128, att=None, global_feature=0)
+    from model import baseline_models as bm
+    m, ref = bm.two_d_cnn_lstm(1, F, 64, **kw), mo.two_d_cnn_lstm(1, F, 64, **kw)
+    sd = closed_form_state(ref, prefix="h128.")
+    m.load_state_dict(sd), ref.load_state_dict(sd)
+    m, ref = m.cuda().train(), ref.train()
+    zero_dropout(m), zero_dropout(ref)
+    torch.nn.functional.cross_entropy(m(x.cuda()), le.view(-1).cuda()).backward()
+    torch.nn.functional.cross_entropy(ref(x), le.view(-1)).backward()
+    got, want = dict(m.named_parameters()), dict(ref.named_parameters())
+    for name in ("pred_emotion_layer.weight", "dense1.weight", "rnn.weight_hh_l1", "rnn.weight_ih_l1_reverse",
+                 "rnn.weight_hh_l0_reverse", "rnn.bias_ih_l0", "rnn.weight_ih_l0"):
+        g, w = got[name].grad.cpu(), want[name].grad
+        assert _cos(g, w) > 0.999 and float((g - w).norm() / w.norm()) < 0.03, name
 
 
 def test_grl_step_with_attention_vs_reference(GA):

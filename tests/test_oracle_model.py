@@ -151,6 +151,9 @@ def test_oracle_attention_global_feature_multitask_vs_reference(GA):
         p1, p2 = mk_opt("multitask", None, 1, "multi.").eval()(x, gf)
         np.testing.assert_allclose(p1.numpy(), GA["multi_gf_eval_emo"], rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(p2.numpy(), GA["multi_gf_eval_gen"], rtol=1e-4, atol=1e-5)
+        m = mo.two_d_cnn_lstm(1, F, 64)          # class defaults: hidden 128, attention 256, global_feature=1
+        m.load_state_dict(closed_form_state(m, prefix="defaults."))
+        np.testing.assert_allclose(m.eval()(x, gf).numpy(), GA["defaults_eval_logits"], rtol=1e-4, atol=1e-5)
     emo, gen = mk_opt("emotion", "self_att", 0, "emotion."), mk_opt("gender", "self_att", 0, "gender.")
     noise = mo.cloak_noise(torch.zeros(1, W, F), torch.ones(1, W, F), torch.tensor(0.01), torch.tensor(10.0), "cpu")
     noise.load_state_dict(closed_form_state(noise, prefix="noise."))

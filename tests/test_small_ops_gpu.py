@@ -102,12 +102,13 @@ def test_gru_pack_matches_permute_and_transpose():
         assert torch.equal(bcat.cpu(), torch.cat([bf, br]))
 
 
-@pytest.mark.parametrize("B,T", [(7, 25), (4, 3), (1, 1)])
-def test_gru_layer_forward_backward(B, T):
-    """One bidirectional GRU layer (input projections by sept_gemm + recurrent kernel) vs nn.GRU."""
+@pytest.mark.parametrize("B,T,H", [(7, 25, 64), (4, 3, 64), (1, 1, 64), (5, 25, 128), (2, 2, 128)])
+def test_gru_layer_forward_backward(B, T, H):
+    """One bidirectional GRU layer (input projections by sept_gemm + recurrent kernel) vs nn.GRU, for the
+    trainer's hidden size (64) and the class default (128)."""
     from sept_amd import ops
     torch.manual_seed(B)
-    K, H = 48, 64
+    K, G = 48, 3 * H
     ref = nn.GRU(K, H, num_layers=1, batch_first=True, bidirectional=True)
     x = torch.randn(B, T, K, requires_grad=True)
     want, _ = ref(x)
@@ -115,26 +116,26 @@ def test_gru_layer_forward_backward(B, T):
     want.backward(dout)
     P = {n: p.detach().cuda() for n, p in ref.named_parameters()}
     xc = x.detach().cuda().view(B * T, K)
-    gi = torch.empty(B * T, 384, device="cuda")
-    ops.gemm_raw(xc, K, 1, P["weight_ih_l0"], 1, K, gi, 384, B * T, 192, K, P["bias_ih_l0"])
-    ops.gemm_raw(xc, K, 1, P["weight_ih_l0_reverse"], 1, K, gi[:, 192:], 384, B * T, 192, K, P["bias_ih_l0_reverse"])
-    out, gates = ops.gru_forward(gi.view(B, T, 2, 192), P["weight_hh_l0"], P["weight_hh_l0_reverse"],
+    gi = torch.empty(B * T, 2 * G, device="cuda")
+    ops.gemm_raw(xc, K, 1, P["weight_ih_l0"], 1, K, gi, 2 * G, B * T, G, K, P["bias_ih_l0"])
+    ops.gemm_raw(xc, K, 1, P["weight_ih_l0_reverse"], 1, K, gi[:, G:], 2 * G, B * T, G, K, P["bias_ih_l0_reverse"])
+    out, gates = ops.gru_forward(gi.view(B, T, 2, G), P["weight_hh_l0"], P["weight_hh_l0_reverse"],
                                  P["bias_hh_l0"], P["bias_hh_l0_reverse"])
     assert torch.allclose(out.cpu(), want.detach(), rtol=1e-4, atol=1e-5)
     dgi, dgh, hprev = ops.gru_backward(dout.cuda(), out, gates, P["weight_hh_l0"], P["weight_hh_l0_reverse"])
-    dgi2, dgh2, hp2 = dgi.view(B * T, 384), dgh.view(B * T, 384), hprev.view(B * T, 128)
+    dgi2, dgh2, hp2 = dgi.view(B * T, 2 * G), dgh.view(B * T, 2 * G), hprev.view(B * T, 2 * H)
     for d, tag in ((0, ""), (1, "_reverse")):
-        gs, gh = dgi2[:, d * 192:(d + 1) * 192], dgh2[:, d * 192:(d + 1) * 192]
+        gs, gh = dgi2[:, d * G:(d + 1) * G], dgh2[:, d * G:(d + 1) * G]
         grads = dict(ref.named_parameters())
         chk = [("weight_ih_l0" + tag, ops.linear_backward_weight(gs, xc)),
-               ("weight_hh_l0" + tag, ops.linear_backward_weight(gh, hp2[:, d * 64:(d + 1) * 64])),
+               ("weight_hh_l0" + tag, ops.linear_backward_weight(gh, hp2[:, d * H:(d + 1) * H])),
                ("bias_ih_l0" + tag, ops.colsum(gs)), ("bias_hh_l0" + tag, ops.colsum(gh))]
         for name, got in chk:
             w = grads[name].grad
             assert torch.allclose(got.cpu(), w, rtol=1e-3, atol=1e-5 + 1e-4 * w.abs().max()), name
     dx = torch.empty(B * T, K, device="cuda")
-    ops.gemm_raw(dgi2, 384, 1, P["weight_ih_l0"], K, 1, dx, K, B * T, K, 192)
-    ops.gemm_raw(dgi2[:, 192:], 384, 1, P["weight_ih_l0_reverse"], K, 1, dx, K, B * T, K, 192, beta=1.0)
+    ops.gemm_raw(dgi2, 2 * G, 1, P["weight_ih_l0"], K, 1, dx, K, B * T, K, G)
+    ops.gemm_raw(dgi2[:, G:], 2 * G, 1, P["weight_ih_l0_reverse"], K, 1, dx, K, B * T, K, G, beta=1.0)
     assert torch.allclose(dx.cpu().view(B, T, K), x.grad, rtol=1e-3, atol=1e-5)
 
 

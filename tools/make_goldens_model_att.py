@@ -2,7 +2,7 @@
 """Writes tests/golden/model_golden_att.npz: the REFERENCE modules (imported read-only from
 /root/reference/model, no bytecode written) on closed-form weights and inputs for the optional
 branches of two_d_cnn_lstm -- att='self_att', global_feature concat (88 functionals), pred='multitask'
-(baseline_models.py:233-258) -- and the GRL wrapper with attention (cloak_models.py:178-186, 215-223).
+(baseline_models.py:233-258), the class-default constructor (hidden 128) -- and the GRL wrapper with attention (cloak_models.py:178-186, 215-223).
 Runs only in the build container; only these vectors travel.  F = 80, B = 8, W = 200."""
 import os
 import sys
@@ -56,6 +56,10 @@ def main():
         m = mk("multitask", None, 1, "multi.").eval()
         p1, p2 = m(x, gf)
         out["multi_gf_eval_emo"], out["multi_gf_eval_gen"] = p1.numpy(), p2.numpy()
+        # the class DEFAULTS: hidden 128, attention_size 256, global_feature=1, att=None (baseline_models.py:144-145)
+        m = ref_bm.two_d_cnn_lstm(1, F, 64)
+        m.load_state_dict(closed_form_state(m, prefix="defaults."))
+        out["defaults_eval_logits"] = m.eval()(x, gf).numpy()
     # GRL wrapper with attention in both branches, one train-mode step (dropout off, eps injected)
     emo, gen = mk("emotion", "self_att", 0, "emotion."), mk("gender", "self_att", 0, "gender.")
     noise = ref_cm.cloak_noise(torch.zeros(1, W, F), torch.ones(1, W, F), torch.tensor(0.01), torch.tensor(10.0), "cpu")
