@@ -7,8 +7,9 @@ kernels of libsept_hip (NHWC bf16 MFMA convs, fused BatchNorm/ReLU/pool/dropout,
 The torch sub-modules held here (`conv`, `rnn`, `dense1`, ...) are parameter containers:
 their own forward is never called and there is no eager/CPU fallback.
 
-Scope: att None / 'self_att', rnn_cell='gru', hidden 64 or 128, global_feature concat
-not supported on the HIP path.
+Scope: att None / 'self_att', global_feature concat, pred emotion / gender /
+multitask; rnn_cell='gru' with 2 bidirectional layers of hidden 64 or 128.  Other RNN shapes and
+rnn_cell='lstm' raise NotImplementedError (there is no fallback).
 """
 try:
     from . import _paths  # noqa: F401
