@@ -46,14 +46,19 @@ __device__ __forceinline__ bf16x4 lds_tr(const unsigned char* p) {
       (__attribute__((address_space(3))) bf16x4*)(reinterpret_cast<uintptr_t>(p)));
 }
 
-template <int CIN, int COUT, int MBZ, int NBZ>
-__global__ __launch_bounds__(256) void sept_conv5x5_wgrad_kernel(WgArgs a) {
+// NW waves per workgroup share a tile; the 25 taps are dealt round-robin to the waves.  NW = 8 puts
+// two waves on every SIMD (128 accumulator registers each instead of 224), so one wave's LDS / barrier
+// waits hide under the other's MFMAs.
+template <int CIN, int COUT, int MBZ, int NBZ, int NW>
+__global__ __launch_bounds__(64 * NW) void sept_conv5x5_wgrad_kernel(WgArgs a) {
+  constexpr int NTHR = 64 * NW;
   constexpr int MSL = COUT / 32 / MBZ;  // output-channel slices
   constexpr int CX = NBZ * 32, CY = MBZ * 32;
   constexpr int PSX = CX * 2 + 16, PSY = CY * 2 + 16;
   constexpr int CPP = CX / 8, CPY = CY / 8;
-  constexpr int YCH = (kMT * CPY) / 256;
-  constexpr int NT = 7;  // taps per wave (wave 0: 7, others: 6)
+  constexpr int YCH = (kMT * CPY + NTHR - 1) / NTHR;
+  constexpr int XCH = (kXCH * 256 + NTHR - 1) / NTHR;  // 16-byte input chunks a lane prefetches per tile
+  constexpr int NT = (25 + NW - 1) / NW;  // taps per wave (wave 0 owns the odd one)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int W = a.W, H = a.H, HW = H * W, W4 = W + 4;
   const size_t xbytes = size_t(a.nr_max) * W4 * PSX;
@@ -79,14 +84,14 @@ __global__ __launch_bounds__(256) void sept_conv5x5_wgrad_kernel(WgArgs a) {
   int tapoff[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    const int tap = min(wave + 4 * j, 24);
+    const int tap = min(wave + NW * j, 24);
     tapoff[j] = ((tap / 5) * W4 + (tap % 5)) * PSX;
   }
 
   const int tiles_per_img = (HW + kMT - 1) / kMT;
   const long n_tiles = long(a.B) * tiles_per_img;
 
-  uint4 xr[kXCH], yr[YCH];
+  uint4 xr[XCH], yr[YCH];
   auto tile_geom = [&](long tile_id, int& b, int& q0, int& h_first, int& NR) {
     b = tile_id / tiles_per_img;
     q0 = int(tile_id % tiles_per_img) * kMT;
@@ -99,8 +104,8 @@ __global__ __launch_bounds__(256) void sept_conv5x5_wgrad_kernel(WgArgs a) {
     const bf16* xb = a.x + size_t(b) * HW * CIN + cin0;
     const int total = NR * W4 * CPP;
 #pragma unroll
-    for (int j = 0; j < kXCH; ++j) {
-      const int i = tid + 256 * j;
+    for (int j = 0; j < XCH; ++j) {
+      const int i = tid + NTHR * j;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (i < total) {
         const int c = i % CPP, px = i / CPP;
@@ -114,10 +119,10 @@ __global__ __launch_bounds__(256) void sept_conv5x5_wgrad_kernel(WgArgs a) {
     const bf16* yb = a.dy + size_t(b) * HW * COUT + cout0;
 #pragma unroll
     for (int j = 0; j < YCH; ++j) {
-      const int i = tid + 256 * j;
+      const int i = tid + NTHR * j;
       const int c = i % CPY, t = i / CPY;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (q0 + t < HW) v = *reinterpret_cast<const uint4*>(yb + size_t(q0 + t) * COUT + c * 8);
+      if (t < kMT && q0 + t < HW) v = *reinterpret_cast<const uint4*>(yb + size_t(q0 + t) * COUT + c * 8);
       yr[j] = v;
     }
   };
@@ -126,15 +131,15 @@ __global__ __launch_bounds__(256) void sept_conv5x5_wgrad_kernel(WgArgs a) {
     tile_geom(tile_id, b, q0, h_first, NR);
     const int total = NR * W4 * CPP;
 #pragma unroll
-    for (int j = 0; j < kXCH; ++j) {
-      const int i = tid + 256 * j;
+    for (int j = 0; j < XCH; ++j) {
+      const int i = tid + NTHR * j;
       if (i < total) *reinterpret_cast<uint4*>(buf + size_t(i / CPP) * PSX + (i % CPP) * 16) = xr[j];
     }
     unsigned char* yt = buf + xbytes;
 #pragma unroll
     for (int j = 0; j < YCH; ++j) {
-      const int i = tid + 256 * j;
-      *reinterpret_cast<uint4*>(yt + size_t(i / CPY) * PSY + (i % CPY) * 16) = yr[j];
+      const int i = tid + NTHR * j;
+      if (i < kMT * CPY) *reinterpret_cast<uint4*>(yt + size_t(i / CPY) * PSY + (i % CPY) * 16) = yr[j];
     }
   };
 
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(256) void sept_conv5x5_wgrad_kernel(WgArgs a) {
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        if (j == NT - 1 && wave != 0) break;  // taps 24.. only exist for wave 0 (wave-uniform)
+        if (wave + NW * j >= 25) break;  // the odd tap only exists for wave 0 (wave-uniform)
 #pragma unroll
         for (int nb = 0; nb < NBZ; ++nb) {
           const bf16x4 lo = lds_tr(xa[0] + tapoff[j] + nb * 64), hi = lds_tr(xa[1] + tapoff[j] + nb * 64);
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(256) void sept_conv5x5_wgrad_kernel(WgArgs a) {
   float* slab = a.ws + (size_t(z) * gridDim.x + blockIdx.x) * (25 * MBZ * NBZ * 1024);
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    const int tap = wave + 4 * j;
+    const int tap = wave + NW * j;
     if (tap >= 25) break;
 #pragma unroll
     for (int mb = 0; mb < MBZ; ++mb)
@@ -244,7 +249,7 @@ __global__ __launch_bounds__(256) void sept_conv5x5_wgrad_finalize_kernel(const 
 constexpr int kSlabFloats = 25 * 2 * 1024;  // every supported shape has MBZ * NBZ = 2
 constexpr int kTotalWG = 256;               // one 4-wave workgroup per CU (accumulators fill the VGPR file)
 
-template <int CIN, int COUT, int MBZ, int NBZ>
+template <int CIN, int COUT, int MBZ, int NBZ, int NW>
 int launch_wgrad(const WgArgs& a0, float* dw, hipStream_t st) {
   static_assert(MBZ * NBZ == 2, "slab size");
   WgArgs a = a0;
@@ -253,13 +258,13 @@ int launch_wgrad(const WgArgs& a0, float* dw, hipStream_t st) {
   constexpr int PSX = NBZ * 64 + 16, PSY = MBZ * 64 + 16;
   a.nr_max = wg_nr_max(a.W);
   const size_t smem = 2 * (size_t(a.nr_max) * (a.W + 4) * PSX + size_t(kMT) * PSY);
-  SEPT_REQUIRE(smem <= 160 * 1024 && a.nr_max * (a.W + 4) * (NBZ * 4) <= kXCH * 256, SEPT_ERR_UNSUPPORTED,
+  SEPT_REQUIRE(smem <= 160 * 1024 && a.nr_max * (a.W + 4) * (NBZ * 4) <= ((kXCH * 256 + 64 * NW - 1) / (64 * NW)) * 64 * NW, SEPT_ERR_UNSUPPORTED,
                "sept_conv5x5_backward_weight: W=%d is too wide for the LDS tile (%zu B)", a.W, smem);
   const long n_tiles = long(a.B) * ((a.H * a.W + kMT - 1) / kMT);
   const int G = int(std::min<long>(n_tiles, std::max(1, kTotalWG / Z)));
-  const void* fn = reinterpret_cast<const void*>(&sept_conv5x5_wgrad_kernel<CIN, COUT, MBZ, NBZ>);
+  const void* fn = reinterpret_cast<const void*>(&sept_conv5x5_wgrad_kernel<CIN, COUT, MBZ, NBZ, NW>);
   SEPT_HIP(sept::allow_max_lds(fn));
-  hipLaunchKernelGGL((sept_conv5x5_wgrad_kernel<CIN, COUT, MBZ, NBZ>), dim3(G, 1, Z), dim3(256), smem, st, a);
+  hipLaunchKernelGGL((sept_conv5x5_wgrad_kernel<CIN, COUT, MBZ, NBZ, NW>), dim3(G, 1, Z), dim3(64 * NW), smem, st, a);
   hipLaunchKernelGGL((sept_conv5x5_wgrad_finalize_kernel<CIN, COUT, MBZ, NBZ>), dim3(NBLK * 1024 / 64, Z),
                      dim3(256), 0, st, a.ws, G, dw);
   return sept::launch_check("sept_conv5x5_wgrad_kernel");
@@ -280,9 +285,16 @@ extern "C" int sept_conv5x5_backward_weight(const void* x, const void* dy, float
   SEPT_REQUIRE(B > 0 && H > 0 && W > 0, SEPT_ERR_INVALID, "sept_conv5x5_backward_weight: B=%d H=%d W=%d", B, H, W);
   WgArgs a{static_cast<const bf16*>(x), static_cast<const bf16*>(dy), ws, B, H, W, 0};
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (cin == 32 && cout == 64) return launch_wgrad<32, 64, 2, 1>(a, dw, st);
-  if (cin == 64 && cout == 128) return launch_wgrad<64, 128, 1, 2>(a, dw, st);
-  if (cin == 128 && cout == 128) return launch_wgrad<128, 128, 1, 2>(a, dw, st);
+  static const int nw = getenv("SEPT_WGRAD_NW") ? atoi(getenv("SEPT_WGRAD_NW")) : 8;   // tuning aid: 4 or 8 waves
+  if (nw == 4) {
+    if (cin == 32 && cout == 64) return launch_wgrad<32, 64, 2, 1, 4>(a, dw, st);
+    if (cin == 64 && cout == 128) return launch_wgrad<64, 128, 1, 2, 4>(a, dw, st);
+    if (cin == 128 && cout == 128) return launch_wgrad<128, 128, 1, 2, 4>(a, dw, st);
+  } else {
+    if (cin == 32 && cout == 64) return launch_wgrad<32, 64, 2, 1, 8>(a, dw, st);
+    if (cin == 64 && cout == 128) return launch_wgrad<64, 128, 1, 2, 8>(a, dw, st);
+    if (cin == 128 && cout == 128) return launch_wgrad<128, 128, 1, 2, 8>(a, dw, st);
+  }
   return sept::fail(SEPT_ERR_UNSUPPORTED,
                     "sept_conv5x5_backward_weight: cin=%d cout=%d (supported: 32->64, 64->128, 128->128)", cin, cout);
 }
