@@ -412,17 +412,20 @@ __global__ __launch_bounds__(256) void sept_conv1_dgrad_stream_kernel(const bf16
       }
     }
     // ---- output row r = y - 3: its Z rows y-5 .. y-1 were completed in earlier steps ----
+    // the gather runs on the waves that have no (or the smallest) MFMA block: pixels 0..63 on wave 3,
+    // 64..127 on wave 2, so the MFMA path of waves 0/1 and the gather path overlap inside a step
     const int r = y - 3;
-    if (r >= r0 && r < r1 && tid < W) {
+    const int gp = (3 - wave) * 64 + lane;
+    if (r >= r0 && r < r1 && gp < W) {
       float sum = 0.f;
 #pragma unroll
       for (int dh = 0; dh < 5; ++dh) {
         const int sz = s - 5 + dh;   // step that produced Z row r + dh - 2 = y - 5 + dh
-        const float* zr = zring + size_t(sz % kRing) * NP * kZS + tid * kZS + dh * 5;
+        const float* zr = zring + size_t(sz % kRing) * NP * kZS + gp * kZS + dh * 5;
 #pragma unroll
         for (int dw = 0; dw < 5; ++dw) sum += zr[dw * kZS + dw];
       }
-      dx[(size_t(b) * H + r) * W + tid] = sum;
+      dx[(size_t(b) * H + r) * W + gp] = sum;
     }
     lstore((s + 1) & 1, y + 1, pre_next1);  // row y + 1
     sept::lds_barrier();             // LDS-only barrier: the rows requested above stay in flight
