@@ -39,3 +39,47 @@ def sliding_window_predict(model, features, win_len=200, mask=None, pooling="mea
         model.train(was_training)
     probs, pred = ops.softmax_mean(logits.float(), nwin)
     return pred, probs
+
+
+def suppression_mask(scales: torch.Tensor, suppression_ratio: float):
+    """adversary_cloak_evaluation.py:263-267: None for ratio 0, else 0 where scales() exceeds its
+    `suppression_ratio`-th percentile (np.nanpercentile on the host, as the reference computes it) and
+    1 elsewhere."""
+    import numpy as np
+    if not suppression_ratio:
+        return None
+    thr = float(np.nanpercentile(scales.detach().float().cpu().numpy(), int(suppression_ratio)))
+    return torch.where(scales.detach() > thr, torch.zeros_like(scales), torch.ones_like(scales))
+
+
+@torch.no_grad()
+def cloak_evaluation_predict(cloak_model, baseline_model, adversary_model, features, win_len=200, mask=None,
+                             global_feature=None):
+    """test() of adversary_cloak_evaluation.py:40-110: every window goes through the cloak model (noise
+    added, optionally masked), the NOISY window through the clean emotion model and through the gender
+    adversary; softmax, mean over the utterance's windows, arg-max.  Returns
+    ((emotion prediction, probabilities), (adversary prediction, probabilities)).  All windows of all
+    utterances share one forward here, i.e. one noise draw, where the reference draws one per window."""
+    if features.dim() == 4:
+        features = features[:, 0]
+    B, T, F = features.shape
+    if T < win_len:
+        raise ValueError(f"utterance of {T} frames is shorter than the {win_len}-frame window")
+    nwin = (T - win_len) // SHIFT_LEN + 1
+    x = ops.window_norm(features.float().contiguous(), None, None, win_len, SHIFT_LEN).view(B * nwin, 1, win_len, F)
+    gf = None if global_feature is None else global_feature.repeat_interleave(nwin, dim=0)
+    models = (cloak_model, baseline_model, adversary_model)
+    was = [m.training for m in models]
+    for m in models:
+        m.eval()
+    try:
+        # only the cloak's noisy output is consumed by this loop (the wrapper's own predictions are unused)
+        noisy = (cloak_model.intermed(x) if mask is None else cloak_model.intermed(x, mask)).detach()
+        logits = baseline_model(noisy) if gf is None else baseline_model(noisy, gf)
+        adv_logits = adversary_model(noisy) if gf is None else adversary_model(noisy, gf)
+    finally:
+        for m, t in zip(models, was):
+            m.train(t)
+    probs, pred = ops.softmax_mean(logits.float(), nwin)
+    aprobs, apred = ops.softmax_mean(adv_logits.float(), nwin)
+    return (pred, probs), (apred, aprobs)

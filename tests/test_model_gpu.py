@@ -501,3 +501,36 @@ def test_multitask_backward_matches_oracle():
                  "rnn.weight_hh_l1", "rnn.weight_ih_l1_reverse"):
         g, w = got[name].grad.cpu(), dict(ref.named_parameters())[name].grad
         assert _cos(g, w) > 0.999 and float((g - w).norm() / w.norm()) < 0.03, name
+
+
+def test_cloak_evaluation_predict_and_suppression_mask():
+    """adversary_cloak_evaluation.py: percentile suppression mask (:263-267) and the test() loop (:40-110:
+    noisy windows through the clean emotion model and the gender adversary) -- batched HIP path vs the
+    oracle's one-window-per-forward loop with the same injected epsilon."""
+    from sept_amd.inference import cloak_evaluation_predict, suppression_mask
+    F, T = 80, 351
+    torch.manual_seed(5)
+    feats = torch.randn(2, 1, T, F)
+    grl, ref = build_grl(F).eval(), _oracle_grl(F).eval()
+    ref.load_state_dict({k: v.cpu() for k, v in grl.state_dict().items()})
+    base, adv = mk(F, "emotion").eval(), mk(F, "gender").eval()
+    base_o, adv_o = mk_oracle(F, "emotion").eval(), mk_oracle(F, "gender").eval()
+    scales = grl.intermed.scales()
+    assert suppression_mask(scales, 0) is None
+    mask = suppression_mask(scales, 30)
+    thr = np.nanpercentile(scales.detach().cpu().numpy(), 30)
+    want_mask = (scales.detach().cpu().numpy() <= thr).astype(np.float32)
+    assert np.array_equal(mask.cpu().numpy(), want_mask) and 0.25 < 1 - want_mask.mean() < 0.75 or want_mask.mean() in (0.0, 1.0)
+    (pred, probs), (apred, aprobs) = cloak_evaluation_predict(grl, base, adv, feats.cuda(), mask=mask)
+    nwin = int((T - 200) / 50) + 1
+    for b in range(2):
+        pl, al = [], []
+        with torch.no_grad():
+            for i in range(nwin):
+                w = feats[b:b + 1, :, i * 50:i * 50 + 200, :]
+                _, _, noisy = ref(w, mask=mask.cpu(), grl=False, pooling="mean")
+                pl.append(torch.softmax(base_o(noisy), 1)[0].numpy())
+                al.append(torch.softmax(adv_o(noisy), 1)[0].numpy())
+        np.testing.assert_allclose(probs[b].cpu().numpy(), np.mean(pl, 0), atol=1e-2)
+        np.testing.assert_allclose(aprobs[b].cpu().numpy(), np.mean(al, 0), atol=1e-2)
+    assert pred.shape == (2,) and apred.shape == (2,)
