@@ -96,12 +96,12 @@ __global__ __launch_bounds__(256) void sept_conv1_fwd_kernel(const float* __rest
   }
 }
 
-// Forward on the exact-fp32 matrix pipe (v_mfma_f32_32x32x2_f32): per 32-pixel block a 32 x 26 x 32
-// product -- A = weights [channel][tap] (the 26th "tap" is the bias against a constant 1), B =
-// im2col of the staged fp32 rows [tap][pixel].  The 13 weight fragments of a lane never change,
-// so they stay in registers; B comes from LDS with one b32 read per MFMA (both wave halves read
-// the same row shifted by one tap, i.e. broadcasts, no bank conflicts).  Products are exact fp32
-// like the scalar form; the write of y (64 B per pixel) is what bounds the kernel.
+// Forward on the bf16 matrix pipe with split operands: per 32-pixel block a 32 x 32 x 32 product (taps
+// padded to 32; the 26th "tap" is the bias against a constant 1) -- A = weights [channel][tap], B = im2col of
+// the staged fp32 rows [tap][pixel].  Both operands are split into bf16 hi + lo and multiplied in three
+// passes (hi*hi + hi*lo + lo*hi), so the products carry ~2^-17 relative error (the output is rounded to bf16
+// anyway) at a quarter of the exact-fp32 MFMA's cycles; the weight fragments never change and stay in
+// registers.  The write of y (64 B per pixel) is what bounds the kernel.
 constexpr int kFwdRows = 16;  // output rows per workgroup
 constexpr int kStatLd = 33;   // floats per lane in the statistics exchange (odd: conflict-free)
 // STATS: the kernel also leaves this workgroup's per-channel (sum, sum of squares) of the bf16-rounded
@@ -120,14 +120,20 @@ __global__ __launch_bounds__(256) void sept_conv1_fwd_mfma_kernel(const float* _
   const int nrows = min(kFwdRows, H - h0);
   stage_x(x + size_t(b) * H * W, tile, h0, nrows + 4, H, W);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, c = lane & 31;
-  float wfrag[13];
-  int tapoff[13];
+  // A operand (weights): lane (channel c, k half) holds taps 16*ks + 8*half + j, j = 0..7, of both K steps, split
+  // into bf16 hi + lo (w = hi + lo up to 2^-17); tap 25 is the bias (against a constant 1), taps 26..31 are zero
+  bf16x8 whi[2], wlo[2];
+  int tapoff[2][8];
 #pragma unroll
-  for (int s = 0; s < 13; ++s) {
-    const int t = 2 * s + half;
-    wfrag[s] = t < kTaps ? wprep[t * kC + c] : wprep[kTaps * kC + c];  // t == 25: bias
-    tapoff[s] = t < kTaps ? (t / 5) * W4 + t % 5 : 0;
-  }
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int t = 16 * ks + 8 * half + j;
+      const float wv = t < kTaps ? wprep[t * kC + c] : (t == kTaps ? wprep[kTaps * kC + c] : 0.f);
+      whi[ks][j] = (bf16)wv;
+      wlo[ks][j] = (bf16)(wv - float(whi[ks][j]));
+      tapoff[ks][j] = t < kTaps ? (t / 5) * W4 + t % 5 : 0;
+    }
   __syncthreads();
   const int npx = nrows * W, nblk = (npx + 31) / 32;
   bf16* yb = y + (size_t(b) * H + h0) * W * kC;
@@ -145,9 +151,22 @@ __global__ __launch_bounds__(256) void sept_conv1_fwd_mfma_kernel(const float* _
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-    for (int s = 0; s < 13; ++s) {
-      const float xv = (s == 12 && half) ? 1.0f : tp[tapoff[s]];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wfrag[s], xv, acc, 0, 0, 0);
+    for (int ks = 0; ks < 2; ++ks) {
+      // B operand (im2col): the 8 taps of this lane for pixel q, split into hi + lo like the weights;
+      // three passes hi*hi + hi*lo + lo*hi keep the products at ~2^-17 relative (the output is bf16)
+      bf16x8 xhi, xlo;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int t = 16 * ks + 8 * half + j;   // half is a lane property: both candidates are compile-time taps
+        float xv = tp[tapoff[ks][j]];
+        if (ks == 1) xv = (half && j == 1) ? 1.0f : ((half && j > 1) ? 0.f : xv);
+        (void)t;
+        xhi[j] = (bf16)xv;
+        xlo[j] = (bf16)(xv - float(xhi[j]));
+      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo[ks], xhi, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[ks], xlo, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[ks], xhi, acc, 0, 0, 0);
     }
     // acc[4j + i] = channel 8j + 4*half + i of pixel q.  Swap halves (v_permlane32_swap) so the
     // lower lane of a pixel holds channels 0..15 and the upper one 16..31: two 16-byte stores each.
