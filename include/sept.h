@@ -205,6 +205,18 @@ int sept_gru_backward(const float* dout, const float* out, const float* gates, c
                       const float* whh_rev, float* dgi, float* dgh, float* hprev, int B, int T, int H,
                       void* stream);
 
+/* LSTM recurrence (gate order i, f, g, o; nn.LSTM of deep_two_d_cnn_lstm_tmp, baseline_models.py:388-509, and the
+ * rnn_cell='lstm' option of the other classes): gi (B, T, 2, 4H) = x W_ih^T + b_ih for both directions;
+ * out (B, T, 2H); gates (B, T, 2, 4, H) and cells (B, T, 2, H) are kept for the backward pass, which returns
+ * dgates (B, T, 2, 4H) -- the gradient wrt the gate pre-activations, i.e. of BOTH gi and W_hh h + b_hh -- and
+ * hprev (B, T, 2, H), the operand of dW_hh.  H = 64 or 128. */
+int sept_lstm_forward(const float* gi, const float* whh_fwd, const float* whh_rev, const float* bhh_fwd,
+                      const float* bhh_rev, float* out, float* gates, float* cells, int B, int T, int H,
+                      void* stream);
+int sept_lstm_backward(const float* dout, const float* out, const float* gates, const float* cells,
+                       const float* whh_fwd, const float* whh_rev, float* dgates, float* hprev, int B,
+                       int T, int H, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * cloak_noise (model/cloak_models.py:24-58).  n_per = W*F elements of locs/rhos/eps/mask.
  *   scales = (1 + tanh(rhos)) / 2 * (max_scale - min_scale) + min_scale          (:41-43)

@@ -3,7 +3,7 @@
 A plain-torch (fp32, autograd) restatement of the reference modules that sit on the path:
     GradientReversalFunction / GradientReversal      model/reversal_gradient.py:5-32
     cloak_noise                                      model/cloak_models.py:24-58
-    two_d_cnn_lstm (+ deep_two_d_cnn_lstm, one_d_cnn_lstm)   model/baseline_models.py:19-385
+    two_d_cnn_lstm (+ deep_two_d_cnn_lstm, its LSTM clone deep_two_d_cnn_lstm_tmp, one_d_cnn_lstm)   model/baseline_models.py:19-509
     two_d_cnn_lstm_syn / two_d_cnn_lstm_syn_with_grl model/cloak_models.py:61-226
     the per-step loss of train()                     training/training_cloak_with_grl.py:138-160
 with the reference's constructor signatures, attribute names and state-dict keys, so a
@@ -177,6 +177,16 @@ class two_d_cnn_lstm(_TwoDBase):
 class deep_two_d_cnn_lstm(_TwoDBase):
     def __init__(self, *a, **k):
         super().__init__(True, *a, **k)
+
+
+class deep_two_d_cnn_lstm_tmp(_TwoDBase):
+    """baseline_models.py:388-509: the deep variant again, with rnn_cell defaulting to 'lstm'."""
+
+    def __init__(self, input_channel, input_spec_size, cnn_filter_size, lstm_hidden_size=128, num_layers_lstm=2,
+                 pred="emotion", bidirectional=True, rnn_cell="lstm", attention_size=256, variable_lengths=False,
+                 global_feature=1, att=None):
+        super().__init__(True, input_channel, input_spec_size, cnn_filter_size, lstm_hidden_size, num_layers_lstm, pred,
+                         bidirectional, rnn_cell, attention_size, variable_lengths, global_feature, att)
 
 
 class one_d_cnn_lstm(nn.Module):

@@ -8,8 +8,8 @@ The torch sub-modules held here (`conv`, `rnn`, `dense1`, ...) are parameter con
 their own forward is never called and there is no eager/CPU fallback.
 
 Scope: att None / 'self_att', global_feature concat, pred emotion / gender /
-multitask; rnn_cell='gru' with 2 bidirectional layers of hidden 64 or 128.  Other RNN shapes and
-rnn_cell='lstm' raise NotImplementedError (there is no fallback).
+multitask; rnn_cell 'gru' or 'lstm' with 2 bidirectional layers of hidden 64 or 128 (other RNN shapes
+raise NotImplementedError: there is no fallback).
 """
 try:
     from . import _paths  # noqa: F401
@@ -120,6 +120,18 @@ class two_d_cnn_lstm(_TwoD):
 
 class deep_two_d_cnn_lstm(_TwoD):
     _deep = True
+
+
+class deep_two_d_cnn_lstm_tmp(_TwoD):
+    """The reference's clone of the deep variant whose recurrent cell defaults to an LSTM
+    (baseline_models.py:388-509; model_type 'tmp' of training_adversary_baselines.py:396-404)."""
+    _deep = True
+
+    def __init__(self, input_channel, input_spec_size, cnn_filter_size, lstm_hidden_size=128, num_layers_lstm=2,
+                 pred='emotion', bidirectional=True, rnn_cell='lstm', attention_size=256, variable_lengths=False,
+                 global_feature=1, att=None):
+        super().__init__(input_channel, input_spec_size, cnn_filter_size, lstm_hidden_size, num_layers_lstm, pred,
+                         bidirectional, rnn_cell, attention_size, variable_lengths, global_feature, att)
 
 
 class one_d_cnn_lstm(nn.Module):

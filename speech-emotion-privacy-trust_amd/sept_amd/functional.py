@@ -98,11 +98,11 @@ def trunk_params(model, head: str, att="model"):
             dps = [n.p for n in nxt if isinstance(n, torch.nn.Dropout2d)]
             drop_ps.append(dps[0] if dps else 0.0)
     rnn = model.rnn
-    if not isinstance(rnn, torch.nn.GRU):
-        raise NotImplementedError("only rnn_cell='gru' is implemented on the HIP path")
+    if not isinstance(rnn, (torch.nn.GRU, torch.nn.LSTM)):
+        raise NotImplementedError("the HIP path implements rnn_cell 'gru' and 'lstm'")
     if rnn.hidden_size not in (64, 128) or rnn.num_layers != 2 or not rnn.bidirectional:
-        raise NotImplementedError("HIP GRU supports hidden 64 (the trainer's config) or 128 (the class default), "
-                                  "2 layers, bidirectional")
+        raise NotImplementedError("the HIP recurrences support hidden 64 (the trainer's config) or 128 (the class "
+                                  "default), 2 layers, bidirectional")
     att = model.att if att == "model" else att
     if att not in (None, "self_att"):
         raise ValueError(f"unknown attention mode {att!r}")
@@ -210,8 +210,9 @@ def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None, gfeat=Non
     r = P.rnn
     S.seq, S.T, S.D, S.C, S.Wd = seq, T, D, C, w
     Hh = r.hidden_size            # hidden units per direction; H2 = GRU output width, G = 3 gates per direction
-    H2, G = 2 * Hh, 3 * Hh
-    S.Hh = Hh
+    lstm = isinstance(r, torch.nn.LSTM)        # gate blocks per direction: 4 (i, f, g, o) or 3 (r, z, n)
+    H2, G = 2 * Hh, (4 if lstm else 3) * Hh
+    S.Hh, S.lstm = Hh, lstm
     layer_in = seq
     S.gru = []
     for layer in range(2):
@@ -224,8 +225,13 @@ def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None, gfeat=Non
         K = layer_in.shape[1]
         # (B*T, 2G): both directions in one product, on the split-bf16 matrix pipe when K allows
         gi = ops.linear_nt_split(layer_in, wcat, bcat) if _nt_ok(K) else ops.linear_forward(layer_in, wcat, bcat)
-        out, gates = ops.gru_forward(gi.view(B, T, 2, G), whf, whr, bhf, bhr)
-        Gs = SimpleNamespace(inp=layer_in, out=out, gates=gates, wcat=wcat, wcatT=wcatT, whf=whf, whr=whr, mask=None)
+        cells = None
+        if lstm:
+            out, gates, cells = ops.lstm_forward(gi.view(B, T, 2, G), whf, whr, bhf, bhr)
+        else:
+            out, gates = ops.gru_forward(gi.view(B, T, 2, G), whf, whr, bhf, bhr)
+        Gs = SimpleNamespace(inp=layer_in, out=out, gates=gates, cells=cells, wcat=wcat, wcatT=wcatT, whf=whf, whr=whr,
+                             mask=None)
         if layer == 0:
             nxt = out.view(B * T, H2)
             if train and (r.dropout > 0 or "rnn" in inj):
@@ -298,7 +304,7 @@ def trunk_backward(S, P, dlogits, need_wgrad=True, need_dx=True):
     if dz.shape[1] != S.zdim:   # the appended global features are inputs: no gradient needed
         dz = dz[:, :S.zdim].contiguous()
     Hh = S.Hh
-    H2, G = 2 * Hh, 3 * Hh
+    H2, G = 2 * Hh, (4 if S.lstm else 3) * Hh
     if S.att is not None:
         out1 = S.gru[1].out
         x2 = out1.view(B * T, H2)
@@ -321,12 +327,17 @@ def trunk_backward(S, P, dlogits, need_wgrad=True, need_dx=True):
     for layer in (1, 0):
         Gs = S.gru[layer]
         sfx = f"_l{layer}"
-        dgi, dgh, hprev = ops.gru_backward(dout.contiguous(), Gs.out, Gs.gates, Gs.whf, Gs.whr)
+        if S.lstm:   # gi and W_hh h enter the gates as a sum: one gradient serves both
+            dgi, hprev = ops.lstm_backward(dout.contiguous(), Gs.out, Gs.gates, Gs.cells, Gs.whf, Gs.whr)
+            dgh = dgi
+        else:
+            dgi, dgh, hprev = ops.gru_backward(dout.contiguous(), Gs.out, Gs.gates, Gs.whf, Gs.whr)
         dgi2, dgh2, hp2 = dgi.view(B * T, 2 * G), dgh.view(B * T, 2 * G), hprev.view(B * T, H2)
         K = Gs.inp.shape[1]
         if need_wgrad:
             dwcat = ops.linear_backward_weight(dgi2, Gs.inp)      # (2G, K): both directions in one product
-            dbih, dbhh = ops.colsum(dgi2), ops.colsum(dgh2)
+            dbih = ops.colsum(dgi2)
+            dbhh = dbih if S.lstm else ops.colsum(dgh2)
             for d, tag in ((0, ""), (1, "_reverse")):
                 gh = dgh2[:, d * G:(d + 1) * G]
                 dwih = dwcat[d * G:(d + 1) * G]

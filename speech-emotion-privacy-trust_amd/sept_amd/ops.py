@@ -330,6 +330,30 @@ def gru_forward(gi, whh_f, whh_r, bhh_f, bhh_r):
     return out, gates
 
 
+def lstm_forward(gi, whh_f, whh_r, bhh_f, bhh_r):
+    """gi (B,T,2,4H), whh_* (4H,H), bhh_* (4H) -> out (B,T,2H), gates (B,T,2,4,H), cells (B,T,2,H)."""
+    B, T = gi.shape[0], gi.shape[1]
+    H = whh_f.shape[1]
+    out = torch.empty((B, T, 2 * H), dtype=torch.float32, device=gi.device)
+    gates = torch.empty((B, T, 2, 4, H), dtype=torch.float32, device=gi.device)
+    cells = torch.empty((B, T, 2, H), dtype=torch.float32, device=gi.device)
+    check(lib.sept_lstm_forward(gi.data_ptr(), whh_f.data_ptr(), whh_r.data_ptr(), bhh_f.data_ptr(), bhh_r.data_ptr(),
+                                out.data_ptr(), gates.data_ptr(), cells.data_ptr(), B, T, H, _s(gi)), "sept_lstm_forward")
+    return out, gates, cells
+
+
+def lstm_backward(dout, out, gates, cells, whh_f, whh_r):
+    """-> dgates (B,T,2,4H) (gradient wrt the gate pre-activations = dgi = dgh), hprev (B,T,2,H)."""
+    B, T = dout.shape[0], dout.shape[1]
+    H = whh_f.shape[1]
+    dgates = torch.empty((B, T, 2, 4 * H), dtype=torch.float32, device=dout.device)
+    hprev = torch.empty((B, T, 2, H), dtype=torch.float32, device=dout.device)
+    check(lib.sept_lstm_backward(dout.data_ptr(), out.data_ptr(), gates.data_ptr(), cells.data_ptr(), whh_f.data_ptr(),
+                                 whh_r.data_ptr(), dgates.data_ptr(), hprev.data_ptr(), B, T, H, _s(dout)),
+          "sept_lstm_backward")
+    return dgates, hprev
+
+
 def gru_backward(dout, out, gates, whh_f, whh_r):
     B, T = dout.shape[0], dout.shape[1]
     H = whh_f.shape[1]

@@ -28,7 +28,7 @@ def _build():
     for mod in m.modules():
         if isinstance(mod, (nn.Dropout, nn.Dropout2d)):
             mod.p = 0.0
-        if isinstance(mod, nn.GRU):
+        if isinstance(mod, (nn.GRU, nn.LSTM)):
             mod.dropout = 0.0
     return m
 

@@ -30,7 +30,7 @@ def zero_dropout(mod):
     for m in mod.modules():
         if isinstance(m, (nn.Dropout, nn.Dropout2d)):
             m.p = 0.0
-        if isinstance(m, nn.GRU):
+        if isinstance(m, (nn.GRU, nn.LSTM)):
             m.dropout = 0.0
 
 
@@ -154,6 +154,23 @@ def test_oracle_attention_global_feature_multitask_vs_reference(GA):
         m = mo.two_d_cnn_lstm(1, F, 64)          # class defaults: hidden 128, attention 256, global_feature=1
         m.load_state_dict(closed_form_state(m, prefix="defaults."))
         np.testing.assert_allclose(m.eval()(x, gf).numpy(), GA["defaults_eval_logits"], rtol=1e-4, atol=1e-5)
+    # deep_two_d_cnn_lstm_tmp (LSTM cell): eval logits, train-mode loss and gradients
+    kw = dict(lstm_hidden_size=64, num_layers_lstm=2, pred="emotion", attention_size=128, att=None, global_feature=0)
+    m = mo.deep_two_d_cnn_lstm_tmp(1, F, 64, **kw)
+    assert isinstance(m.rnn, nn.LSTM)
+    m.load_state_dict(closed_form_state(m, prefix="tmp."))
+    with torch.no_grad():
+        np.testing.assert_allclose(m.eval()(x).numpy(), GA["tmp_lstm_eval_logits"], rtol=1e-4, atol=1e-5)
+    m.train()
+    zero_dropout(m)
+    loss = nn.functional.cross_entropy(m(x), le.view(-1))
+    loss.backward()
+    assert float(loss) == pytest.approx(float(GA["tmp_lstm_train_loss"]), rel=1e-5)
+    for name in ("rnn.weight_hh_l1", "rnn.weight_ih_l1_reverse", "rnn.bias_hh_l0", "dense1.weight"):
+        g = dict(m.named_parameters())[name].grad
+        want = GA["tmp_lstm_grad_" + name]
+        np.testing.assert_allclose(g.reshape(-1)[:want.size].double().numpy(), want, rtol=2e-3,
+                                   atol=2e-3 * float(GA["tmp_lstm_gradnorm_" + name]) / want.size ** 0.5)
     emo, gen = mk_opt("emotion", "self_att", 0, "emotion."), mk_opt("gender", "self_att", 0, "gender.")
     noise = mo.cloak_noise(torch.zeros(1, W, F), torch.ones(1, W, F), torch.tensor(0.01), torch.tensor(10.0), "cpu")
     noise.load_state_dict(closed_form_state(noise, prefix="noise."))

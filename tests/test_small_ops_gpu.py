@@ -284,3 +284,40 @@ def test_preprocess_speaker_stats_window_norm_and_augmentation():
     xa, la = pp.balance_by_augmentation(x, labels, generator=torch.Generator().manual_seed(1))
     assert xa.shape[0] == 120 and torch.bincount(la.cpu()).tolist() == [40, 40, 40]
     assert float(xa[:64].abs().max()) == 0.0 and float(xa[64:].std()) == pytest.approx(0.05, rel=5e-2)
+
+
+@pytest.mark.parametrize("B,T,H", [(7, 25, 64), (3, 2, 64), (1, 1, 64), (5, 25, 128), (2, 3, 128)])
+def test_lstm_layer_forward_backward(B, T, H):
+    """One bidirectional LSTM layer (input projections by sept_gemm + sept_lstm_forward / backward) vs nn.LSTM
+    (the default cell of deep_two_d_cnn_lstm_tmp, baseline_models.py:388-509)."""
+    from sept_amd import ops
+    torch.manual_seed(B + H)
+    K, G = 48, 4 * H
+    ref = nn.LSTM(K, H, num_layers=1, batch_first=True, bidirectional=True)
+    x = torch.randn(B, T, K, requires_grad=True)
+    want, _ = ref(x)
+    dout = torch.randn(B, T, 2 * H)
+    want.backward(dout)
+    P = {n: p.detach().cuda() for n, p in ref.named_parameters()}
+    xc = x.detach().cuda().view(B * T, K)
+    gi = torch.empty(B * T, 2 * G, device="cuda")
+    ops.gemm_raw(xc, K, 1, P["weight_ih_l0"], 1, K, gi, 2 * G, B * T, G, K, P["bias_ih_l0"])
+    ops.gemm_raw(xc, K, 1, P["weight_ih_l0_reverse"], 1, K, gi[:, G:], 2 * G, B * T, G, K, P["bias_ih_l0_reverse"])
+    out, gates, cells = ops.lstm_forward(gi.view(B, T, 2, G), P["weight_hh_l0"], P["weight_hh_l0_reverse"],
+                                         P["bias_hh_l0"], P["bias_hh_l0_reverse"])
+    assert torch.allclose(out.cpu(), want.detach(), rtol=1e-4, atol=1e-5)
+    dg, hprev = ops.lstm_backward(dout.cuda(), out, gates, cells, P["weight_hh_l0"], P["weight_hh_l0_reverse"])
+    dg2, hp2 = dg.view(B * T, 2 * G), hprev.view(B * T, 2 * H)
+    grads = dict(ref.named_parameters())
+    for d, tag in ((0, ""), (1, "_reverse")):
+        gs = dg2[:, d * G:(d + 1) * G]
+        chk = [("weight_ih_l0" + tag, ops.linear_backward_weight(gs, xc)),
+               ("weight_hh_l0" + tag, ops.linear_backward_weight(gs, hp2[:, d * H:(d + 1) * H])),
+               ("bias_ih_l0" + tag, ops.colsum(gs)), ("bias_hh_l0" + tag, ops.colsum(gs))]
+        for name, got in chk:
+            w = grads[name].grad
+            assert torch.allclose(got.cpu(), w, rtol=1e-3, atol=1e-5 + 1e-4 * w.abs().max()), name
+    dx = torch.empty(B * T, K, device="cuda")
+    ops.gemm_raw(dg2, 2 * G, 1, P["weight_ih_l0"], K, 1, dx, K, B * T, K, G)
+    ops.gemm_raw(dg2[:, G:], 2 * G, 1, P["weight_ih_l0_reverse"], K, 1, dx, K, B * T, K, G, beta=1.0)
+    assert torch.allclose(dx.cpu().view(B, T, K), x.grad, rtol=1e-3, atol=1e-5)

@@ -44,7 +44,7 @@ def zero_dropout(mod):
     for m in mod.modules():
         if isinstance(m, (nn.Dropout, nn.Dropout2d)):
             m.p = 0.0
-        if isinstance(m, nn.GRU):
+        if isinstance(m, (nn.GRU, nn.LSTM)):
             m.dropout = 0.0
 
 

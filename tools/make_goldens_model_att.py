@@ -35,7 +35,7 @@ def zero_dropout(mod):
     for m in mod.modules():
         if isinstance(m, (nn.Dropout, nn.Dropout2d)):
             m.p = 0.0
-        if isinstance(m, nn.GRU):
+        if isinstance(m, (nn.GRU, nn.LSTM)):
             m.dropout = 0.0
 
 
@@ -60,6 +60,26 @@ def main():
         m = ref_bm.two_d_cnn_lstm(1, F, 64)
         m.load_state_dict(closed_form_state(m, prefix="defaults."))
         out["defaults_eval_logits"] = m.eval()(x, gf).numpy()
+        # deep_two_d_cnn_lstm_tmp (:388-509): deep stack + LSTM (its default cell), hidden 64, flatten head
+        m = ref_bm.deep_two_d_cnn_lstm_tmp(1, F, 64, lstm_hidden_size=64, num_layers_lstm=2, pred="emotion",
+                                           attention_size=128, att=None, global_feature=0)
+        m.load_state_dict(closed_form_state(m, prefix="tmp."))
+        out["tmp_lstm_eval_logits"] = m.eval()(x).numpy()
+    # one train-mode step of the LSTM model (dropout off): loss and gradient norms / slices
+    m = ref_bm.deep_two_d_cnn_lstm_tmp(1, F, 64, lstm_hidden_size=64, num_layers_lstm=2, pred="emotion",
+                                       attention_size=128, att=None, global_feature=0)
+    m.load_state_dict(closed_form_state(m, prefix="tmp."))
+    m.train()
+    zero_dropout(m)
+    loss = nn.functional.cross_entropy(m(x), le.view(-1))
+    loss.backward()
+    out["tmp_lstm_train_loss"] = np.array(loss.item())
+    for name in ("rnn.weight_hh_l1", "rnn.weight_ih_l1_reverse", "rnn.bias_hh_l0", "dense1.weight"):
+        g = dict(m.named_parameters())[name].grad
+        out["tmp_lstm_grad_" + name] = sl(g)
+        out["tmp_lstm_gradnorm_" + name] = np.array(g.double().norm().item())
+    with torch.no_grad():
+        pass
     # GRL wrapper with attention in both branches, one train-mode step (dropout off, eps injected)
     emo, gen = mk("emotion", "self_att", 0, "emotion."), mk("gender", "self_att", 0, "gender.")
     noise = ref_cm.cloak_noise(torch.zeros(1, W, F), torch.ones(1, W, F), torch.tensor(0.01), torch.tensor(10.0), "cpu")
