@@ -143,9 +143,9 @@ struct BnFwdArgs {
   int B, H, W, C, pool;
 };
 
-template <int CPP>
+template <int CPP, int P>
 __global__ __launch_bounds__(256) void sept_bn_relu_pool_fwd_kernel(BnFwdArgs a) {
-  const int C = CPP * 8, P = a.pool;
+  constexpr int C = CPP * 8;
   const int Ho = a.H / P, Wo = a.W / P;
   const long n_items = long(a.B) * Ho * Wo * CPP;
   const int chunk = threadIdx.x % CPP;  // 256 % CPP == 0: the chunk of a lane never changes
@@ -156,13 +156,16 @@ __global__ __launch_bounds__(256) void sept_bn_relu_pool_fwd_kernel(BnFwdArgs a)
     const long px = i / CPP;
     const int wo = px % Wo, ho = (px / Wo) % Ho, b = px / (long(Wo) * Ho);
     const bf16* xp = a.x + ((long(b) * a.H + ho * P) * a.W + wo * P) * C + chunk * 8;
-    f32x8 m = {0, 0, 0, 0, 0, 0, 0, 0};  // relu floor
-    for (int dh = 0; dh < P; ++dh)
-      for (int dw = 0; dw < P; ++dw) {
-        const f32x8 v = load8(xp + (long(dh) * a.W + dw) * C) * sc + sh;
+    f32x8 xv[P * P];   // the window's loads are issued together
 #pragma unroll
-        for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], v[e]);
-      }
+    for (int q = 0; q < P * P; ++q) xv[q] = load8(xp + (long(q / P) * a.W + q % P) * C);
+    f32x8 m = {0, 0, 0, 0, 0, 0, 0, 0};  // relu floor
+#pragma unroll
+    for (int q = 0; q < P * P; ++q) {
+      const f32x8 v = xv[q] * sc + sh;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], v[e]);
+    }
     if (a.drop) m *= loadf8(a.drop + long(b) * C + chunk * 8);
     store8(a.y + px * C + chunk * 8, m);
   }
@@ -394,8 +397,13 @@ extern "C" int sept_bn_relu_pool_forward(const void* x, const float* mean, const
               B, H, W, C, pool};
   const long items = long(B) * (H / pool) * (W / pool) * (C / 8);
   const int grid = int(std::min<long>((items + 255) / 256, 4096));
-  SEPT_CPP_DISPATCH(C, hipLaunchKernelGGL(sept_bn_relu_pool_fwd_kernel<CPP>, dim3(grid), dim3(256), 0,
-                                          static_cast<hipStream_t>(stream), a));
+  if (pool == 2) {
+    SEPT_CPP_DISPATCH(C, hipLaunchKernelGGL((sept_bn_relu_pool_fwd_kernel<CPP, 2>), dim3(grid), dim3(256), 0,
+                                            static_cast<hipStream_t>(stream), a));
+  } else {
+    SEPT_CPP_DISPATCH(C, hipLaunchKernelGGL((sept_bn_relu_pool_fwd_kernel<CPP, 1>), dim3(grid), dim3(256), 0,
+                                            static_cast<hipStream_t>(stream), a));
+  }
   return sept::launch_check("sept_bn_relu_pool_fwd_kernel");
 }
 
