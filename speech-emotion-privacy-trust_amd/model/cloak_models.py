@@ -15,6 +15,8 @@ except ImportError:
     import _paths  # noqa: F401
     from reversal_gradient import GradientReversal
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -93,6 +95,18 @@ class two_d_cnn_lstm_syn(nn.Module):
         return preds, noisy
 
 
+# run the emotion and the gender branch of the GRL step on two HIP streams (SEPT_CONCURRENT=0 disables)
+CONCURRENT_BRANCHES = os.environ.get("SEPT_CONCURRENT", "1") != "0"
+_STREAMS = {}
+
+
+def _branch_streams(device):
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _STREAMS:
+        _STREAMS[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+    return _STREAMS[key]
+
+
 class two_d_cnn_lstm_syn_with_grl(nn.Module):
     def __init__(self, original_model, gender_model, noise_model, grl_lambda):
         super().__init__()
@@ -109,8 +123,32 @@ class two_d_cnn_lstm_syn_with_grl(nn.Module):
         noisy = x.detach()
         pool = _pool_arg(pooling)
         att = self.original_model.att   # the reference keys BOTH branches on the emotion model's flag (:171, :208)
-        preds1 = self.original_model.hip_logits(x, 'emotion', pool, global_feature=global_feature, att=att)
-        # gender branch: the GradientReversal module sits in front of its conv stack
-        xr = self.gender_model.conv[0](x)
-        preds2 = self.gender_model.hip_logits(xr, 'gender', pool, global_feature=global_feature, att=att)
+        if not (CONCURRENT_BRANCHES and x.is_cuda):
+            preds1 = self.original_model.hip_logits(x, 'emotion', pool, global_feature=global_feature, att=att)
+            # gender branch: the GradientReversal module sits in front of its conv stack
+            xr = self.gender_model.conv[0](x)
+            preds2 = self.gender_model.hip_logits(xr, 'gender', pool, global_feature=global_feature, att=att)
+            return preds1, preds2, noisy
+        # The two branches only share the noisy input: each runs on its own HIP stream (forward here,
+        # backward on the same streams through autograd), so the latency-bound kernels of one (GRU
+        # steps, small GEMMs, reductions) fill the gaps of the other's.  Kernels stay deterministic;
+        # only their interleaving changes.
+        cur = torch.cuda.current_stream(x.device)
+        s1, s2 = _branch_streams(x.device)
+        s1.wait_stream(cur)
+        s2.wait_stream(cur)
+        capturing = torch.cuda.is_current_stream_capturing()   # graph-private memory needs no stream records
+        if not capturing:
+            x.record_stream(s1)
+            x.record_stream(s2)
+        with torch.cuda.stream(s1):
+            preds1 = self.original_model.hip_logits(x, 'emotion', pool, global_feature=global_feature, att=att)
+        with torch.cuda.stream(s2):
+            xr = self.gender_model.conv[0](x)
+            preds2 = self.gender_model.hip_logits(xr, 'gender', pool, global_feature=global_feature, att=att)
+        cur.wait_stream(s1)
+        cur.wait_stream(s2)
+        if not capturing:
+            preds1.record_stream(cur)
+            preds2.record_stream(cur)
         return preds1, preds2, noisy

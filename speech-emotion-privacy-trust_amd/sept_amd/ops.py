@@ -80,8 +80,9 @@ _WS = {}
 
 
 def workspace(name: str, nfloats: int, device) -> torch.Tensor:
-    """Persistent fp32 scratch per (purpose, device); reused across calls on one stream."""
-    key = (name, str(device))
+    """Persistent fp32 scratch per (purpose, device, stream): kernels enqueued on different streams
+    (the two branches of the GRL step) must not share a workspace."""
+    key = (name, str(device), torch.cuda.current_stream(device).cuda_stream)
     t = _WS.get(key)
     if t is None or t.numel() < nfloats:
         t = _WS[key] = torch.empty(int(nfloats), dtype=torch.float32, device=device)
