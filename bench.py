@@ -196,7 +196,9 @@ def main():
     ap.add_argument("--clips-per-gpu", type=int, default=32)
     ap.add_argument("--mels", type=int, default=80)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph")
+    ap.add_argument("--graph", dest="graph", action="store_true", default=True,
+                    help="replay the step from a captured HIP graph (default)")
+    ap.add_argument("--no-graph", dest="graph", action="store_false", help="enqueue every kernel from the host each step")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -266,11 +268,19 @@ def main():
 
     step_fn = None
     if a.graph:
+        # the whole step (features, both branches on their two streams, loss, backward, gradient packing) is
+        # captured once and replayed; the all-reduce and the optimiser kernel stay outside the graph.  If the
+        # capture is refused the eager step is used (a performance choice only: the same kernels run either way)
+        timer = ops.TIMER
         ops.TIMER = None
-        step_fn = pipe.capture(wav, le, lg, weights)
-        for _ in range(2):
-            step_fn()
-        torch.cuda.synchronize()
+        try:
+            step_fn = pipe.capture(wav, le, lg, weights)
+            for _ in range(2):
+                step_fn()
+            torch.cuda.synchronize()
+        except Exception as e:   # noqa: BLE001
+            print(f"bench: HIP graph capture unavailable ({type(e).__name__}: {e}); timing the eager step", file=sys.stderr)
+            step_fn, a.graph, ops.TIMER = None, False, timer
 
     # ---- timed region ----
     barrier()
