@@ -227,7 +227,9 @@ class FusedPipeline:
         tr.model.train()
         tr.flat.zero_grad()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # thread_local: other threads (e.g. the RCCL watchdog of a process group polling its events) may keep
+        # calling the runtime while this thread captures
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             _advance_rng(wav.device)
             x = self.features(wav)
             preds, preds_grl, _ = tr.model(x.view(x.shape[0], 1, self.win, self.n_mels), mask=None, grl=False,
