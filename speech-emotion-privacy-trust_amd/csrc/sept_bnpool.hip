@@ -20,7 +20,8 @@ typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) float f32x8;
 
-constexpr int kParts = 512;  // partial-sum blocks (workspace rows)
+constexpr int kParts = 2048;     // most partial-sum blocks of a reduction pass (workspace columns)
+constexpr int kStatParts = 512;  // blocks of the forward statistics pass (its per-block epilogue is heavier)
 
 __device__ __forceinline__ f32x8 load8(const bf16* p) {
   const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
@@ -37,9 +38,10 @@ __device__ __forceinline__ f32x8 loadf8(const float* p) {
 }
 
 // block-level deterministic reduction of per-thread (a[8], b[8]) over the threads sharing a
-// channel chunk; writes [2C] floats (sum_a[C], sum_b[C]) to dst.
+// channel chunk; writes this block's column of the TRANSPOSED partials ws[2C][nparts] (sum_a[C] rows,
+// then sum_b[C] rows), so that the finalize pass reads each statistic contiguously.
 template <int CPP>
-__device__ __forceinline__ void block_reduce_2c(const f32x8& a, const f32x8& b, float* dst, float* lds) {
+__device__ __forceinline__ void block_reduce_2c(const f32x8& a, const f32x8& b, float* ws, int nparts, float* lds) {
   const int tid = threadIdx.x;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -52,8 +54,26 @@ __device__ __forceinline__ void block_reduce_2c(const f32x8& a, const f32x8& b, 
     const int which = tid / C, c = tid % C, chunk = c / 8, e = c % 8;
     float s = 0.f;
     for (int t = chunk; t < 256; t += CPP) s += lds[t * 16 + which * 8 + e];
-    dst[tid] = s;
+    ws[size_t(tid) * nparts + blockIdx.x] = s;
   }
+}
+
+// one workgroup per channel adds up a row pair of the transposed partials in float64 and a fixed order:
+// threads 0-127 the first statistic, 128-255 the second; returns both totals to thread 0
+__device__ __forceinline__ void channel_totals(const float* parts, int nparts, int C, int c, double& t0, double& t1) {
+  __shared__ double red[256];
+  const int which = threadIdx.x >> 7, t = threadIdx.x & 127;
+  const float* p = parts + (size_t(which) * C + c) * nparts;
+  double acc = 0.0;
+  for (int i = t; i < nparts; i += 128) acc += double(p[i]);
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int k = 64; k > 0; k >>= 1) {
+    if (t < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  t0 = red[0];
+  t1 = red[128];
 }
 
 // ---- forward statistics -------------------------------------------------------------------
@@ -74,15 +94,16 @@ __global__ __launch_bounds__(256) void sept_bn_stats_partial_kernel(const bf16* 
     s += v;
     ss += v * v;
   }
-  block_reduce_2c<CPP>(s, ss, ws + size_t(blockIdx.x) * 2 * CPP * 8, lds);
+  block_reduce_2c<CPP>(s, ss, ws, gridDim.x, lds);
 }
 
-__global__ void sept_bn_stats_finalize_kernel(const float* ws, int nparts, int C, double n, float* mean,
-                                              float* invstd, float* running_mean, float* running_var,
-                                              long long* nbt, float momentum, float eps) {
-  const int c = blockIdx.x;  // one wave per channel
-  const double s = sept::wave_sum_partials(ws, nparts, size_t(2) * C, c);
-  const double ss = sept::wave_sum_partials(ws, nparts, size_t(2) * C, size_t(C) + c);
+__global__ __launch_bounds__(256) void sept_bn_stats_finalize_kernel(const float* ws, int nparts, int C, double n,
+                                                                     float* mean, float* invstd, float* running_mean,
+                                                                     float* running_var, long long* nbt, float momentum,
+                                                                     float eps) {
+  const int c = blockIdx.x;  // one workgroup per channel
+  double s, ss;
+  channel_totals(ws, nparts, C, c, s, ss);
   if (threadIdx.x != 0) return;
   if (c == 0 && nbt) *nbt += 1;
   const double m = s / n;
@@ -99,10 +120,10 @@ __global__ void sept_bn_stats_finalize_kernel(const float* ws, int nparts, int C
 
 // sync-BN pieces: float64 per-channel (sum, sum of squares) of this rank's shard, and the statistics
 // from sums that were added up over the ranks
-__global__ void sept_bn_sums_kernel(const float* ws, int nparts, int C, double* sums) {
+__global__ __launch_bounds__(256) void sept_bn_sums_kernel(const float* ws, int nparts, int C, double* sums) {
   const int c = blockIdx.x;
-  const double s = sept::wave_sum_partials(ws, nparts, size_t(2) * C, c);
-  const double ss = sept::wave_sum_partials(ws, nparts, size_t(2) * C, size_t(C) + c);
+  double s, ss;
+  channel_totals(ws, nparts, C, c, s, ss);
   if (threadIdx.x == 0) {
     sums[c] = s;
     sums[C + c] = ss;
@@ -176,7 +197,7 @@ struct BnBwdArgs {
   const bf16* dy;  // [B][Ho][Wo][C]
   const bf16* x;   // pre-BN conv output [B][H][W][C]
   const float *mean, *invstd, *gamma, *beta, *drop;
-  float* ws;        // partials [kParts][2C], then sums at ws + kParts*2C
+  float* ws;        // transposed partials [2C][blocks] (blocks <= kParts), then sums at ws + kParts*2C
   bf16* dx;         // [B][H][W][C]
   int B, H, W, C, pool;
   const float* sums;  // [2C] sum dy, sum dy*xhat used by the apply pass (the local ones in ws, or all-reduced ones)
@@ -242,13 +263,14 @@ __global__ __launch_bounds__(256) void sept_bn_bwd_reduce_kernel(BnBwdArgs a) {
     s1 += g;
     s2 += g * xh;
   }
-  block_reduce_2c<CPP>(s1, s2, a.ws + size_t(blockIdx.x) * 2 * CPP * 8, lds);
+  block_reduce_2c<CPP>(s1, s2, a.ws, gridDim.x, lds);
 }
 
-__global__ void sept_bn_bwd_finalize_kernel(float* ws, int nparts, int C, float* dgamma, float* dbeta, float* sums_out) {
-  const int c = blockIdx.x;  // one wave per channel
-  const double s1 = sept::wave_sum_partials(ws, nparts, size_t(2) * C, c);
-  const double s2 = sept::wave_sum_partials(ws, nparts, size_t(2) * C, size_t(C) + c);
+__global__ __launch_bounds__(256) void sept_bn_bwd_finalize_kernel(float* ws, int nparts, int C, float* dgamma,
+                                                                   float* dbeta, float* sums_out) {
+  const int c = blockIdx.x;  // one workgroup per channel
+  double s1, s2;
+  channel_totals(ws, nparts, C, c, s1, s2);
   if (threadIdx.x != 0) return;
   float* sums = ws + size_t(kParts) * 2 * C;
   sums[c] = float(s1);      // sum dy      (= dbeta)
@@ -306,7 +328,7 @@ __global__ __launch_bounds__(256) void sept_bn_bwd_apply_kernel(BnBwdArgs a) {
   }
 }
 
-int grid_for(long items) { return int(std::min<long>((items + 255) / 256, kParts)); }
+int grid_for(long items, int cap = kParts) { return int(std::min<long>((items + 255) / 256, cap)); }
 
 }  // namespace
 
@@ -326,43 +348,12 @@ extern "C" int sept_bn_stats(const void* x, long n_rows, int C, float* ws, float
   SEPT_REQUIRE(x && ws && mean && invstd && n_rows > 0, SEPT_ERR_INVALID, "sept_bn_stats: bad argument");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const long items = n_rows * (C / 8);
-  const int grid = grid_for(items);
+  const int grid = grid_for(items, kStatParts);
   SEPT_CPP_DISPATCH(C, hipLaunchKernelGGL(sept_bn_stats_partial_kernel<CPP>, dim3(grid), dim3(256), 0, st,
                                           static_cast<const bf16*>(x), items, ws));
-  hipLaunchKernelGGL(sept_bn_stats_finalize_kernel, dim3(C), dim3(64), 0, st, ws, grid, C,
+  hipLaunchKernelGGL(sept_bn_stats_finalize_kernel, dim3(C), dim3(256), 0, st, ws, grid, C,
                      double(n_rows), mean, invstd, running_mean, running_var, num_batches_tracked, momentum, eps);
   return sept::launch_check("sept_bn_stats");
-}
-
-// finalize over TRANSPOSED partials [2C][nparts] (one workgroup per channel; threads 0-127 add up the
-// sums, 128-255 the sums of squares, in float64 and in a fixed order)
-__global__ __launch_bounds__(256) void sept_bn_stats_finalize_t_kernel(const float* parts, int nparts, int C, double n,
-                                                                       float* mean, float* invstd, float* running_mean,
-                                                                       float* running_var, long long* nbt, float momentum,
-                                                                       float eps) {
-  __shared__ double red[256];
-  const int c = blockIdx.x, which = threadIdx.x >> 7, t = threadIdx.x & 127;
-  const float* p = parts + (size_t(which) * C + c) * nparts;
-  double acc = 0.0;
-  for (int i = t; i < nparts; i += 128) acc += double(p[i]);
-  red[threadIdx.x] = acc;
-  __syncthreads();
-  for (int k = 64; k > 0; k >>= 1) {
-    if (t < k) red[threadIdx.x] += red[threadIdx.x + k];
-    __syncthreads();
-  }
-  if (threadIdx.x != 0) return;
-  if (c == 0 && nbt) *nbt += 1;
-  const double m = red[0] / n;
-  double var = red[128] / n - m * m;
-  var = var < 0 ? 0 : var;
-  mean[c] = float(m);
-  invstd[c] = float(1.0 / sqrt(var + double(eps)));
-  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * float(m);
-  if (running_var) {
-    const double unbiased = n > 1 ? var * n / (n - 1) : var;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * float(unbiased);
-  }
 }
 
 // statistics from per-workgroup partials, TRANSPOSED [2C][nparts], left by a producer kernel (sept_conv1_forward_stats)
@@ -371,7 +362,7 @@ extern "C" int sept_bn_stats_from_partials(const float* partials, int nparts, lo
                                            long long* num_batches_tracked, float momentum, float eps, void* stream) {
   SEPT_REQUIRE(partials && mean && invstd && nparts > 0 && n_rows > 0 && C > 0, SEPT_ERR_INVALID,
                "sept_bn_stats_from_partials: bad argument");
-  hipLaunchKernelGGL(sept_bn_stats_finalize_t_kernel, dim3(C), dim3(256), 0, static_cast<hipStream_t>(stream), partials,
+  hipLaunchKernelGGL(sept_bn_stats_finalize_kernel, dim3(C), dim3(256), 0, static_cast<hipStream_t>(stream), partials,
                      nparts, C, double(n_rows), mean, invstd, running_mean, running_var, num_batches_tracked, momentum, eps);
   return sept::launch_check("sept_bn_stats_from_partials");
 }
@@ -417,7 +408,7 @@ int bn_bwd_launch_reduce(BnBwdArgs& a, float* dgamma, float* dbeta, float* sums_
   } else {
     SEPT_CPP_DISPATCH(C, hipLaunchKernelGGL((sept_bn_bwd_reduce_kernel<CPP, 1>), dim3(grid), dim3(256), 0, st, a));
   }
-  hipLaunchKernelGGL(sept_bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, a.ws, grid, C, dgamma, dbeta, sums_out);
+  hipLaunchKernelGGL(sept_bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, a.ws, grid, C, dgamma, dbeta, sums_out);
   return SEPT_OK;
 }
 int bn_bwd_launch_apply(BnBwdArgs& a, hipStream_t st) {
@@ -457,10 +448,10 @@ extern "C" int sept_bn_partial_sums(const void* x, long n_rows, int C, float* ws
   SEPT_REQUIRE(x && ws && sums && n_rows > 0, SEPT_ERR_INVALID, "sept_bn_partial_sums: bad argument");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const long items = n_rows * (C / 8);
-  const int grid = grid_for(items);
+  const int grid = grid_for(items, kStatParts);
   SEPT_CPP_DISPATCH(C, hipLaunchKernelGGL(sept_bn_stats_partial_kernel<CPP>, dim3(grid), dim3(256), 0, st,
                                           static_cast<const bf16*>(x), items, ws));
-  hipLaunchKernelGGL(sept_bn_sums_kernel, dim3(C), dim3(64), 0, st, ws, grid, C, sums);
+  hipLaunchKernelGGL(sept_bn_sums_kernel, dim3(C), dim3(256), 0, st, ws, grid, C, sums);
   return sept::launch_check("sept_bn_partial_sums");
 }
 
