@@ -289,6 +289,18 @@ int sept_dropout_mask(float* out, long n, float p, unsigned long long seed, cons
 int sept_normal(float* out, long n, float mean, float stdv, unsigned long long seed, const long long* offset_dev,
                 unsigned long long offset, void* stream);
 int sept_counter_add(long long* counter, long long inc, void* stream);
+/* Fused classifier head for the common case (att None, mean pooling, no global features; baseline_models.py:231-258):
+ * z = mean_t(x (B, T, D)); d1 = z W1^T + b1; d1a = relu(d1) * dropscale (NULL = 1); logits (B, NC) = d1a Wh^T + bh, Wh
+ * (NC, D1) being the prediction layer (both layers stacked for pred='multitask').  z, d1, d1a are kept for the
+ * backward pass; sept_head_backward returns dd1 = dL/dd1 (operand of the weight gradients, which stay GEMMs) and
+ * dx (B, T, D) = dL/dx.  D, D1 <= 256. */
+int sept_head_forward(const float* x, const float* W1, const float* b1, const float* dropscale,
+                      const float* Wh, const float* bh, float* z, float* d1, float* d1a, float* logits, int B,
+                      int T, int D, int D1, int NC, void* stream);
+int sept_head_backward(const float* dlogits, const float* Wh, const float* d1, const float* dropscale,
+                       const float* W1, float* dd1, float* dx, int B, int T, int D, int D1, int NC,
+                       void* stream);
+
 /* Multi-head self-attention pooling of two_d_cnn_lstm with att='self_att' (baseline_models.py:233-242,
  * cloak_models.py:178-186): scores (B, T, NH) = att_linear2(tanh(att_linear1(x))) come from sept_gemm +
  * sept_tanh_forward; sept_att_pool_forward takes the softmax over T per head (probs, kept for the backward

@@ -590,6 +590,68 @@ __global__ void resample_kernel(const float* x, const float* ker, float* out, in
   }
 }
 
+// ---------------- fused classifier head (baseline_models.py:231-258 with att None, mean pooling) ----------------
+// z = mean_t(x); d1 = z W1^T + b1; d1a = relu(d1) * dropscale; logits = d1a Wh^T + bh   for up to two heads.
+// Five tiny launches (mean, GEMM, relu/dropout, GEMM(s)) sit at the end of every forward chain and as many at
+// the start of every backward chain; one workgroup per sample does them back to back.  D <= 256, D1 <= 256.
+constexpr int kHeadMaxD = 256;
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* x, const float* W1, const float* b1, const float* drop,
+                                                       const float* Wh, const float* bh, float* z, float* d1, float* d1a,
+                                                       float* logits, int T, int D, int D1, int NC) {
+  __shared__ float zs[kHeadMaxD], as[kHeadMaxD];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid < D) {
+    const float* xb = x + size_t(b) * T * D + tid;
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += xb[size_t(t) * D];
+    s /= float(T);
+    zs[tid] = s;
+    z[size_t(b) * D + tid] = s;
+  }
+  __syncthreads();
+  if (tid < D1) {
+    const float* w = W1 + size_t(tid) * D;
+    float s = b1 ? b1[tid] : 0.f;
+    for (int k = 0; k < D; ++k) s = fmaf(zs[k], w[k], s);
+    const float a = fmaxf(s, 0.f) * (drop ? drop[size_t(b) * D1 + tid] : 1.0f);
+    d1[size_t(b) * D1 + tid] = s;
+    d1a[size_t(b) * D1 + tid] = a;
+    as[tid] = a;
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int c = wave; c < NC; c += 4) {   // one wave per class: dot over D1 in a fixed lane order
+    const float* w = Wh + size_t(c) * D1;
+    float s = 0.f;
+    for (int k = lane; k < D1; k += 64) s = fmaf(as[k], w[k], s);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) logits[size_t(b) * NC + c] = s + (bh ? bh[c] : 0.f);
+  }
+}
+// data path of the backward pass: d_d1a = dlogits Wh; d_d1 = d_d1a * (d1 > 0) * dropscale; dz = d_d1 W1;
+// dx[b][t][:] = dz / T.  d_d1 is also returned (operand of the weight gradients, which stay separate GEMMs).
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* dlogits, const float* Wh, const float* d1,
+                                                       const float* drop, const float* W1, float* dd1, float* dx, int T,
+                                                       int D, int D1, int NC) {
+  __shared__ float gs[kHeadMaxD];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid < D1) {
+    float s = 0.f;
+    for (int c = 0; c < NC; ++c) s = fmaf(dlogits[size_t(b) * NC + c], Wh[size_t(c) * D1 + tid], s);
+    const float g = d1[size_t(b) * D1 + tid] > 0.f ? s * (drop ? drop[size_t(b) * D1 + tid] : 1.0f) : 0.f;
+    gs[tid] = g;
+    dd1[size_t(b) * D1 + tid] = g;
+  }
+  __syncthreads();
+  if (tid < D) {
+    float s = 0.f;
+    for (int j = 0; j < D1; ++j) s = fmaf(gs[j], W1[size_t(j) * D + tid], s);
+    s /= float(T);
+    float* o = dx + size_t(b) * T * D + tid;
+    for (int t = 0; t < T; ++t) o[size_t(t) * D] = s;
+  }
+}
+
 // ---------------- optimisers (training_cloak_with_grl.py:416-421) ----------------
 // torch.optim.SGD(momentum, weight_decay, dampening 0, nesterov False)
 __global__ void sgd_kernel(float* p, const float* g, float* buf, long n, float lr, float momentum, float wd,
@@ -916,6 +978,28 @@ extern "C" int sept_resample_forward(const float* x, const float* ker, float* ou
   hipLaunchKernelGGL(resample_kernel, dim3(blocks_for(long(B) * target)), dim3(kThreads), 0, ST(stream), x, ker, out, B, L,
                      orig, newf, width, target);
   return sept::launch_check("resample_kernel");
+}
+
+extern "C" int sept_head_forward(const float* x, const float* W1, const float* b1, const float* dropscale,
+                                 const float* Wh, const float* bh, float* z, float* d1, float* d1a, float* logits, int B,
+                                 int T, int D, int D1, int NC, void* stream) {
+  if (B == 0) return SEPT_OK;
+  SEPT_REQUIRE(x && W1 && Wh && z && d1 && d1a && logits && B > 0 && T > 0 && D > 0 && D <= kHeadMaxD && D1 > 0 &&
+                   D1 <= kHeadMaxD && NC > 0, SEPT_ERR_INVALID, "sept_head_forward: B=%d T=%d D=%d D1=%d NC=%d", B, T, D, D1, NC);
+  hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), 0, ST(stream), x, W1, b1, dropscale, Wh, bh, z, d1, d1a, logits,
+                     T, D, D1, NC);
+  return sept::launch_check("head_fwd_kernel");
+}
+
+extern "C" int sept_head_backward(const float* dlogits, const float* Wh, const float* d1, const float* dropscale,
+                                  const float* W1, float* dd1, float* dx, int B, int T, int D, int D1, int NC,
+                                  void* stream) {
+  if (B == 0) return SEPT_OK;
+  SEPT_REQUIRE(dlogits && Wh && d1 && W1 && dd1 && dx && B > 0 && T > 0 && D > 0 && D <= kHeadMaxD && D1 > 0 &&
+                   D1 <= kHeadMaxD && NC > 0, SEPT_ERR_INVALID, "sept_head_backward: B=%d T=%d D=%d D1=%d NC=%d", B, T, D, D1, NC);
+  hipLaunchKernelGGL(head_bwd_kernel, dim3(B), dim3(256), 0, ST(stream), dlogits, Wh, d1, dropscale, W1, dd1, dx, T, D, D1,
+                     NC);
+  return sept::launch_check("head_bwd_kernel");
 }
 
 extern "C" int sept_sgd_step(float* p, const float* g, float* momentum_buf, long n, float lr, float momentum,

@@ -242,6 +242,22 @@ def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None, gfeat=Non
         S.gru.append(Gs)
     out1 = S.gru[1].out
     S.att = None
+    S.fused_head = (P.att is None and pooling == "mean" and gfeat is None and H2 <= 256
+                    and P.dense1.weight.shape == (P.dense1.weight.shape[0], H2) and P.dense1.weight.shape[0] <= 256)
+    if S.fused_head:   # mean over time + dense1 + ReLU/dropout + prediction layer(s) in one launch
+        dmask = None
+        if train and (P.dense_p > 0 or "dense" in inj):
+            m = inj.get("dense")
+            dmask = m if m is not None else masks["dense"]
+        if len(P.heads) == 1:
+            wh, bh = P.heads[0].weight, P.heads[0].bias
+        else:   # pred='multitask': the two prediction layers stacked into one (NC, D1) operand
+            wh = torch.cat([h.weight.detach() for h in P.heads]).contiguous()
+            bh = torch.cat([h.bias.detach() for h in P.heads]).contiguous()
+        logits, z, d1, d1a = ops.head_forward(out1, P.dense1.weight, P.dense1.bias, dmask, wh, bh)
+        S.zdim = z.shape[1]
+        S.z, S.d1, S.dmask, S.d1a, S.wh = z, d1, dmask, d1a, wh
+        return logits, (S if need_grad else None)
     if P.att == "self_att":   # baseline_models.py:233-242: 16-head additive attention over time
         x2 = out1.view(B * T, H2)
         a1t = ops.tanh_forward(ops.linear_forward(x2, P.att1.weight, P.att1.bias))
@@ -283,6 +299,21 @@ def trunk_backward(S, P, dlogits, need_wgrad=True, need_dx=True):
             grads[param] = g
 
     dlogits = dlogits.contiguous()
+    Hh = S.Hh
+    H2, G = 2 * Hh, (4 if S.lstm else 3) * Hh
+    if S.fused_head:
+        d_d1, dout = ops.head_backward(dlogits, S.wh, S.d1, S.dmask, P.dense1.weight, T)
+        if need_wgrad:
+            c0 = 0
+            for h in P.heads:
+                n = h.weight.shape[0]
+                dl = dlogits[:, c0:c0 + n]
+                c0 += n
+                put(h.weight, ops.linear_backward_weight(dl, S.d1a))
+                put(h.bias, ops.colsum(dl))
+            put(P.dense1.weight, ops.linear_backward_weight(d_d1, S.z))
+            put(P.dense1.bias, ops.colsum(d_d1))
+        return _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx)
     d_d1a, c0 = None, 0
     for h in P.heads:
         n = h.weight.shape[0]
@@ -322,6 +353,14 @@ def trunk_backward(S, P, dlogits, need_wgrad=True, need_dx=True):
         ops.gemm_raw(d_a1, d_a1.stride(0), 1, w1, w1.shape[1], 1, dout, H2, B * T, H2, w1.shape[0], beta=1.0)
     else:
         dout = ops.mean_t_backward(dz, T) if S.pooling == "mean" else dz.view(B, T, H2)
+    return _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx)
+
+
+def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx):
+    """The recurrent layers and the conv stack of trunk_backward, from the gradient of the last recurrent output."""
+    B, T = S.B, S.T
+    Hh = S.Hh
+    H2, G = 2 * Hh, (4 if S.lstm else 3) * Hh
     r = P.rnn
     dseq = None
     for layer in (1, 0):

@@ -424,6 +424,31 @@ def relu_dropout_backward(dy, x, dropscale=None):
     return dx
 
 
+def head_forward(x, W1, b1, dropscale, Wh, bh):
+    """Fused mean-over-time + dense1 + ReLU/dropout + prediction layer(s): x (B,T,D) -> (logits (B,NC), z, d1, d1a)."""
+    B, T, D = x.shape
+    D1, NC = W1.shape[0], Wh.shape[0]
+    dev = x.device
+    z = torch.empty((B, D), dtype=torch.float32, device=dev)
+    d1 = torch.empty((B, D1), dtype=torch.float32, device=dev)
+    d1a = torch.empty_like(d1)
+    logits = torch.empty((B, NC), dtype=torch.float32, device=dev)
+    check(lib.sept_head_forward(x.data_ptr(), W1.data_ptr(), _p(b1), _p(dropscale), Wh.data_ptr(), _p(bh), z.data_ptr(),
+                                d1.data_ptr(), d1a.data_ptr(), logits.data_ptr(), B, T, D, D1, NC, _s(x)), "sept_head_forward")
+    return logits, z, d1, d1a
+
+
+def head_backward(dlogits, Wh, d1, dropscale, W1, T):
+    """-> (dd1 (B,D1), dx (B,T,D)) of the fused head."""
+    B, NC = dlogits.shape
+    D1, D = W1.shape
+    dd1 = torch.empty((B, D1), dtype=torch.float32, device=dlogits.device)
+    dx = torch.empty((B, T, D), dtype=torch.float32, device=dlogits.device)
+    check(lib.sept_head_backward(dlogits.data_ptr(), Wh.data_ptr(), d1.data_ptr(), _p(dropscale), W1.data_ptr(),
+                                 dd1.data_ptr(), dx.data_ptr(), B, T, D, D1, NC, _s(dlogits)), "sept_head_backward")
+    return dd1, dx
+
+
 def mean_t_forward(x):
     B, T, D = x.shape
     z = torch.empty((B, D), dtype=torch.float32, device=x.device)
