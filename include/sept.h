@@ -238,6 +238,8 @@ int sept_cloak_backward(const float* dxa, const float* dxb, float gscale_b, cons
 int sept_scale(const float* x, float a, float* y, long n, void* stream);
 /* y = x * m  (GRU inter-layer dropout with a pre-scaled mask) */
 int sept_mul(const float* x, const float* m, float* y, long n, void* stream);
+/* y = x * (*scalar_dev): scale by a value that lives on the device (no host read of a loss gradient). */
+int sept_scale_dev(const float* x, const float* scalar_dev, float* y, long n, void* stream);
 /* y = relu(x) * dropscale (nullable)  -- dense_relu1 + dropout, baseline_models.py:248-249 */
 int sept_relu_dropout_forward(const float* x, const float* dropscale, float* y, long n, void* stream);
 int sept_relu_dropout_backward(const float* dy, const float* x, const float* dropscale, float* dx, long n,

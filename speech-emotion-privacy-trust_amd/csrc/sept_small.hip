@@ -93,6 +93,11 @@ __global__ __launch_bounds__(256) void cloak_bwd_kernel(const float* dxa, const 
 __global__ void scale_kernel(const float* x, float a, float* y, long n) { GRID_STRIDE(i, n) y[i] = a * x[i]; }
 
 __global__ void mul_kernel(const float* x, const float* m, float* y, long n) { GRID_STRIDE(i, n) y[i] = x[i] * m[i]; }
+// y = x * (*s): a scale that lives on the device (the upstream gradient of a scalar loss)
+__global__ void scale_dev_kernel(const float* x, const float* s, float* y, long n) {
+  const float a = *s;
+  GRID_STRIDE(i, n) y[i] = a * x[i];
+}
 
 // y = relu(x) * dropscale
 __global__ void relu_drop_fwd_kernel(const float* x, const float* m, float* y, long n) {
@@ -723,6 +728,13 @@ extern "C" int sept_scale(const float* x, float a, float* y, long n, void* strea
   SEPT_REQUIRE(x && y && n > 0, SEPT_ERR_INVALID, "sept_scale: bad argument");
   hipLaunchKernelGGL(scale_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, ST(stream), x, a, y, n);
   return sept::launch_check("scale_kernel");
+}
+
+extern "C" int sept_scale_dev(const float* x, const float* scalar_dev, float* y, long n, void* stream) {
+  if (n == 0) return SEPT_OK;
+  SEPT_REQUIRE(x && scalar_dev && y && n > 0, SEPT_ERR_INVALID, "sept_scale_dev: bad argument");
+  hipLaunchKernelGGL(scale_dev_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, ST(stream), x, scalar_dev, y, n);
+  return sept::launch_check("scale_dev_kernel");
 }
 
 extern "C" int sept_mul(const float* x, const float* m, float* y, long n, void* stream) {

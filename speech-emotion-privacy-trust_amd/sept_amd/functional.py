@@ -552,8 +552,8 @@ class GrlStepLossFn(torch.autograd.Function):
     def backward(ctx, g):
         d1, d2 = ctx.d
         # g is the upstream scalar (1.0 for loss.backward()); keep it on-device
-        gd1 = ops.mul(d1, g.expand_as(d1).contiguous())
-        gd2 = ops.mul(d2, g.expand_as(d2).contiguous()) if d2 is not None else None
+        gd1 = ops.scale_dev(d1, g)
+        gd2 = ops.scale_dev(d2, g) if d2 is not None else None
         drhos = None
         if ctx.scale_cfg is not None:
             lam, mn, mx, mean = ctx.scale_cfg
@@ -561,7 +561,7 @@ class GrlStepLossFn(torch.autograd.Function):
             zero = torch.zeros((1, rh.numel()), dtype=torch.float32, device=rh.device)
             _, drhos = ops.cloak_backward(zero, None, 0.0, rh, zero.view_as(rh), None, mn, mx, scale_lambda=lam,
                                           scale_mean=mean, need_locs=False)
-            drhos = ops.mul(drhos, g.expand_as(drhos).contiguous())
+            drhos = ops.scale_dev(drhos, g)
         return gd1, gd2, None, None, None, None, None, drhos, None, None
 
 

@@ -478,6 +478,14 @@ def loss_sub_log(loss, mean, lam):
     check(lib.sept_loss_sub_log(loss.data_ptr(), mean.data_ptr(), float(lam), _s(loss)), "sept_loss_sub_log")
 
 
+def scale_dev(x, scalar):
+    """x * scalar for a 0-dim fp32 DEVICE tensor `scalar` (one launch, no broadcast copy)."""
+    y = torch.empty_like(x)
+    sc = scalar.detach().reshape(()).float()
+    check(lib.sept_scale_dev(x.data_ptr(), sc.data_ptr(), y.data_ptr(), x.numel(), _s(x)), "sept_scale_dev")
+    return y
+
+
 def tanh_forward(x):
     y = torch.empty_like(x)
     check(lib.sept_tanh_forward(x.data_ptr(), y.data_ptr(), x.numel(), _s(x)), "sept_tanh_forward")
