@@ -166,12 +166,27 @@ def secondary(a, dev):
         per = {t: n * ms / 2 for t, (n, ms) in ops.TIMER.summary().items() if "wgrad" not in t}
         dominant = max(per, key=per.get)
         ops.TIMER = ops.KernelTimer(tags={dominant})
+    step = lambda: tr.train_step(x, le, w)   # noqa: E731
+    if a.graph:
+        timer, ops.TIMER = ops.TIMER, None
+        try:
+            step = tr.capture(x, le, w)
+            step()
+            torch.cuda.synchronize()
+        except Exception as e:   # noqa: BLE001
+            print(f"bench: HIP graph capture unavailable ({type(e).__name__}: {e}); timing the eager step", file=sys.stderr)
+            a.graph, ops.TIMER = False, timer
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        tr.train_step(x, le, w)
+        step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if a.workload == "baseline2d":
+        if a.graph:   # kernels inside a replay cannot be bracketed by events: time the kernel over a few eager steps
+            ops.TIMER = ops.KernelTimer(tags={dominant})
+            for _ in range(3):
+                tr.train_step(x, le, w)
+            torch.cuda.synchronize()
         n_launch, k_ms = ops.TIMER.summary()[dominant]
         ops.TIMER = None
         fl = conv_flops(dominant, Bw, F)
@@ -181,7 +196,8 @@ def secondary(a, dev):
     return {"metric": "windows/sec, baseline emotion CNN train step (BASELINE config 3)",
             "value": round(Bw * a.steps / dt, 1), "unit": "windows/s", "ms_per_step": round(dt / a.steps * 1e3, 3),
             "dtype": "bf16" if a.workload == "baseline2d" else "f32",
-            "config": {"workload": f"{cls.__name__} emotion fwd+bwd+SGD, {Bw} windows of 200 x {F}", "windows": Bw},
+            "config": {"workload": f"{cls.__name__} emotion fwd+bwd+SGD, {Bw} windows of 200 x {F}", "windows": Bw,
+                       "hip_graph": bool(a.graph)},
             "roofline": roof}
 
 

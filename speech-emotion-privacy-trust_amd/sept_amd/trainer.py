@@ -190,6 +190,35 @@ class BaselineTrainer:
         self.optimizer_step()
         return loss.detach(), preds.detach()
 
+    def capture(self, features, labels, weights=None):
+        """Record forward + loss + backward + gradient packing of ONE step over the given STATIC input
+        tensors into a HIP graph; returns `replay()` (graph launch, then the all-reduce and the optimiser
+        kernel eagerly).  Call after at least one eager step; refill the inputs with copy_() between
+        replays.  SGD only, as FusedPipeline.capture.  At the reference's 32 windows per step the eager
+        step is bound by its ~100 launches; the replay is not."""
+        if self.kind != "sgd" or self.steps < 1:
+            raise RuntimeError("capture() needs optimizer='sgd' and at least one eager warm-up step")
+        self.model.train()
+        self.flat.zero_grad()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            _advance_rng(features.device)
+            preds = self.model(features)
+            loss = SF.GrlStepLossFn.apply(preds, None, labels, None, weights, 0.0, 0.0, None, 0.0, 0.0)
+            loss.backward()
+            self.flat.gather_grads()
+            out = (loss.detach(), preds.detach())
+
+        def replay():
+            graph.replay()
+            if self.world > 1:
+                torch.distributed.all_reduce(self.flat.grad[:self.flat.n_active], group=self.pg)
+            self.optimizer_step()
+            return out
+
+        replay.graph = graph
+        return replay
+
 
 class FusedPipeline:
     """waveforms (B, L) on the device -> mel(n_fft 800, F) -> windows -> z-norm -> GRL step."""

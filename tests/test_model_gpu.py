@@ -617,3 +617,26 @@ def test_reference_style_training_loop_runs_unchanged():
         else:
             # the updates are a few ulps of the fp32 parameters, so the two optimisers' roundings show: 1 %
             assert float((d_tr - d_ref).norm() / d_ref.norm()) < 1e-2, n
+
+
+def test_baseline_trainer_graph_replay_equals_eager():
+    """BaselineTrainer.capture: replaying the captured step gives bit-identical parameters to eager steps."""
+    from model import baseline_models as bm
+    from sept_amd.trainer import BaselineTrainer
+    F = 80
+    x = closed_form_input(B, W, F).cuda()
+    le, _, wts = (t.cuda() for t in closed_form_labels(B))
+    res = []
+    for use_graph in (False, True):
+        m = mk(F, "emotion").train()
+        zero_dropout(m)
+        tr = BaselineTrainer(m, optimizer="sgd", lr=0.01)
+        tr.train_step(x, le, wts)
+        if use_graph:
+            step = tr.capture(x, le, wts)
+            step(), step()
+        else:
+            tr.train_step(x, le, wts), tr.train_step(x, le, wts)
+        torch.cuda.synchronize()
+        res.append(tr.flat.flat.clone())
+    assert torch.equal(res[0], res[1])
