@@ -104,6 +104,7 @@ def _branch_streams(device):
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
     if key not in _STREAMS:
         _STREAMS[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+        SF.NO_WGRAD_FORK.update(st.cuda_stream for st in _STREAMS[key])   # see functional.WGRAD_STREAM
     return _STREAMS[key]
 
 

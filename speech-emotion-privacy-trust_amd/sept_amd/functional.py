@@ -9,6 +9,7 @@ CPU or through eager torch math: torch supplies storage, views, RNG draws and th
 tape only.
 """
 import math
+import os
 from types import SimpleNamespace
 
 import torch
@@ -356,8 +357,42 @@ def trunk_backward(S, P, dlogits, need_wgrad=True, need_dx=True):
     return _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx)
 
 
+# Weight gradients are off the critical path of the backward pass (nothing downstream reads them until
+# the optimiser), so on a top-level stream they are enqueued on a side stream while the data-gradient
+# chain continues; the two join at the end of the network's backward (SEPT_WGRAD_STREAM=0 keeps one
+# stream).  Streams registered in NO_WGRAD_FORK (the two GRL branch streams, themselves forked) keep
+# everything in line: a forked stream joining another forked stream inside a HIP-graph capture crashes
+# hipStreamEndCapture on ROCm 7.2 (fork -> fork is fine, the nested JOIN is not), and the two branches
+# already fill the device.
+WGRAD_STREAM = os.environ.get("SEPT_WGRAD_STREAM", "1") != "0"
+NO_WGRAD_FORK = set()
+_WG_STREAMS = {}
+
+
+def _wgrad_stream(device):
+    cur = torch.cuda.current_stream(device).cuda_stream
+    if cur in NO_WGRAD_FORK:
+        return None
+    key = (device.index, cur)
+    if key not in _WG_STREAMS:
+        _WG_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _WG_STREAMS[key]
+
+
 def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx):
     """The recurrent layers and the conv stack of trunk_backward, from the gradient of the last recurrent output."""
+    dev = dout.device
+    wg = _wgrad_stream(dev) if (WGRAD_STREAM and need_wgrad and dout.is_cuda) else None
+    keep = []   # operands of side-stream kernels stay referenced until the join below
+
+    def side(fn, *operands):
+        """Run fn() -- weight-gradient launches only -- on the side stream, after everything enqueued so far."""
+        if wg is None:
+            return fn()
+        wg.wait_stream(torch.cuda.current_stream(dev))
+        keep.extend(operands)
+        with torch.cuda.stream(wg):
+            return fn()
     B, T = S.B, S.T
     Hh = S.Hh
     H2, G = 2 * Hh, (4 if S.lstm else 3) * Hh
@@ -374,18 +409,21 @@ def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx):
         dgi2, dgh2, hp2 = dgi.view(B * T, 2 * G), dgh.view(B * T, 2 * G), hprev.view(B * T, H2)
         K = Gs.inp.shape[1]
         if need_wgrad:
-            dwcat = ops.linear_backward_weight(dgi2, Gs.inp)      # (2G, K): both directions in one product
-            dbih = ops.colsum(dgi2)
-            dbhh = dbih if S.lstm else ops.colsum(dgh2)
-            for d, tag in ((0, ""), (1, "_reverse")):
-                gh = dgh2[:, d * G:(d + 1) * G]
-                dwih = dwcat[d * G:(d + 1) * G]
-                if layer == 0:
-                    dwih = ops.permute_cols(dwih, S.C, S.Wd, inverse=True)
-                put(getattr(r, "weight_ih" + sfx + tag), dwih)
-                put(getattr(r, "weight_hh" + sfx + tag), ops.linear_backward_weight(gh, hp2[:, d * Hh:(d + 1) * Hh]))
-                put(getattr(r, "bias_ih" + sfx + tag), dbih[d * G:(d + 1) * G])
-                put(getattr(r, "bias_hh" + sfx + tag), dbhh[d * G:(d + 1) * G])
+            def rnn_wgrads(layer=layer, sfx=sfx, Gs=Gs, dgi2=dgi2, dgh2=dgh2, hp2=hp2):
+                dwcat = ops.linear_backward_weight(dgi2, Gs.inp)      # (2G, K): both directions in one product
+                dbih = ops.colsum(dgi2)
+                dbhh = dbih if S.lstm else ops.colsum(dgh2)
+                for d, tag in ((0, ""), (1, "_reverse")):
+                    gh = dgh2[:, d * G:(d + 1) * G]
+                    dwih = dwcat[d * G:(d + 1) * G]
+                    if layer == 0:
+                        dwih = ops.permute_cols(dwih, S.C, S.Wd, inverse=True)
+                    put(getattr(r, "weight_ih" + sfx + tag), dwih)
+                    put(getattr(r, "weight_hh" + sfx + tag),
+                        ops.linear_backward_weight(gh, hp2[:, d * Hh:(d + 1) * Hh]))
+                    put(getattr(r, "bias_ih" + sfx + tag), dbih[d * G:(d + 1) * G])
+                    put(getattr(r, "bias_hh" + sfx + tag), dbhh[d * G:(d + 1) * G])
+            side(rnn_wgrads, dgi2, dgh2, hp2, Gs.inp)
         # gradient wrt the layer input: dgi [W_if; W_ir]  (one product, reduction length 2G)
         odt = torch.float32 if layer == 1 else torch.bfloat16
         din = ops.linear_nt_split(dgi2, Gs.wcatT, None, out_dtype=odt)
@@ -411,19 +449,22 @@ def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx):
             put(bn.bias, dbeta)
         if li == 0:
             if need_wgrad and cv.weight.requires_grad:
-                dw, db = ops.conv1_backward_weight(S.x, dpre)
+                dw, db = side(lambda dpre=dpre: ops.conv1_backward_weight(S.x, dpre), dpre, S.x)
                 put(cv.weight, dw)
                 put(cv.bias, db)
             if need_dx:
                 dx = ops.conv1_backward_data(dpre, cv.weight)
         else:
             if need_wgrad and cv.weight.requires_grad:
-                put(cv.weight, ops.conv5x5_backward_weight(blk.inp, dpre))
+                put(cv.weight, side(lambda blk=blk, dpre=dpre: ops.conv5x5_backward_weight(blk.inp, dpre), dpre, blk.inp))
                 # the conv bias feeds straight into a training-mode BatchNorm, whose backward has
                 # zero channel sum by construction: d(bias) == 0 (the reference gets rounding noise)
                 put(cv.bias, torch.zeros_like(cv.bias))
             wtd = _cached("convdgrad", cv.weight, lambda: ops.conv5x5_prep_weights(cv.weight, 1))
             dact = ops.conv5x5(dpre, wtd)
+    if wg is not None:   # join: the caller (autograd) sees every gradient on this branch's stream
+        torch.cuda.current_stream(dev).wait_stream(wg)
+        keep.clear()
     return dx, grads
 
 
