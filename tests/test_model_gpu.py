@@ -174,6 +174,18 @@ def test_grl_train_step_vs_reference(F, G):
     assert int(grl.gender_model.conv[1][1].num_batches_tracked) == 1
 
 
+def _randomise(grl, seed):
+    """Replace the (smooth, ill-conditioned) closed-form weights by seeded random ones of the same scale."""
+    torch.manual_seed(seed)
+    sd = {}
+    for key, v in grl.state_dict().items():
+        if v.is_floating_point() and "running_var" not in key:
+            v = (torch.randn_like(v.cpu()) * (v.float().std().cpu() + 1e-3) + v.float().mean().cpu()).to(v.dtype)
+        sd[key] = v.cpu()
+    grl.load_state_dict(sd)
+    return sd
+
+
 def test_grl_train_step_rough_data():
     """Same step on non-smooth (seeded random) inputs and weights, where arg-max ties are rare:
     every gradient of the HIP path must point the way the fp32 oracle's does.  The residual is
@@ -185,13 +197,7 @@ def test_grl_train_step_rough_data():
     le, lg, wts = closed_form_labels(B)
     grl = build_grl(F).train()
     zero_dropout(grl)
-    torch.manual_seed(7)
-    sd = {}
-    for key, v in grl.state_dict().items():
-        if v.is_floating_point() and "running_var" not in key:
-            v = (torch.randn_like(v.cpu()) * (v.float().std().cpu() + 1e-3) + v.float().mean().cpu()).to(v.dtype)
-        sd[key] = v.cpu()
-    grl.load_state_dict(sd)
+    sd = _randomise(grl, 7)
     p1, p2, _ = grl(x.cuda(), mask=None, grl=False, pooling="mean")
     SF.GrlStepLossFn.apply(p1, p2, le.cuda(), lg.cuda(), wts.cuda(), 0.1, 0.05, grl.intermed.rhos, 0.01,
                            10.0).backward()
@@ -205,6 +211,31 @@ def test_grl_train_step_rough_data():
             assert c > 0.98 and rel < 0.2, (name, c, rel)
         else:
             assert c > 0.999 and rel < 0.03, (name, c, rel)
+
+
+@pytest.mark.parametrize("Bn,F", [(1, 80), (3, 40), (13, 80), (37, 128)])
+def test_grl_train_step_ragged_batches(Bn, F):
+    """The last batch of an epoch is ragged (DataLoader without drop_last, training scripts :401-415 of the
+    reference's cloak training): batch sizes that are not multiples of any tile, down to a single window,
+    and the feature sizes the reference extracts (40 / 80 / 128).  Seeded random data, oracle comparison."""
+    from sept_amd import functional as SF
+    torch.manual_seed(11 + Bn)
+    x = torch.randn(Bn, 1, W, F)
+    le, lg, wts = closed_form_labels(Bn)
+    grl = build_grl(F).train()
+    zero_dropout(grl)
+    sd = _randomise(grl, 7)
+    p1, p2, _ = grl(x.cuda(), mask=None, grl=False, pooling="mean")
+    assert p1.shape == (Bn, 4) and p2.shape == (Bn, 2)
+    SF.GrlStepLossFn.apply(p1, p2, le.cuda(), lg.cuda(), wts.cuda(), 0.1, 0.05, grl.intermed.rhos, 0.01,
+                           10.0).backward()
+    ref = _oracle_grl(F, sd)
+    q1, q2, _ = ref(x, mask=None, grl=False, pooling="mean")
+    mo.grl_step_loss(q1, q2, le, lg, wts, 0.1, 0.05, ref).backward()
+    close_logits(p1, q1.detach().numpy())
+    close_logits(p2, q2.detach().numpy())
+    for name, (c, rel) in _grad_report(grl, ref).items():
+        assert c > (0.9 if _is_conv_stack(name) else 0.995), (name, c, rel)
 
 
 def test_syn_and_deep_variants():
