@@ -134,10 +134,13 @@ int sept_bn_eval_stats(const float* running_mean, const float* running_var, int 
 int sept_bn_relu_pool_forward(const void* x_bf16, const float* mean, const float* invstd, const float* gamma,
                               const float* beta, const float* dropscale, void* y_bf16, int B, int H, int W,
                               int C, int pool, void* stream);
-int sept_bn_relu_pool_backward(const void* dy_bf16, const void* x_bf16, const float* mean, const float* invstd,
-                               const float* gamma, const float* beta, const float* dropscale, float* ws,
-                               void* dx_bf16, float* dgamma, float* dbeta, int B, int H, int W, int C, int pool,
-                               void* stream);
+/* y_bf16: the pooled output sept_bn_relu_pool_forward produced for the same x (dropout applied), or NULL.
+ * With it the channel sums (sum dy, sum dy*xhat) are taken from the pooled tensors alone -- xhat at a
+ * window's maximum is (y / dropscale - beta) / gamma -- instead of from every window of x. */
+int sept_bn_relu_pool_backward(const void* dy_bf16, const void* x_bf16, const void* y_bf16, const float* mean,
+                               const float* invstd, const float* gamma, const float* beta, const float* dropscale,
+                               float* ws, void* dx_bf16, float* dgamma, float* dbeta, int B, int H, int W, int C,
+                               int pool, void* stream);
 
 /* Sync-BN pieces (statistics over the GLOBAL batch of a data-parallel step; off by default).  The two
  * fused entries above split where the per-channel sums exist so the caller can all-reduce them:
@@ -150,8 +153,8 @@ int sept_bn_partial_sums(const void* x, long n_rows, int C, float* ws, double* s
 int sept_bn_stats_from_sums(const double* sums, double n_total, int C, float* mean, float* invstd,
                             float* running_mean, float* running_var, long long* num_batches_tracked,
                             float momentum, float eps, void* stream);
-int sept_bn_relu_pool_backward_reduce(const void* dy, const void* x, const float* mean, const float* invstd,
-                                      const float* gamma, const float* beta, const float* dropscale,
+int sept_bn_relu_pool_backward_reduce(const void* dy, const void* x, const void* y, const float* mean,
+                                      const float* invstd, const float* gamma, const float* beta, const float* dropscale,
                                       float* ws, float* sums, float* dgamma, float* dbeta, int B, int H,
                                       int W, int C, int pool, void* stream);
 int sept_bn_relu_pool_backward_apply(const void* dy, const void* x, const float* mean, const float* invstd,

@@ -196,6 +196,7 @@ __global__ __launch_bounds__(256) void sept_bn_relu_pool_fwd_kernel(BnFwdArgs a)
 struct BnBwdArgs {
   const bf16* dy;  // [B][Ho][Wo][C]
   const bf16* x;   // pre-BN conv output [B][H][W][C]
+  const bf16* y;   // pooled output of the forward pass [B][Ho][Wo][C] (dropout applied), or null
   const float *mean, *invstd, *gamma, *beta, *drop;
   float* ws;        // transposed partials [2C][blocks] (blocks <= kParts), then sums at ws + kParts*2C
   bf16* dx;         // [B][H][W][C]
@@ -262,6 +263,60 @@ __global__ __launch_bounds__(256) void sept_bn_bwd_reduce_kernel(BnBwdArgs a) {
     bn_bwd_window<CPP, P>(a, i / CPP, chunk, mu, is, sc, sh, g, xh, arg, xv);
     s1 += g;
     s2 += g * xh;
+  }
+  block_reduce_2c<CPP>(s1, s2, a.ws, gridDim.x, lds);
+}
+
+// The same two sums from the POOLED tensors alone.  The gradient lands on the window's maximum, and
+// there gamma * xhat + beta equals the pooled output (before dropout) whenever that is positive, so
+// xhat = (y / dropscale - beta) / gamma: the pass reads y and dy (1/P^2 of the pre-activation tensor)
+// instead of every window.  y is bf16, which perturbs xhat by 2^-9 |y / gamma| with random sign --
+// below the bf16 rounding the pre-activations carry anyway.  Channel chunks with a tiny |gamma| take
+// the window path (the quotient would amplify the rounding).
+template <int CPP, int P>
+__global__ __launch_bounds__(256) void sept_bn_bwd_reduce_pooled_kernel(BnBwdArgs a) {
+  constexpr int C = CPP * 8;
+  __shared__ float lds[256 * 16];
+  const long n_items = long(a.B) * (a.H / P) * (a.W / P) * CPP;
+  const long per_b = long(a.H / P) * (a.W / P);
+  const int chunk = threadIdx.x % CPP;
+  const f32x8 mu = loadf8(a.mean + chunk * 8), is = loadf8(a.invstd + chunk * 8);
+  const f32x8 ga = loadf8(a.gamma + chunk * 8), be = loadf8(a.beta + chunk * 8);
+  const f32x8 sc = ga * is, sh = be - mu * ga * is;
+  bool small = false;
+  f32x8 rg;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    small |= !(fabsf(ga[e]) >= 1e-3f);
+    rg[e] = 1.f / ga[e];
+  }
+  f32x8 s1 = {0, 0, 0, 0, 0, 0, 0, 0}, s2 = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (small) {
+    for (long i = long(blockIdx.x) * 256 + threadIdx.x; i < n_items; i += long(gridDim.x) * 256) {
+      f32x8 g, xh, xv[P * P];
+      int arg[8];
+      bn_bwd_window<CPP, P>(a, i / CPP, chunk, mu, is, sc, sh, g, xh, arg, xv);
+      s1 += g;
+      s2 += g * xh;
+    }
+  } else {
+    for (long i = long(blockIdx.x) * 256 + threadIdx.x; i < n_items; i += long(gridDim.x) * 256) {
+      const long px = i / CPP;
+      f32x8 g = load8(a.dy + px * C + chunk * 8);
+      f32x8 y = load8(a.y + px * C + chunk * 8);
+      if (a.drop) {
+        const f32x8 d = loadf8(a.drop + (px / per_b) * C + chunk * 8);
+        g *= d;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = d[e] > 0.f ? y[e] / d[e] : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float ge = y[e] > 0.f ? g[e] : 0.f;   // ReLU inactive (or channel dropped): no gradient
+        s1[e] += ge;
+        s2[e] += ge * (y[e] - be[e]) * rg[e];
+      }
+    }
   }
   block_reduce_2c<CPP>(s1, s2, a.ws, gridDim.x, lds);
 }
@@ -403,7 +458,11 @@ int bn_bwd_launch_reduce(BnBwdArgs& a, float* dgamma, float* dbeta, float* sums_
   const int C = a.C, pool = a.pool;
   const long items = long(a.B) * (a.H / pool) * (a.W / pool) * (C / 8);
   const int grid = grid_for(items);
-  if (pool == 2) {
+  if (a.y && pool == 2) {
+    SEPT_CPP_DISPATCH(C, hipLaunchKernelGGL((sept_bn_bwd_reduce_pooled_kernel<CPP, 2>), dim3(grid), dim3(256), 0, st, a));
+  } else if (a.y) {
+    SEPT_CPP_DISPATCH(C, hipLaunchKernelGGL((sept_bn_bwd_reduce_pooled_kernel<CPP, 1>), dim3(grid), dim3(256), 0, st, a));
+  } else if (pool == 2) {
     SEPT_CPP_DISPATCH(C, hipLaunchKernelGGL((sept_bn_bwd_reduce_kernel<CPP, 2>), dim3(grid), dim3(256), 0, st, a));
   } else {
     SEPT_CPP_DISPATCH(C, hipLaunchKernelGGL((sept_bn_bwd_reduce_kernel<CPP, 1>), dim3(grid), dim3(256), 0, st, a));
@@ -424,7 +483,8 @@ int bn_bwd_launch_apply(BnBwdArgs& a, hipStream_t st) {
 }
 }  // namespace
 
-extern "C" int sept_bn_relu_pool_backward(const void* dy, const void* x, const float* mean, const float* invstd,
+extern "C" int sept_bn_relu_pool_backward(const void* dy, const void* x, const void* y, const float* mean,
+                                          const float* invstd,
                                           const float* gamma, const float* beta, const float* dropscale,
                                           float* ws, void* dx, float* dgamma, float* dbeta, int B, int H, int W,
                                           int C, int pool, void* stream) {
@@ -434,8 +494,8 @@ extern "C" int sept_bn_relu_pool_backward(const void* dy, const void* x, const f
   SEPT_REQUIRE(dy && x && mean && invstd && gamma && beta && ws && dx, SEPT_ERR_INVALID,
                "sept_bn_relu_pool_backward: null argument");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  BnBwdArgs a{static_cast<const bf16*>(dy), static_cast<const bf16*>(x), mean, invstd, gamma, beta, dropscale,
-              ws, static_cast<bf16*>(dx), B, H, W, C, pool, ws + size_t(kParts) * 2 * C,
+  BnBwdArgs a{static_cast<const bf16*>(dy), static_cast<const bf16*>(x), static_cast<const bf16*>(y), mean, invstd,
+              gamma, beta, dropscale, ws, static_cast<bf16*>(dx), B, H, W, C, pool, ws + size_t(kParts) * 2 * C,
               1.0f / (float(B) * H * W)};
   if (int e = bn_bwd_launch_reduce(a, dgamma, dbeta, nullptr, st)) return e;
   if (int e = bn_bwd_launch_apply(a, st)) return e;
@@ -464,7 +524,8 @@ extern "C" int sept_bn_stats_from_sums(const double* sums, double n_total, int C
   return sept::launch_check("sept_bn_stats_from_sums");
 }
 
-extern "C" int sept_bn_relu_pool_backward_reduce(const void* dy, const void* x, const float* mean, const float* invstd,
+extern "C" int sept_bn_relu_pool_backward_reduce(const void* dy, const void* x, const void* y, const float* mean,
+                                                 const float* invstd,
                                                  const float* gamma, const float* beta, const float* dropscale,
                                                  float* ws, float* sums, float* dgamma, float* dbeta, int B, int H,
                                                  int W, int C, int pool, void* stream) {
@@ -472,8 +533,8 @@ extern "C" int sept_bn_relu_pool_backward_reduce(const void* dy, const void* x, 
                "sept_bn_relu_pool_backward_reduce: B=%d H=%d W=%d pool=%d", B, H, W, pool);
   SEPT_REQUIRE(dy && x && mean && invstd && gamma && beta && ws && sums, SEPT_ERR_INVALID,
                "sept_bn_relu_pool_backward_reduce: null argument");
-  BnBwdArgs a{static_cast<const bf16*>(dy), static_cast<const bf16*>(x), mean, invstd, gamma, beta, dropscale,
-              ws, nullptr, B, H, W, C, pool, nullptr, 0.f};
+  BnBwdArgs a{static_cast<const bf16*>(dy), static_cast<const bf16*>(x), static_cast<const bf16*>(y), mean, invstd,
+              gamma, beta, dropscale, ws, nullptr, B, H, W, C, pool, nullptr, 0.f};
   if (int e = bn_bwd_launch_reduce(a, dgamma, dbeta, sums, static_cast<hipStream_t>(stream))) return e;
   return sept::launch_check("sept_bn_relu_pool_backward_reduce");
 }
@@ -486,7 +547,7 @@ extern "C" int sept_bn_relu_pool_backward_apply(const void* dy, const void* x, c
                "sept_bn_relu_pool_backward_apply: B=%d H=%d W=%d pool=%d", B, H, W, pool);
   SEPT_REQUIRE(dy && x && mean && invstd && gamma && beta && sums && dx, SEPT_ERR_INVALID,
                "sept_bn_relu_pool_backward_apply: null argument");
-  BnBwdArgs a{static_cast<const bf16*>(dy), static_cast<const bf16*>(x), mean, invstd, gamma, beta, dropscale,
+  BnBwdArgs a{static_cast<const bf16*>(dy), static_cast<const bf16*>(x), nullptr, mean, invstd, gamma, beta, dropscale,
               nullptr, static_cast<bf16*>(dx), B, H, W, C, pool, sums, float(1.0 / n_total)};
   if (int e = bn_bwd_launch_apply(a, static_cast<hipStream_t>(stream))) return e;
   return sept::launch_check("sept_bn_relu_pool_backward_apply");

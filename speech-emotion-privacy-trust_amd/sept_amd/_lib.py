@@ -50,7 +50,7 @@ SIGNATURES = {
                               c_float, c_float, c_void_p]),
     "sept_bn_eval_stats": (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "sept_bn_relu_pool_forward": (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p]),
-    "sept_bn_relu_pool_backward": (c_int, [c_void_p] * 11 + [c_int] * 5 + [c_void_p]),
+    "sept_bn_relu_pool_backward": (c_int, [c_void_p] * 12 + [c_int] * 5 + [c_void_p]),
     "sept_gemm_nt_split": (c_int, [c_void_p, c_long, c_int, c_void_p, c_long, c_void_p, c_long, c_int, c_void_p,
                                    c_int, c_int, c_int, c_void_p]),
     "sept_gemm_tn_workspace_floats": (c_size_t, [c_int, c_int]),
@@ -99,7 +99,7 @@ SIGNATURES = {
     "sept_bn_partial_sums": (c_int, [c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p]),
     "sept_bn_stats_from_sums": (c_int, [c_void_p, c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_float, c_float, c_void_p]),
-    "sept_bn_relu_pool_backward_reduce": (c_int, [c_void_p] * 11 + [c_int] * 5 + [c_void_p]),
+    "sept_bn_relu_pool_backward_reduce": (c_int, [c_void_p] * 12 + [c_int] * 5 + [c_void_p]),
     "sept_bn_relu_pool_backward_apply": (c_int, [c_void_p] * 8 + [c_double, c_void_p] + [c_int] * 5 + [c_void_p]),
     "sept_conv1_stats_parts": (c_int, [c_int, c_int]),
     "sept_conv1_forward_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,

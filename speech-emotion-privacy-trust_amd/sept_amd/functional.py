@@ -200,7 +200,7 @@ def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None, gfeat=Non
             d2 = inj.get("drop2d")
             drop = d2[li] if d2 is not None else masks[("c", li)]
         out = ops.bn_relu_pool_forward(pre, mean, invstd, bn.weight, bn.bias, drop, pool)
-        S.blocks.append(SimpleNamespace(inp=act, pre=pre, mean=mean, invstd=invstd, drop=drop, pool=pool, h=h, w=w,
+        S.blocks.append(SimpleNamespace(inp=act, pre=pre, out=out, mean=mean, invstd=invstd, drop=drop, pool=pool, h=h, w=w,
                                         bn_train=bn.training, sync=_SYNC_BN["on"] and bn.training))
         act = out
         h, w = h // pool, w // pool
@@ -365,6 +365,8 @@ def trunk_backward(S, P, dlogits, need_wgrad=True, need_dx=True):
 # hipStreamEndCapture on ROCm 7.2 (fork -> fork is fine, the nested JOIN is not), and the two branches
 # already fill the device.
 WGRAD_STREAM = os.environ.get("SEPT_WGRAD_STREAM", "1") != "0"
+# BatchNorm backward: channel sums from the pooled tensors (SEPT_BN_POOLED=0: from every window of the pre-activations)
+BN_POOLED_SUMS = os.environ.get("SEPT_BN_POOLED", "1") != "0"
 NO_WGRAD_FORK = set()
 _WG_STREAMS = {}
 
@@ -443,7 +445,8 @@ def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx):
         want_bn = need_wgrad and bn.weight.requires_grad
         dpre, dgamma, dbeta = ops.bn_relu_pool_backward(dact, blk.pre, blk.mean, blk.invstd, bn.weight, bn.bias,
                                                         blk.drop, blk.pool, need_param_grads=want_bn,
-                                                        sync_group=_SYNC_BN["group"], sync=blk.sync)
+                                                        sync_group=_SYNC_BN["group"], sync=blk.sync,
+                                                        y=blk.out if BN_POOLED_SUMS else None)
         if want_bn:
             put(bn.weight, dgamma)
             put(bn.bias, dbeta)

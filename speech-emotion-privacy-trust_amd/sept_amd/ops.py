@@ -2,7 +2,7 @@
 Activations are NHWC bf16 on the device; every function raises on CPU tensors."""
 import torch
 
-from ._lib import lib, check, current_stream_ptr, require_cuda
+from ._lib import SeptError, lib, check, current_stream_ptr, require_cuda
 
 
 def _s(t):
@@ -191,18 +191,22 @@ def bn_relu_pool_forward(x, mean, invstd, gamma, beta, dropscale=None, pool=2):
 
 
 def bn_relu_pool_backward(dy, x, mean, invstd, gamma, beta, dropscale=None, pool=2, need_param_grads=True,
-                          sync_group=None, sync=False):
-    """With sync=True the (sum dy, sum dy*xhat) pair is all-reduced between the reduce and the apply pass
+                          sync_group=None, sync=False, y=None):
+    """y: the pooled output bn_relu_pool_forward returned for the same x (then the channel sums are taken
+    from the pooled tensors alone; see include/sept.h).  With sync=True the (sum dy, sum dy*xhat) pair is all-reduced between the reduce and the apply pass
     (sync-BN); dgamma / dbeta stay the local sums -- the data-parallel gradient average finishes them."""
     require_cuda(dy, x)
     B, H, W, C = x.shape
+    if y is not None and (y.dtype != torch.bfloat16 or tuple(y.shape) != (B, H // pool, W // pool, C)
+                          or not y.is_contiguous()):
+        raise SeptError(f"bn_relu_pool_backward: y must be the contiguous bf16 pooled output, got {tuple(y.shape)} {y.dtype}")
     ws = workspace("bn", lib.sept_bn_workspace_floats(C), x.device)
     dx = torch.empty_like(x)
     dgamma = torch.empty(C, dtype=torch.float32, device=x.device) if need_param_grads else None
     dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if need_param_grads else None
     if sync:
         sums = torch.empty(2 * C, dtype=torch.float32, device=x.device)
-        check(lib.sept_bn_relu_pool_backward_reduce(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+        check(lib.sept_bn_relu_pool_backward_reduce(dy.data_ptr(), x.data_ptr(), _p(y), mean.data_ptr(), invstd.data_ptr(),
                                                     gamma.data_ptr(), beta.data_ptr(), _p(dropscale), ws.data_ptr(),
                                                     sums.data_ptr(), _p(dgamma), _p(dbeta), B, H, W, C, pool, _s(x)),
               "sept_bn_relu_pool_backward_reduce")
@@ -212,7 +216,7 @@ def bn_relu_pool_backward(dy, x, mean, invstd, gamma, beta, dropscale=None, pool
                                                    float(B) * H * W * world, dx.data_ptr(), B, H, W, C, pool, _s(x)),
               "sept_bn_relu_pool_backward_apply")
         return dx, dgamma, dbeta
-    check(lib.sept_bn_relu_pool_backward(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+    check(lib.sept_bn_relu_pool_backward(dy.data_ptr(), x.data_ptr(), _p(y), mean.data_ptr(), invstd.data_ptr(),
                                          gamma.data_ptr(), beta.data_ptr(), _p(dropscale), ws.data_ptr(),
                                          dx.data_ptr(), _p(dgamma), _p(dbeta), B, H, W, C, pool, _s(x)),
           "sept_bn_relu_pool_backward")

@@ -48,11 +48,16 @@ def test_conv1_forward_backward(B, H, W):
 @pytest.mark.parametrize("B,H,W,C,pool", [(4, 200, 80, 32, 2), (3, 100, 40, 64, 2), (3, 50, 20, 128, 2),
                                           (2, 25, 10, 128, 1), (2, 51, 21, 64, 2)])
 @pytest.mark.parametrize("drop", [False, True])
-def test_bn_relu_pool_forward_backward(B, H, W, C, pool, drop):
+@pytest.mark.parametrize("pooled", [False, True])
+def test_bn_relu_pool_forward_backward(B, H, W, C, pool, drop, pooled):
+    """pooled: the backward takes its channel sums from the pooled output y (the training path) instead of
+    from every window of x; channels with a tiny |gamma| must fall back to the windows."""
     from sept_amd import ops
     g = torch.Generator().manual_seed(C + H)
     x = (torch.randn(B, H, W, C, generator=g) * 1.5 + 0.3).bfloat16().cuda()
-    gamma = (1 + 0.2 * torch.randn(C, generator=g)).cuda()
+    gamma = (1 + 0.2 * torch.randn(C, generator=g))
+    gamma[3], gamma[C - 5] = 1e-5, -2e-4
+    gamma = gamma.cuda()
     beta = (0.2 * torch.randn(C, generator=g)).cuda()
     rm, rv = torch.zeros(C).cuda(), torch.ones(C).cuda()
     nbt = torch.zeros((), dtype=torch.int64).cuda()
@@ -60,7 +65,8 @@ def test_bn_relu_pool_forward_backward(B, H, W, C, pool, drop):
     if drop:
         ds = ((torch.rand(B, C, generator=g) > 0.2).float() / 0.8).cuda()
     mean, invstd = ops.bn_stats(x, rm, rv, nbt)
-    y = ops.bn_relu_pool_forward(x, mean, invstd, gamma, beta, ds, pool).float()
+    y16 = ops.bn_relu_pool_forward(x, mean, invstd, gamma, beta, ds, pool)
+    y = y16.float()
 
     # reference on the CPU in fp32 (torch-ROCm's GPU batch_norm backward returns a dbeta that
     # disagrees with the sum of its own incoming gradient for odd widths -- observed on this
@@ -78,12 +84,17 @@ def test_bn_relu_pool_forward_backward(B, H, W, C, pool, drop):
     assert torch.allclose(rm.cpu(), rm2, atol=1e-6) and torch.allclose(rv.cpu(), rv2, rtol=1e-5) and int(nbt) == 1
     assert torch.allclose(y.cpu(), want.detach(), rtol=1e-2, atol=1e-2)
     dy = torch.randn(want.shape, generator=g).bfloat16().cuda()
-    dx, dgamma, dbeta = ops.bn_relu_pool_backward(dy, x, mean, invstd, gamma, beta, ds, pool)
+    dx, dgamma, dbeta = ops.bn_relu_pool_backward(dy, x, mean, invstd, gamma, beta, ds, pool,
+                                                  y=y16 if pooled else None)
     t.backward(nchw(dy.float().cpu()))
     wdx = nhwc(xr.grad)
     # dx is rounded to bf16 once: per-element bound of one bf16 ulp + a small absolute term
     assert ((dx.float().cpu() - wdx).abs() <= wdx.abs() * 2 ** -7 + 1e-3 * wdx.abs().max()).all()
-    assert torch.allclose(dgamma.cpu(), gr.grad, rtol=1e-3, atol=1e-3 * gr.grad.abs().max())
+    # pooled sums: xhat at the maximum is recovered from the bf16 pooled output (one more bf16 rounding,
+    # 2^-9 relative, random sign), so dgamma carries a few 1e-3 of noise -- the same size as the rounding
+    # the bf16 pre-activations already have against an fp32 network; dbeta does not depend on xhat
+    tol = 5e-3 if pooled else 1e-3
+    assert torch.allclose(dgamma.cpu(), gr.grad, rtol=tol, atol=tol * gr.grad.abs().max())
     assert torch.allclose(dbeta.cpu(), br.grad, rtol=1e-3, atol=1e-3 * br.grad.abs().max())
 
 
@@ -125,7 +136,7 @@ def test_sync_bn_split_entries_equal_global_batch():
     for h in halves:
         xs, dys, dr = x[h].contiguous(), dy[h].contiguous(), drop[h].contiguous()
         sums, dg, db = torch.empty(2 * C, device="cuda"), torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
-        check(lib.sept_bn_relu_pool_backward_reduce(dys.data_ptr(), xs.data_ptr(), mean_f.data_ptr(), invstd_f.data_ptr(),
+        check(lib.sept_bn_relu_pool_backward_reduce(dys.data_ptr(), xs.data_ptr(), None, mean_f.data_ptr(), invstd_f.data_ptr(),
                                                     gamma.data_ptr(), beta.data_ptr(), dr.data_ptr(), ws.data_ptr(),
                                                     sums.data_ptr(), dg.data_ptr(), db.data_ptr(), 2, H, W, C, pool, s), "red")
         parts.append((xs, dys, dr, dg, db))
