@@ -344,13 +344,15 @@ def main():
     from model import cloak_models as _cm
     iso_ms = None
     if _cm.CONCURRENT_BRANCHES:
+        from sept_amd import functional as _sf
         _cm.CONCURRENT_BRANCHES = False
+        wg_side, _sf.WGRAD_STREAM = _sf.WGRAD_STREAM, False   # no weight-gradient side stream either: one queue
         ops.TIMER = ops.KernelTimer(tags={dominant})
         for _ in range(2):
             trainer.train_step(pipe.features(wav).view(Bw, 1, WIN, F), le, lg, weights)
         torch.cuda.synchronize()
         iso_ms = ops.TIMER.summary()[dominant][1]
-        _cm.CONCURRENT_BRANCHES = True
+        _cm.CONCURRENT_BRANCHES, _sf.WGRAD_STREAM = True, wg_side
     ops.TIMER = None
 
     # kernel-only mel figure (config 2: batch 256, F mels) for the north-star HBM target
