@@ -178,10 +178,20 @@ class one_d_cnn_lstm(nn.Module):
         return None
 
     def forward(self, input_var, global_feature=None):
+        # The reference's own forward (baseline_models.py:100-140) cannot run these two options: the RNN is
+        # commented out, so att_linear1 (2*lstm_hidden inputs) meets 512 channels, the attention output is
+        # 512 wide where the classifier takes 512*4, and a concatenated global feature widens z past the
+        # classifier's 2048 inputs -- torch raises a shape error there.  Same here, before any launch.
         if global_feature is not None:
-            raise NotImplementedError("global_feature concat (openSMILE functionals) is outside the HIP path")
-        if self.att is not None or self.pred == 'multitask':
-            raise NotImplementedError("att / multitask heads are outside the HIP path")
+            raise RuntimeError("one_d_cnn_lstm: z (B, 2048) + global_feature does not fit classifier Linear(2048, 128) "
+                               "(the reference raises the same shape error, baseline_models.py:124-127)")
+        if self.att is not None:
+            raise RuntimeError("one_d_cnn_lstm: att='self_att' cannot run in the reference either (att_linear1 / "
+                               "classifier shapes, baseline_models.py:113-127)")
         x = input_var.squeeze(dim=1).float()      # (B, T, F): time-major, mel bins are the Conv1d channels
+        if self.pred == 'multitask':              # (emotion, gender) tuple, :129-132
+            both = SF.run_one_d(self, x, [self.pred_emotion_layer, self.pred_gender_layer])
+            n = self.pred_emotion_layer.weight.shape[0]
+            return both[:, :n], both[:, n:]
         head = self.pred_emotion_layer if self.pred == 'emotion' else self.pred_gender_layer
         return SF.run_one_d(self, x, head)

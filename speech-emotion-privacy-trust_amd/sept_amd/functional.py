@@ -647,7 +647,16 @@ def one_d_forward(x, model, head, need_grad=True, injected=None):
         m = inj.get("dense")
         dmask = m if m is not None else _drop_mask(tuple(d1.shape), x.device, pdrop)
     d1a = ops.relu_dropout_forward(d1, dmask)
-    logits = ops.linear_forward(d1a, head.weight, head.bias)
+    heads = list(head) if isinstance(head, (list, tuple)) else [head]   # pred='multitask': both, side by side
+    if len(heads) == 1:
+        logits = ops.linear_forward(d1a, head.weight, head.bias)
+    else:
+        logits = torch.empty((B, sum(h.weight.shape[0] for h in heads)), dtype=torch.float32, device=x.device)
+        c0 = 0
+        for h_ in heads:
+            n = h_.weight.shape[0]
+            ops.linear_forward(d1a, h_.weight, h_.bias, out=logits[:, c0:c0 + n])
+            c0 += n
     S.z, S.d1, S.dmask, S.d1a = z, d1, dmask, d1a
     return logits, (S if need_grad else None)
 
@@ -658,9 +667,19 @@ def one_d_backward(S, model, head, dlogits, need_dx=False):
     convs = [m for m in model.conv if isinstance(m, torch.nn.Conv1d)]
     lin = model.classifier[0]
     dlogits = dlogits.contiguous()
-    d = ops.linear_backward_input(dlogits, head.weight)
-    grads[head.weight] = ops.linear_backward_weight(dlogits, S.d1a)
-    grads[head.bias] = ops.colsum(dlogits)
+    heads = list(head) if isinstance(head, (list, tuple)) else [head]
+    d, c0 = None, 0
+    for h_ in heads:
+        n = h_.weight.shape[0]
+        dl = dlogits[:, c0:c0 + n]
+        c0 += n
+        if d is None:
+            d = ops.linear_backward_input(dl, h_.weight)
+        else:   # second head of pred='multitask': accumulate
+            ops.gemm_raw(dl, dl.stride(0), 1, h_.weight, h_.weight.shape[1], 1, d, d.stride(0), B,
+                         h_.weight.shape[1], n, beta=1.0)
+        grads[h_.weight] = ops.linear_backward_weight(dl, S.d1a)
+        grads[h_.bias] = ops.colsum(dl)
     d = ops.relu_dropout_backward(d, S.d1, S.dmask)
     grads[lin.weight] = ops.linear_backward_weight(d, S.z)
     grads[lin.bias] = ops.colsum(d)
@@ -696,5 +715,7 @@ class OneDFn(torch.autograd.Function):
 
 def run_one_d(model, x, head, injected=None):
     params = [p for m in model.conv if isinstance(m, torch.nn.Conv1d) for p in (m.weight, m.bias)]
-    params += [model.classifier[0].weight, model.classifier[0].bias, head.weight, head.bias]
+    params += [model.classifier[0].weight, model.classifier[0].bias]
+    for h_ in (head if isinstance(head, (list, tuple)) else [head]):
+        params += [h_.weight, h_.bias]
     return OneDFn.apply(x, model, head, injected, *params)

@@ -344,6 +344,46 @@ def test_graph_replay_equals_eager_step():
     assert torch.equal(results[0][1], results[1][1])          # deterministic kernels: bit-identical
 
 
+def test_one_d_cnn_multitask_and_unrunnable_options():
+    """one_d_cnn_lstm pred='multitask' (baseline_models.py:129-132): an (emotion, gender) pair from the shared
+    classifier; both heads' losses flow back.  att='self_att' and a global feature cannot run in the reference
+    (shape errors at :113-127); the drop-in raises before any launch."""
+    from model import baseline_models as bm
+    F = 80
+    x = closed_form_input(B, W, F)
+    kw = dict(lstm_hidden_size=64, num_layers_lstm=2, pred="multitask", attention_size=128, att=None, global_feature=0)
+    m = bm.one_d_cnn_lstm(1, F, 64, **kw)
+    sd = closed_form_state(m, prefix="one_d.")
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    ref = mo.one_d_cnn_lstm(1, F, 64, **kw)
+    ref.load_state_dict(sd)
+    ref.train()
+    zero_dropout(m), zero_dropout(ref)
+    le, lg, wts = closed_form_labels(B)
+    ce = torch.nn.functional.cross_entropy
+    e, g_ = m(x.cuda())
+    assert e.shape == (B, 4) and g_.shape == (B, 2)
+    ((ce(e, le.view(-1).cuda(), reduction="none") + 0.5 * ce(g_, lg.view(-1).cuda(), reduction="none")) * wts.cuda()).mean().backward()
+    re, rg = ref(x)
+    ((ce(re, le.view(-1), reduction="none") + 0.5 * ce(rg, lg.view(-1), reduction="none")) * wts).mean().backward()
+    assert torch.allclose(e.detach().cpu(), re.detach(), rtol=1e-4, atol=1e-5)
+    assert torch.allclose(g_.detach().cpu(), rg.detach(), rtol=1e-4, atol=1e-5)
+    got = dict(m.named_parameters())
+    n_checked = 0
+    for name, p in ref.named_parameters():
+        if p.grad is None:
+            assert got[name].grad is None, name
+            continue
+        assert float((got[name].grad.cpu() - p.grad).norm() / p.grad.norm()) < 5e-4, name
+        n_checked += 1
+    assert n_checked == 12      # 3 convs, classifier, two heads: weight + bias each
+    with pytest.raises(RuntimeError):
+        bm.one_d_cnn_lstm(1, F, 64, **dict(kw, att="self_att")).cuda()(x.cuda())
+    with pytest.raises(RuntimeError):
+        m(x.cuda(), global_feature=torch.zeros(B, 88).cuda())
+
+
 @pytest.mark.parametrize("F", [80, 128])
 def test_one_d_cnn_vs_reference_and_oracle(F, G):
     """one_d_cnn_lstm (baseline_models.py:19-140): eval logits against the reference golden; one
