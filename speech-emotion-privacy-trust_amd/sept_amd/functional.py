@@ -300,21 +300,24 @@ def trunk_backward(S, P, dlogits, need_wgrad=True, need_dx=True):
             grads[param] = g
 
     dlogits = dlogits.contiguous()
+    sq = _SideQueue(dlogits.device, need_wgrad)
     Hh = S.Hh
     H2, G = 2 * Hh, (4 if S.lstm else 3) * Hh
     if S.fused_head:
         d_d1, dout = ops.head_backward(dlogits, S.wh, S.d1, S.dmask, P.dense1.weight, T)
         if need_wgrad:
-            c0 = 0
-            for h in P.heads:
-                n = h.weight.shape[0]
-                dl = dlogits[:, c0:c0 + n]
-                c0 += n
-                put(h.weight, ops.linear_backward_weight(dl, S.d1a))
-                put(h.bias, ops.colsum(dl))
-            put(P.dense1.weight, ops.linear_backward_weight(d_d1, S.z))
-            put(P.dense1.bias, ops.colsum(d_d1))
-        return _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx)
+            def head_wgrads():
+                c0 = 0
+                for h in P.heads:
+                    n = h.weight.shape[0]
+                    dl = dlogits[:, c0:c0 + n]
+                    c0 += n
+                    put(h.weight, ops.linear_backward_weight(dl, S.d1a))
+                    put(h.bias, ops.colsum(dl))
+                put(P.dense1.weight, ops.linear_backward_weight(d_d1, S.z))
+                put(P.dense1.bias, ops.colsum(d_d1))
+            sq.small(head_wgrads, dlogits, d_d1, S.d1a, S.z)
+        return _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq)
     d_d1a, c0 = None, 0
     for h in P.heads:
         n = h.weight.shape[0]
@@ -354,47 +357,88 @@ def trunk_backward(S, P, dlogits, need_wgrad=True, need_dx=True):
         ops.gemm_raw(d_a1, d_a1.stride(0), 1, w1, w1.shape[1], 1, dout, H2, B * T, H2, w1.shape[0], beta=1.0)
     else:
         dout = ops.mean_t_backward(dz, T) if S.pooling == "mean" else dz.view(B, T, H2)
-    return _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx)
+    return _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq)
 
 
 # Weight gradients are off the critical path of the backward pass (nothing downstream reads them until
-# the optimiser), so on a top-level stream they are enqueued on a side stream while the data-gradient
-# chain continues; the two join at the end of the network's backward (SEPT_WGRAD_STREAM=0 keeps one
-# stream).  Streams registered in NO_WGRAD_FORK (the two GRL branch streams, themselves forked) keep
-# everything in line: a forked stream joining another forked stream inside a HIP-graph capture crashes
-# hipStreamEndCapture on ROCm 7.2 (fork -> fork is fine, the nested JOIN is not), and the two branches
-# already fill the device.
+# the optimiser), so they can be enqueued on a side stream while the data-gradient chain continues
+# (SEPT_WGRAD_STREAM=0 keeps one stream).  Which ones go there, and where the side stream joins, depends
+# on the stream the network runs on:
+#   * a top-level stream (the baseline trainer's single model): all of them; the join is the last thing
+#     the network's backward does, so autograd and any caller see finished gradients -- safe for a plain
+#     `loss.backward()` of the drop-in modules;
+#   * one of the two GRL branch streams (registered in NO_WGRAD_FORK; themselves forked from the caller's
+#     stream): a forked stream joining another forked stream inside a HIP-graph capture crashes
+#     hipStreamEndCapture on ROCm 7.2 (fork -> fork is fine, the nested JOIN is not), so the side stream is
+#     only used under `backward(loss)` below -- the trainers' entry -- which joins it into the caller's
+#     stream right after autograd returns and before anything reads a gradient; a bare `loss.backward()`
+#     keeps everything in line.  And only the SMALL products go there (head / dense / recurrent weight and
+#     bias gradients: ~25 latency-bound launches that otherwise sit in the branch's critical chain); the conv
+#     weight gradients stay in line -- as a third queue of MFMA work they made the step slower (2.74 -> 3.00 ms).
 WGRAD_STREAM = os.environ.get("SEPT_WGRAD_STREAM", "1") != "0"
 # BatchNorm backward: channel sums from the pooled tensors (SEPT_BN_POOLED=0: from every window of the pre-activations)
 BN_POOLED_SUMS = os.environ.get("SEPT_BN_POOLED", "1") != "0"
 NO_WGRAD_FORK = set()
 _WG_STREAMS = {}
+_DEFERRED = {"on": False, "pending": []}
 
 
-def _wgrad_stream(device):
-    cur = torch.cuda.current_stream(device).cuda_stream
-    if cur in NO_WGRAD_FORK:
-        return None
-    key = (device.index, cur)
-    if key not in _WG_STREAMS:
-        _WG_STREAMS[key] = torch.cuda.Stream(device=device)
-    return _WG_STREAMS[key]
+def backward(loss):
+    """loss.backward() for the trainers: branch networks may leave small weight gradients on side streams;
+    they are joined into the current stream here, before the caller touches any .grad."""
+    _DEFERRED["on"] = WGRAD_STREAM
+    try:
+        loss.backward()
+    finally:
+        _DEFERRED["on"] = False
+        cur = torch.cuda.current_stream()
+        for wg, _keep in _DEFERRED["pending"]:
+            cur.wait_stream(wg)
+        _DEFERRED["pending"].clear()
 
 
-def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx):
+class _SideQueue:
+    """The weight-gradient side stream of ONE network's backward pass (see the comment above)."""
+
+    def __init__(self, device, enabled):
+        self.dev, self.wg, self.nested, self.keep = device, None, False, []
+        if not (enabled and WGRAD_STREAM and device.type == "cuda"):
+            return
+        cur = torch.cuda.current_stream(device).cuda_stream
+        self.nested = cur in NO_WGRAD_FORK
+        if self.nested and not _DEFERRED["on"]:
+            return
+        key = (device.index, cur)
+        if key not in _WG_STREAMS:
+            _WG_STREAMS[key] = torch.cuda.Stream(device=device)
+        self.wg = _WG_STREAMS[key]
+
+    def _run(self, fn, operands):
+        self.wg.wait_stream(torch.cuda.current_stream(self.dev))   # after everything enqueued so far
+        self.keep.extend(operands)                                  # operands stay referenced until the join
+        with torch.cuda.stream(self.wg):
+            return fn()
+
+    def small(self, fn, *operands):
+        """latency-bound weight-gradient launches: on the side stream whenever there is one"""
+        return fn() if self.wg is None else self._run(fn, operands)
+
+    def big(self, fn, *operands):
+        """MFMA-heavy weight gradients: on the side stream of a top-level network only"""
+        return fn() if (self.wg is None or self.nested) else self._run(fn, operands)
+
+    def finish(self):
+        if self.wg is None:
+            return
+        if self.nested:   # functional.backward() joins
+            _DEFERRED["pending"].append((self.wg, self.keep))
+        else:             # the caller (autograd) sees every gradient on this network's stream
+            torch.cuda.current_stream(self.dev).wait_stream(self.wg)
+            self.keep.clear()
+
+
+def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq):
     """The recurrent layers and the conv stack of trunk_backward, from the gradient of the last recurrent output."""
-    dev = dout.device
-    wg = _wgrad_stream(dev) if (WGRAD_STREAM and need_wgrad and dout.is_cuda) else None
-    keep = []   # operands of side-stream kernels stay referenced until the join below
-
-    def side(fn, *operands):
-        """Run fn() -- weight-gradient launches only -- on the side stream, after everything enqueued so far."""
-        if wg is None:
-            return fn()
-        wg.wait_stream(torch.cuda.current_stream(dev))
-        keep.extend(operands)
-        with torch.cuda.stream(wg):
-            return fn()
     B, T = S.B, S.T
     Hh = S.Hh
     H2, G = 2 * Hh, (4 if S.lstm else 3) * Hh
@@ -425,7 +469,7 @@ def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx):
                         ops.linear_backward_weight(gh, hp2[:, d * Hh:(d + 1) * Hh]))
                     put(getattr(r, "bias_ih" + sfx + tag), dbih[d * G:(d + 1) * G])
                     put(getattr(r, "bias_hh" + sfx + tag), dbhh[d * G:(d + 1) * G])
-            side(rnn_wgrads, dgi2, dgh2, hp2, Gs.inp)
+            sq.small(rnn_wgrads, dgi2, dgh2, hp2, Gs.inp)
         # gradient wrt the layer input: dgi [W_if; W_ir]  (one product, reduction length 2G)
         odt = torch.float32 if layer == 1 else torch.bfloat16
         din = ops.linear_nt_split(dgi2, Gs.wcatT, None, out_dtype=odt)
@@ -452,22 +496,20 @@ def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx):
             put(bn.bias, dbeta)
         if li == 0:
             if need_wgrad and cv.weight.requires_grad:
-                dw, db = side(lambda dpre=dpre: ops.conv1_backward_weight(S.x, dpre), dpre, S.x)
+                dw, db = sq.big(lambda dpre=dpre: ops.conv1_backward_weight(S.x, dpre), dpre, S.x)
                 put(cv.weight, dw)
                 put(cv.bias, db)
             if need_dx:
                 dx = ops.conv1_backward_data(dpre, cv.weight)
         else:
             if need_wgrad and cv.weight.requires_grad:
-                put(cv.weight, side(lambda blk=blk, dpre=dpre: ops.conv5x5_backward_weight(blk.inp, dpre), dpre, blk.inp))
+                put(cv.weight, sq.big(lambda blk=blk, dpre=dpre: ops.conv5x5_backward_weight(blk.inp, dpre), dpre, blk.inp))
                 # the conv bias feeds straight into a training-mode BatchNorm, whose backward has
                 # zero channel sum by construction: d(bias) == 0 (the reference gets rounding noise)
                 put(cv.bias, torch.zeros_like(cv.bias))
             wtd = _cached("convdgrad", cv.weight, lambda: ops.conv5x5_prep_weights(cv.weight, 1))
             dact = ops.conv5x5(dpre, wtd)
-    if wg is not None:   # join: the caller (autograd) sees every gradient on this branch's stream
-        torch.cuda.current_stream(dev).wait_stream(wg)
-        keep.clear()
+    sq.finish()
     return dx, grads
 
 

@@ -137,7 +137,7 @@ class GrlTrainer:
         SF.set_sync_bn(self.sync_bn and self.world > 1, self.pg)
         preds, preds_grl, _ = self.model(features, global_feature=global_feature, mask=mask, grl=False, pooling=pooling)
         loss = self.loss(preds, preds_grl, labels_emo, labels_gen, weights, training=True)
-        loss.backward()
+        SF.backward(loss)
         self.flat.gather_grads()
         if self.world > 1:
             # the loss is a mean over the local shard (:150-151), so averaging equal shards gives
@@ -183,7 +183,7 @@ class BaselineTrainer:
         _advance_rng(features.device)
         preds = self.model(features)
         loss = SF.GrlStepLossFn.apply(preds, None, labels, None, weights, 0.0, 0.0, None, 0.0, 0.0)
-        loss.backward()
+        SF.backward(loss)
         self.flat.gather_grads()
         if self.world > 1:
             torch.distributed.all_reduce(self.flat.grad[:self.flat.n_active], group=self.pg)
@@ -205,7 +205,7 @@ class BaselineTrainer:
             _advance_rng(features.device)
             preds = self.model(features)
             loss = SF.GrlStepLossFn.apply(preds, None, labels, None, weights, 0.0, 0.0, None, 0.0, 0.0)
-            loss.backward()
+            SF.backward(loss)
             self.flat.gather_grads()
             out = (loss.detach(), preds.detach())
 
@@ -264,7 +264,7 @@ class FusedPipeline:
             preds, preds_grl, _ = tr.model(x.view(x.shape[0], 1, self.win, self.n_mels), mask=None, grl=False,
                                            pooling="mean")
             loss = tr.loss(preds, preds_grl, labels_emo_w, labels_gen_w, weights_w, training=True)
-            loss.backward()
+            SF.backward(loss)
             tr.flat.gather_grads()
             out = (loss.detach(), preds.detach(), preds_grl.detach())
 
