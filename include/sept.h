@@ -83,6 +83,14 @@ int sept_conv5x5_prep_weights(const float* w_oihw, int cout, int cin, int mode, 
  * Channel pairs: 32->64, 64->128 (forward), 64->32, 128->64 (data gradient), 128->128. */
 int sept_conv5x5_forward(const void* x_bf16, const void* wt_bf16, const float* bias, void* y_bf16,
                          int B, int H, int W, int cin, int cout, void* stream);
+/* Forward + the BatchNorm statistics partials of its output (training: the BatchNorm that follows needs no
+ * statistics pass): stats[2*cout][sept_conv5x5_stats_parts(B,H,W,cin,cout)] floats -- per-workgroup sums, then
+ * sums of squares, of the bf16-rounded outputs -- to be finished by sept_bn_stats_from_partials.
+ * sept_conv5x5_stats_parts returns 0 when the shape has no statistics form (cin > cout, unsupported pair, or
+ * the LDS copy of the output tile would cost a workgroup per CU). */
+int sept_conv5x5_stats_parts(int B, int H, int W, int cin, int cout);
+int sept_conv5x5_forward_stats(const void* x_bf16, const void* wt_bf16, const float* bias, void* y_bf16, float* stats,
+                               int B, int H, int W, int cin, int cout, void* stream);
 
 /* dW[cout][cin][5][5] (fp32, OIHW, overwritten) = sum over batch and pixels of dy x shifted x.
  * bf16 MFMA with transposing LDS reads; deterministic (per-workgroup slabs in `ws`, which

@@ -37,6 +37,7 @@ struct ConvArgs {
   const float* bias;  // [COUT] or null
   bf16* y;            // [B][H][W][COUT]
   int B, H, W, nr_max;
+  float* stats;       // STATS kernels: BatchNorm statistics partials [2*COUT][B * tiles] (sums, then sums of squares)
 };
 
 __host__ __device__ constexpr int conv_nr_max(int mt, int w) { return (mt + w - 2) / w + 5; }
@@ -52,8 +53,20 @@ __host__ __device__ constexpr int conv_nr_max(int mt, int w) { return (mt + w - 
 // CS > 1: the input channels are processed in CS slices, each with its own staged tile and weight
 // tiles (the accumulators run across slices): for wide inputs (128 channels) this halves the
 // LDS tile so that two workgroups fit on a CU.
-template <int CINF, int COUT, int PB, int WP, int WN, int TGP, int CS>
-__global__ __launch_bounds__(64 * WP * WN) void sept_conv5x5_mfma_kernel(ConvArgs a) {
+// STATS: the epilogue also leaves per-workgroup sums / sums of squares of the (bf16-rounded) outputs per
+// channel -- the statistics pass of the BatchNorm that follows, without reading the tensor back.  The output
+// tile goes through the LDS (free by then) and is summed by columns, which costs no registers: the 8-wave shapes
+// sit at the 128-VGPR limit that lets two workgroups share a CU.
+__host__ __device__ constexpr size_t conv_stats_smem(int mt, int cout, int nthr) {
+  return size_t(mt) * (cout * 2 + 8) + size_t(nthr / cout) * 2 * cout * sizeof(float);
+}
+
+// (Second launch bound = waves per SIMD: the statistics form of an 8-wave shape that lives with two workgroups
+// per CU is held to the 128 VGPRs its plain form uses; shapes whose plain form needs more carry no cap.)
+template <int CINF, int COUT, int PB, int WP, int WN, int TGP, int CS, bool STATS = false>
+__global__ __launch_bounds__(64 * WP * WN,
+                             (STATS && WP * WN == 8 && !(TGP == 0 && CINF >= 64 && (CS == 1 || CINF == 128))) ? 4 : 1)
+void sept_conv5x5_mfma_kernel(ConvArgs a) {
   constexpr bool DBUF = TGP == 0;
   constexpr int TG = DBUF ? 1 : TGP;
   constexpr int CIN = CINF / CS;  // channels per slice
@@ -204,23 +217,77 @@ __global__ __launch_bounds__(64 * WP * WN) void sept_conv5x5_mfma_kernel(ConvArg
 
   // ---- epilogue: + bias, round to bf16, 8-byte NHWC stores ----
   bf16* yb = a.y + size_t(b) * HW * COUT;
+  constexpr int SP = COUT * 2 + 8;   // STATS: bytes per pixel row of the LDS copy (padded: conflict-free 8-byte writes)
+  if constexpr (!STATS) {
 #pragma unroll
-  for (int pb = 0; pb < PB; ++pb) {
-    const int q = q0 + (wave * PB + pb) * 32 + (lane & 31);
-    if (q >= HW) continue;
+    for (int pb = 0; pb < PB; ++pb) {
+      const int q = q0 + (wave * PB + pb) * 32 + (lane & 31);
+      if (q >= HW) continue;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
+      for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int co = (nhalf * NB + nb) * 32 + 8 * g + 4 * (lane >> 5);
-        f32x4 v = {acc[pb][nb][4 * g + 0], acc[pb][nb][4 * g + 1], acc[pb][nb][4 * g + 2],
-                   acc[pb][nb][4 * g + 3]};
-        if (a.bias) {
-          const f32x4 bv = {a.bias[co], a.bias[co + 1], a.bias[co + 2], a.bias[co + 3]};
-          v += bv;
+        for (int g = 0; g < 4; ++g) {
+          const int co = (nhalf * NB + nb) * 32 + 8 * g + 4 * (lane >> 5);
+          f32x4 v = {acc[pb][nb][4 * g + 0], acc[pb][nb][4 * g + 1], acc[pb][nb][4 * g + 2],
+                     acc[pb][nb][4 * g + 3]};
+          if (a.bias) {
+            const f32x4 bv = {a.bias[co], a.bias[co + 1], a.bias[co + 2], a.bias[co + 3]};
+            v += bv;
+          }
+          *reinterpret_cast<bf16x4*>(yb + size_t(q) * COUT + co) = __builtin_convertvector(v, bf16x4);
         }
-        *reinterpret_cast<bf16x4*>(yb + size_t(q) * COUT + co) = __builtin_convertvector(v, bf16x4);
       }
+    }
+  } else {
+    __syncthreads();   // every wave is done with the staged tiles: the LDS is free for a copy of the output tile
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {
+      const int pl = (wave * PB + pb) * 32 + (lane & 31);
+      const int q = q0 + pl;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int co = (nhalf * NB + nb) * 32 + 8 * g + 4 * (lane >> 5);
+          f32x4 v = {acc[pb][nb][4 * g + 0], acc[pb][nb][4 * g + 1], acc[pb][nb][4 * g + 2],
+                     acc[pb][nb][4 * g + 3]};
+          if (a.bias) {
+            const f32x4 bv = {a.bias[co], a.bias[co + 1], a.bias[co + 2], a.bias[co + 3]};
+            v += bv;
+          }
+          bf16x4 r = __builtin_convertvector(v, bf16x4);
+          if (q < HW) *reinterpret_cast<bf16x4*>(yb + size_t(q) * COUT + co) = r;
+          if (q >= HW) r = bf16x4{0, 0, 0, 0};   // pixels past the image add nothing
+          *reinterpret_cast<bf16x4*>(smem + size_t(pl) * SP + co * 2) = r;
+        }
+      }
+    }
+  }
+  if constexpr (STATS) {
+    constexpr int NGRP = NTHR / COUT;   // pixel groups summed side by side
+    static_assert(NTHR % COUT == 0 && MT % NGRP == 0, "column sums need whole pixel groups");
+    float* red = reinterpret_cast<float*>(smem + size_t(MT) * SP);   // [NGRP][2][COUT]
+    __syncthreads();
+    {
+      const int c = tid % COUT, grp = tid / COUT;
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll 8
+      for (int p = grp; p < MT; p += NGRP) {
+        const float v = float(*reinterpret_cast<const bf16*>(smem + size_t(p) * SP + c * 2));
+        t1 += v;
+        t2 += v * v;
+      }
+      red[(grp * 2 + 0) * COUT + c] = t1;
+      red[(grp * 2 + 1) * COUT + c] = t2;
+    }
+    __syncthreads();
+    const int nparts = a.B * int(gridDim.x);
+    const int col = b * int(gridDim.x) + (slot % int(gridDim.x));
+    for (int t = tid; t < 2 * COUT; t += NTHR) {
+      float tot = 0.f;
+#pragma unroll
+      for (int gq = 0; gq < NGRP; ++gq) tot += red[(gq * 2 + t / COUT) * COUT + t % COUT];
+      a.stats[size_t(t) * nparts + col] = tot;
     }
   }
 }
@@ -246,9 +313,11 @@ __global__ void sept_conv5x5_prep_kernel(const float* w, bf16* wt, int cout, int
 struct ConvVariant {
   int cin, cout, pb, wp, wn, tg, cs;
   const void* fn;
+  const void* fn_stats;   // the same kernel with the statistics epilogue (forward shapes only), or null
 };
 #define SEPT_CONV_VARIANT(ci, co, pb, wp, wn, tg, cs) \
-  { ci, co, pb, wp, wn, tg, cs, reinterpret_cast<const void*>(&sept_conv5x5_mfma_kernel<ci, co, pb, wp, wn, tg, cs>) }
+  { ci, co, pb, wp, wn, tg, cs, reinterpret_cast<const void*>(&sept_conv5x5_mfma_kernel<ci, co, pb, wp, wn, tg, cs>), \
+    (ci <= co) ? reinterpret_cast<const void*>(&sept_conv5x5_mfma_kernel<ci, co, pb, wp, wn, tg, cs, (ci <= co)>) : nullptr }
 // Order = measured preference of tile shapes at the training shapes (tools/sweep_conv.py): the
 // 8-wave 256-pixel tiles first, smaller tiles for wide images.  Within the first tile shape that
 // fits, the dispatcher scores the buffering (TG 0 double / TG 1 single) and channel-slice (CS)
@@ -279,12 +348,9 @@ extern "C" int sept_conv5x5_prep_weights(const float* w_oihw, int cout, int cin,
   return sept::launch_check("sept_conv5x5_prep_kernel");
 }
 
-extern "C" int sept_conv5x5_forward(const void* x, const void* wt, const float* bias, void* y, int B, int H,
-                                    int W, int cin, int cout, void* stream) {
-  SEPT_REQUIRE(B >= 0 && H > 0 && W > 0, SEPT_ERR_INVALID, "sept_conv5x5_forward: B=%d H=%d W=%d", B, H, W);
-  if (B == 0) return SEPT_OK;
-  SEPT_REQUIRE(x && wt && y, SEPT_ERR_INVALID, "sept_conv5x5_forward: null argument");
-  SEPT_REQUIRE(B <= 65528, SEPT_ERR_UNSUPPORTED, "sept_conv5x5_forward: B=%d exceeds grid.y", B);
+namespace {
+// The kernel for a shape; with want_stats only if its statistics form keeps the same number of workgroups per CU.
+const ConvVariant* conv_pick(int W, int cin, int cout, bool want_stats, size_t* smem_out) {
   const ConvVariant* best = nullptr;
   size_t best_smem = 0;
   int best_score = -1;
@@ -312,22 +378,65 @@ extern "C" int sept_conv5x5_forward(const void* x, const void* wt, const float* 
       best_score = score;
     }
   }
+  if (best && want_stats) {
+    const size_t need = conv_stats_smem(32 * best->pb * best->wp, cout, 64 * best->wp * best->wn);
+    const size_t both = std::max(best_smem, need);
+    if (!best->fn_stats || both > 160 * 1024 || (160 * 1024) / both < std::min<size_t>(2, (160 * 1024) / best_smem))
+      return nullptr;
+    best_smem = both;
+  }
+  *smem_out = best_smem;
+  return best;
+}
+
+int conv_launch(const char* who, const void* x, const void* wt, const float* bias, void* y, float* stats, int B, int H,
+                int W, int cin, int cout, void* stream) {
+  SEPT_REQUIRE(B >= 0 && H > 0 && W > 0, SEPT_ERR_INVALID, "%s: B=%d H=%d W=%d", who, B, H, W);
+  if (B == 0) return SEPT_OK;
+  SEPT_REQUIRE(x && wt && y, SEPT_ERR_INVALID, "%s: null argument", who);
+  SEPT_REQUIRE(B <= 65528, SEPT_ERR_UNSUPPORTED, "%s: B=%d exceeds grid.y", who, B);
+  size_t best_smem = 0;
+  const ConvVariant* best = conv_pick(W, cin, cout, stats != nullptr, &best_smem);
   SEPT_REQUIRE(best, SEPT_ERR_UNSUPPORTED,
-               "sept_conv5x5_forward: no kernel for cin=%d cout=%d W=%d (supported channel pairs: 32->64, "
-               "64->128, 64->32, 128->64, 128->128)", cin, cout, W);
+               "%s: no kernel for cin=%d cout=%d W=%d (supported channel pairs: 32->64, "
+               "64->128, 64->32, 128->64, 128->128; statistics form: see sept_conv5x5_stats_parts)", who, cin, cout, W);
+  const void* fn = stats ? best->fn_stats : best->fn;
   ConvArgs a;
   a.x = static_cast<const bf16*>(x);
   a.wt = static_cast<const bf16*>(wt);
   a.bias = bias;
+  a.stats = stats;
   a.y = static_cast<bf16*>(y);
   a.B = B;
   a.H = H;
   a.W = W;
   const int mt = 32 * best->pb * best->wp;
   a.nr_max = conv_nr_max(mt, W);
-  SEPT_HIP(sept::allow_max_lds(best->fn));
+  SEPT_HIP(sept::allow_max_lds(fn));
   dim3 grid((H * W + mt - 1) / mt, (B + 7) / 8 * 8), block(64 * best->wp * best->wn);
   void* args[] = {&a};
-  SEPT_HIP(hipLaunchKernel(best->fn, grid, block, args, best_smem, static_cast<hipStream_t>(stream)));
+  SEPT_HIP(hipLaunchKernel(fn, grid, block, args, best_smem, static_cast<hipStream_t>(stream)));
   return SEPT_OK;
+}
+}  // namespace
+
+extern "C" int sept_conv5x5_forward(const void* x, const void* wt, const float* bias, void* y, int B, int H,
+                                    int W, int cin, int cout, void* stream) {
+  return conv_launch("sept_conv5x5_forward", x, wt, bias, y, nullptr, B, H, W, cin, cout, stream);
+}
+
+// Forward + the BatchNorm statistics partials of the output: stats[2*cout][sept_conv5x5_stats_parts(...)] floats
+// (sums, then sums of squares; one column per workgroup), to be finished by sept_bn_stats_from_partials.
+extern "C" int sept_conv5x5_stats_parts(int B, int H, int W, int cin, int cout) {
+  size_t smem = 0;
+  const ConvVariant* v = (B > 0 && H > 0 && W > 0) ? conv_pick(W, cin, cout, true, &smem) : nullptr;
+  if (!v) return 0;   // no statistics form for this shape
+  const int mt = 32 * v->pb * v->wp;
+  return B * ((H * W + mt - 1) / mt);
+}
+
+extern "C" int sept_conv5x5_forward_stats(const void* x, const void* wt, const float* bias, void* y, float* stats,
+                                          int B, int H, int W, int cin, int cout, void* stream) {
+  SEPT_REQUIRE(stats && B > 0, SEPT_ERR_INVALID, "sept_conv5x5_forward_stats: null statistics buffer / empty batch");
+  return conv_launch("sept_conv5x5_forward_stats", x, wt, bias, y, stats, B, H, W, cin, cout, stream);
 }

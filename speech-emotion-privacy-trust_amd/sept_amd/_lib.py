@@ -36,6 +36,8 @@ SIGNATURES = {
     "sept_conv5x5_prep_weights": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "sept_conv5x5_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                      c_void_p]),
+    "sept_conv5x5_stats_parts": (c_int, [c_int] * 5),
+    "sept_conv5x5_forward_stats": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
     "sept_conv5x5_wgrad_workspace_floats": (c_size_t, [c_int, c_int]),
     "sept_conv5x5_backward_weight": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                              c_void_p]),

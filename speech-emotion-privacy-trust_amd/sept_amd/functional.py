@@ -186,7 +186,16 @@ def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None, gfeat=Non
             pre = ops.conv1_forward(x, cv.weight, cv.bias)
         else:
             wt = _cached("convfwd", cv.weight, lambda: ops.conv5x5_prep_weights(cv.weight, 0))
-            pre = ops.conv5x5(act, wt, cv.bias)
+            res = None
+            if CONV_FUSED_STATS and bn.training and not _SYNC_BN["on"]:   # statistics in the conv's epilogue
+                res = ops.conv5x5_forward_stats(act, wt, cv.bias, bn.running_mean, bn.running_var,
+                                                bn.num_batches_tracked,
+                                                bn.momentum if bn.momentum is not None else 0.1, bn.eps)
+            if res is not None:
+                pre, mean, invstd = res
+                fused_stats = True
+            else:
+                pre = ops.conv5x5(act, wt, cv.bias)
         if fused_stats:
             pass
         elif bn.training:
@@ -378,6 +387,8 @@ def trunk_backward(S, P, dlogits, need_wgrad=True, need_dx=True):
 WGRAD_STREAM = os.environ.get("SEPT_WGRAD_STREAM", "1") != "0"
 # BatchNorm backward: channel sums from the pooled tensors (SEPT_BN_POOLED=0: from every window of the pre-activations)
 BN_POOLED_SUMS = os.environ.get("SEPT_BN_POOLED", "1") != "0"
+# BatchNorm statistics of the 5x5 conv layers from the conv kernel's epilogue (SEPT_CONV_STATS=0: a separate pass)
+CONV_FUSED_STATS = os.environ.get("SEPT_CONV_STATS", "1") != "0"
 NO_WGRAD_FORK = set()
 _WG_STREAMS = {}
 _DEFERRED = {"on": False, "pending": []}

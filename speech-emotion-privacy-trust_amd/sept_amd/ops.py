@@ -72,6 +72,32 @@ def conv5x5(x: torch.Tensor, wt: torch.Tensor, bias: torch.Tensor = None, out: t
     return out
 
 
+def conv5x5_forward_stats(x, wt, bias, bn_running_mean=None, bn_running_var=None, bn_num_batches_tracked=None,
+                          momentum=0.1, eps=1e-5):
+    """conv5x5 forward that also yields the batch statistics of its output: (y bf16 (B,H,W,cout), mean, invstd),
+    or None when the shape has no statistics form.  The running buffers of the BatchNorm are updated here."""
+    require_cuda(x, wt)
+    B, H, W, cin = x.shape
+    cout = wt.shape[1]
+    nparts = lib.sept_conv5x5_stats_parts(B, H, W, cin, cout)
+    if nparts <= 0:
+        return None
+    assert x.dtype == torch.bfloat16 and wt.dtype == torch.bfloat16 and x.is_contiguous() and wt.is_contiguous()
+    out = torch.empty((B, H, W, cout), dtype=torch.bfloat16, device=x.device)
+    parts = workspace(f"conv5x5_stats{cout}", nparts * 2 * cout, x.device)
+    h = TIMER.start(f"conv5x5_mfma<{cin},{cout}>") if TIMER is not None else None
+    check(lib.sept_conv5x5_forward_stats(x.data_ptr(), wt.data_ptr(), _p(bias), out.data_ptr(), parts.data_ptr(),
+                                         B, H, W, cin, cout, _s(x)), "sept_conv5x5_forward_stats")
+    if h is not None:
+        TIMER.stop(h)
+    mean = torch.empty(cout, dtype=torch.float32, device=x.device)
+    invstd = torch.empty_like(mean)
+    check(lib.sept_bn_stats_from_partials(parts.data_ptr(), nparts, B * H * W, cout, mean.data_ptr(), invstd.data_ptr(),
+                                          _p(bn_running_mean), _p(bn_running_var), _p(bn_num_batches_tracked),
+                                          float(momentum), float(eps), _s(x)), "sept_bn_stats_from_partials")
+    return out, mean, invstd
+
+
 def _p(t):
     return 0 if t is None else t.data_ptr()
 

@@ -170,3 +170,30 @@ def test_conv1_forward_with_fused_bn_statistics(B, H, W):
     mean2, invstd2 = ops.bn_stats(y, rm2, rv2, nb2)
     assert torch.allclose(mean, mean2, rtol=1e-5, atol=1e-6) and torch.allclose(invstd, invstd2, rtol=1e-5)
     assert torch.allclose(rm, rm2, rtol=1e-5, atol=1e-7) and torch.allclose(rv, rv2, rtol=1e-5) and int(nb) == 1
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout", [(5, 100, 40, 32, 64), (3, 50, 20, 64, 128), (2, 25, 10, 128, 128),
+                                            (3, 37, 13, 32, 64), (1, 9, 5, 64, 128)])
+def test_conv5x5_forward_with_fused_bn_statistics(B, H, W, cin, cout):
+    """sept_conv5x5_forward_stats: same output as the plain forward (bit-equal), and the statistics it leaves
+    equal a BatchNorm statistics pass over that output (mean / invstd and the running buffers)."""
+    from sept_amd import ops
+    g = torch.Generator().manual_seed(cin + H)
+    x = torch.randn(B, H, W, cin, generator=g).bfloat16().cuda()
+    w = (torch.randn(cout, cin, 5, 5, generator=g) * 0.05).cuda()
+    bias = (torch.randn(cout, generator=g) * 0.3).cuda()
+    wt = ops.conv5x5_prep_weights(w, 0)
+    y0 = ops.conv5x5(x, wt, bias)
+    rm0, rv0, n0 = torch.zeros(cout).cuda(), torch.ones(cout).cuda(), torch.zeros((), dtype=torch.int64).cuda()
+    mean0, invstd0 = ops.bn_stats(y0, rm0, rv0, n0)
+    rm1, rv1, n1 = torch.zeros(cout).cuda(), torch.ones(cout).cuda(), torch.zeros((), dtype=torch.int64).cuda()
+    res = ops.conv5x5_forward_stats(x, wt, bias, rm1, rv1, n1)
+    assert res is not None
+    y1, mean1, invstd1 = res
+    assert torch.equal(y0, y1)
+    assert torch.allclose(mean1, mean0, rtol=1e-5, atol=1e-6), (mean1 - mean0).abs().max()
+    assert torch.allclose(invstd1, invstd0, rtol=1e-5), (invstd1 / invstd0 - 1).abs().max()
+    assert torch.allclose(rm1, rm0, rtol=1e-5, atol=1e-7) and torch.allclose(rv1, rv0, rtol=1e-5) and int(n1) == 1
+    # the data-gradient shapes (cin > cout) have no statistics form
+    assert ops.conv5x5_forward_stats(torch.zeros(1, 8, 8, 64, dtype=torch.bfloat16).cuda(),
+                                     torch.zeros(25, 32, 64, dtype=torch.bfloat16).cuda(), None) is None
