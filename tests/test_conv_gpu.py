@@ -52,6 +52,30 @@ def test_conv_data_gradient(B, H, W, cin, cout):
     assert torch.allclose(dx, want, rtol=1e-2, atol=1e-2), (dx - want).abs().max()
 
 
+def test_conv_forward_with_statistics_random_shapes():
+    """Seeded sweep over image sizes that hit every tile-tail case (H*W not a multiple of the 128 / 256-pixel
+    tiles, widths down to the 5-pixel minimum, batch sizes around the 8-image XCD groups): output against the
+    fp32 conv, statistics against the mean / variance of that output."""
+    import random
+    from sept_amd import ops
+    rnd = random.Random(20)
+    for _ in range(14):
+        cin, cout = rnd.choice([(32, 64), (64, 128), (128, 128)])
+        B, H, W = rnd.randint(1, 11), rnd.randint(5, 70), rnd.randint(5, 44)
+        g = torch.Generator().manual_seed(B * 131 + H * 7 + W)
+        x = torch.randn(B, H, W, cin, generator=g).bfloat16().cuda()
+        w = (torch.randn(cout, cin, 5, 5, generator=g) / (cin * 25) ** 0.5).cuda()
+        bias = (0.3 * torch.randn(cout, generator=g)).cuda()
+        res = ops.conv5x5_forward_stats(x, ops.conv5x5_prep_weights(w, 0), bias)
+        assert res is not None, (B, H, W, cin, cout)
+        y, mean, invstd = res
+        want = _ref(x, w, bias)
+        assert ((y.float() - want).abs() <= want.abs() * 2 ** -7 + 1e-3).all(), (B, H, W, cin, cout)
+        yf = y.float().reshape(-1, cout).double()
+        assert torch.allclose(mean.double(), yf.mean(0), rtol=1e-5, atol=1e-6), (B, H, W, cin, cout)
+        assert torch.allclose(invstd.double(), (yf.var(0, unbiased=False) + 1e-5).rsqrt(), rtol=1e-4), (B, H, W, cin, cout)
+
+
 def test_conv_errors():
     from sept_amd import ops
     from sept_amd._lib import SeptError
