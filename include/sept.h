@@ -239,6 +239,12 @@ int sept_lstm_backward(const float* dout, const float* out, const float* gates, 
  * sept_cloak_scales writes scales[n] and/or their mean (device scalar). */
 int sept_cloak_forward(const float* x, const float* locs, const float* rhos, const float* eps, const float* mask,
                        float min_scale, float max_scale, float* xn, int B, long n_per, void* stream);
+/* forward with eps[eps_rows][n_per], eps_rows = 1 (as sept_cloak_forward) or B: one epsilon per row -- the test()
+ * loops (training_cloak_with_grl.py:72-83, adversary_cloak_evaluation.py:66-96) run ONE window per forward, so
+ * cloak_noise.sample_noise draws a fresh epsilon for every window; the batched inference path keeps that. */
+int sept_cloak_forward_rows(const float* x, const float* locs, const float* rhos, const float* eps, int eps_rows,
+                            const float* mask, float min_scale, float max_scale, float* xn, int B, long n_per,
+                            void* stream);
 int sept_cloak_scales(const float* rhos, float min_scale, float max_scale, float* scales, float* mean_out, long n,
                       void* stream);
 int sept_cloak_backward(const float* dxa, const float* dxb, float gscale_b, const float* rhos, const float* eps,
@@ -247,6 +253,8 @@ int sept_cloak_backward(const float* dxa, const float* dxb, float gscale_b, cons
 
 /* y = a * x  (GradientReversalFunction.backward with a = -lambda, reversal_gradient.py:18-23) */
 int sept_scale(const float* x, float a, float* y, long n, void* stream);
+/* y[i] = value (zero gradients of conv biases in front of a train-mode BatchNorm; flat-buffer housekeeping) */
+int sept_fill(float* y, float value, long n, void* stream);
 /* y = x * m  (GRU inter-layer dropout with a pre-scaled mask) */
 int sept_mul(const float* x, const float* m, float* y, long n, void* stream);
 /* y = x * (*scalar_dev): scale by a value that lives on the device (no host read of a loss gradient). */
@@ -358,6 +366,14 @@ int sept_resample_forward(const float* x, const float* ker, float* out, int B, l
 size_t sept_speaker_stats_workspace_doubles(int B, int F);
 int sept_speaker_stats(const float* mel_btf, const int* spk, int B, int T, int F, int S, double* ws,
                        float* stats, void* stream);
+/* The reference's OWN statistics population (preprocess_adversary_data.py:26-27 appends every row of every SAVED
+ * item): a clip saved as nwin windows counts frame t once per window containing it and never the frames behind the
+ * last window; a clip shorter than win, or a test-split speaker's clip (saved whole, once: :55-59, whole_clip[b]
+ * != 0), counts every frame once.  lengths[b] <= T = valid frames of clip b (NULL: T); same outputs / workspace as
+ * sept_speaker_stats, which weights every frame 1. */
+int sept_speaker_stats_windows(const float* mel_btf, const int* spk, const int* lengths,
+                               const unsigned char* whole_clip, int B, int T, int F, int S, int win, int shift,
+                               double* ws, float* stats, void* stream);
 int sept_window_norm_spk(const float* mel_btf, const float* stats, const int* spk, int mode, float* out,
                          int B, int T, int F, int win, int shift, int nwin, void* stream);
 int sept_add_normal(const float* x, float* out, long n, float stdv, unsigned long long seed,
@@ -369,6 +385,15 @@ int sept_sgd_step(float* p, const float* g, float* momentum_buf, long n, float l
                   float weight_decay, int first_step, float grad_scale, void* stream);
 int sept_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
                    float eps, float weight_decay, int step, float grad_scale, void* stream);
+/* The same updates with the learning rate (and Adam's step count, >= 1, kept current by sept_counter_add) read
+ * from device memory: the optimiser can then be part of a captured HIP graph, and a scheduler -- StepLR(10, 0.5)
+ * for SGD, ReduceLROnPlateau for Adam, training_cloak_with_grl.py:418,421 -- drives it by writing *lr_dev between
+ * replays.  momentum_buf must start as zeros (torch's first SGD step, buf = d, then falls out of the recurrence). */
+int sept_sgd_step_dev(float* p, const float* g, float* momentum_buf, long n, const float* lr_dev, float momentum,
+                      float weight_decay, float grad_scale, void* stream);
+int sept_adam_step_dev(float* p, const float* g, float* m, float* v, long n, const float* lr_dev, float beta1,
+                       float beta2, float eps, float weight_decay, const long long* step_dev, float grad_scale,
+                       void* stream);
 
 #ifdef __cplusplus
 }

@@ -19,6 +19,12 @@ Differences from the reference that are deliberate and test-only:
   * dropout masks and the cloak epsilon can be injected (``eps=``, ``drop=``) so that train
     mode is reproducible across implementations; with nothing injected the modules behave
     like the reference (torch RNG).
+  * ``sim_bf16`` (set by ``simulate_bf16(model)``): the conv stack rounds to bf16 exactly where the HIP path
+    stores bf16 -- conv weights of the 5x5 MFMA layers, the pre-BatchNorm conv outputs and the pooled block
+    outputs in the forward pass, and the gradients of those two activation tensors in the backward pass -- so
+    that both sides take the SAME max-pool decisions and a gradient comparison is not blurred by near-ties
+    (an fp32 network and a bf16 one pick different, equally valid window maxima).  Off by default: the
+    restatement pinned to the reference is the fp32 one.
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this file.
 """
 import torch
@@ -79,6 +85,34 @@ class cloak_noise(nn.Module):
 
 
 # ----------------------------------------------------------------------------------------
+# bf16 storage simulation (test hook, see the header)
+# ----------------------------------------------------------------------------------------
+class _RoundBF16(torch.autograd.Function):
+    """A tensor the HIP path keeps in bf16: value rounded forward, its gradient rounded backward."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
+
+
+def _round_weight(w):
+    """bf16 operand copy of an fp32 master weight (the gradient reaches the master unrounded)."""
+    return w + (w.detach().bfloat16().float() - w.detach())
+
+
+def simulate_bf16(model, on=True):
+    """Switch the bf16 storage simulation of every two_d_cnn_lstm-style network inside `model`."""
+    for m in model.modules():
+        if isinstance(m, _TwoDBase):
+            m.sim_bf16 = bool(on)
+    return model
+
+
+# ----------------------------------------------------------------------------------------
 # baseline classifiers (baseline_models.py)
 # ----------------------------------------------------------------------------------------
 def _rnn_cell(name):
@@ -113,6 +147,7 @@ class _TwoDBase(nn.Module):
         self.cnn_filter_size, self.attention_size = cnn_filter_size, attention_size
         self.pred, self.att = pred, att
         self.deep = deep
+        self.sim_bf16 = False
         self.rnn_input_size = int(128 * input_spec_size / 8)
         self.rnn_cell = _rnn_cell(rnn_cell)
         self.dropout = nn.Dropout(p=self.dropout_p)
@@ -142,8 +177,25 @@ class _TwoDBase(nn.Module):
         # nothing: weights stay at torch default init.
 
     # the trunk shared with the cloak wrappers (cloak_models.py:165-193)
+    def _conv_sim_bf16(self, x):
+        """self.conv with the HIP path's bf16 storage points (conv1 runs on split-bf16 operands ~ fp32)."""
+        mods = list(self.conv)
+        if mods and isinstance(mods[0], GradientReversal):      # Sequential(GradientReversal, conv) of the GRL wrapper
+            x, mods = mods[0](x), list(mods[1])
+        i, first = 0, True
+        while i < len(mods):
+            conv, bn, j = mods[i], mods[i + 1], i + 3           # Conv2d, BatchNorm2d, ReLU
+            w = conv.weight if first else _round_weight(conv.weight)
+            pre = _RoundBF16.apply(F.conv2d(x, w, conv.bias, padding=2))
+            y = F.relu(bn(pre))
+            if isinstance(mods[j], nn.MaxPool2d):
+                y, j = mods[j](y), j + 1
+            x = _RoundBF16.apply(mods[j](y))                      # Dropout2d, then the stored block output
+            i, first = j + 1, False
+        return x
+
     def features(self, x, global_feature=None, pooling="model"):
-        x = self.conv(x.float())
+        x = self._conv_sim_bf16(x.float()) if self.sim_bf16 else self.conv(x.float())
         x = x.transpose(1, 2).contiguous()
         s = x.size()
         x = x.reshape(-1, s[1], s[2] * s[3])

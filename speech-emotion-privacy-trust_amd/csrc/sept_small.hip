@@ -20,13 +20,16 @@ __device__ __forceinline__ float cloak_scale(float rho, float smin, float smax) 
   return (1.0f + tanhf(rho)) * 0.5f * (smax - smin) + smin;
 }
 
-// xn[b][i] = x[b][i] (*mask[i]) + locs[i] + scales(rhos[i]) * eps[i] (*mask[i])
+// xn[b][i] = x[b][i] (*mask[i]) + locs[i] + scales(rhos[i]) * eps[b * eps_stride + i] (*mask[i])
+// eps_stride 0: one epsilon for the whole batch (training, cloak_models.py:45-50); n_per: one per row (the
+// reference's test() loops run one window per forward, i.e. a fresh draw per window).
 __global__ void cloak_fwd_kernel(const float* x, const float* locs, const float* rhos, const float* eps,
-                                 const float* mask, float smin, float smax, float* xn, long n_per, long total) {
+                                 long eps_stride, const float* mask, float smin, float smax, float* xn, long n_per,
+                                 long total) {
   GRID_STRIDE(i, total) {
     const long k = i % n_per;
     const float m = mask ? mask[k] : 1.0f;
-    xn[i] = x[i] * m + locs[k] + cloak_scale(rhos[k], smin, smax) * (eps[k] * m);
+    xn[i] = x[i] * m + locs[k] + cloak_scale(rhos[k], smin, smax) * (eps[(i / n_per) * eps_stride + k] * m);
   }
 }
 
@@ -91,6 +94,7 @@ __global__ __launch_bounds__(256) void cloak_bwd_kernel(const float* dxa, const 
 
 // ---------------- generic elementwise ----------------
 __global__ void scale_kernel(const float* x, float a, float* y, long n) { GRID_STRIDE(i, n) y[i] = a * x[i]; }
+__global__ void fill_kernel(float* y, float v, long n) { GRID_STRIDE(i, n) y[i] = v; }
 
 __global__ void mul_kernel(const float* x, const float* m, float* y, long n) { GRID_STRIDE(i, n) y[i] = x[i] * m[i]; }
 // y = x * (*s): a scale that lives on the device (the upstream gradient of a scalar loss)
@@ -515,6 +519,68 @@ __global__ void clip_stats_kernel(const float* mel, int B, int T, int F, double*
     o[0] = s; o[1] = ss; o[2] = mn; o[3] = mx;
   }
 }
+// The reference's population (preprocess_adversary_data.py:26-27, 41-83): the rows of the SAVED items.  A clip of
+// len frames saved as windows [i*shift, i*shift+win), i < nwin = (len - win)/shift + 1, contributes frame t once per
+// window containing it (frames behind the last window: never); a clip shorter than win, or one of a test-split
+// speaker (saved whole, once), contributes every frame once.
+__device__ __forceinline__ int frame_mult(int t, int len, int win, int shift, bool whole) {
+  if (whole || len < win) return 1;
+  const int nwin = (len - win) / shift + 1;
+  const int hi = min(nwin - 1, t / shift);
+  const int lo = t < win ? 0 : (t - win) / shift + 1;   // smallest i with i*shift + win > t
+  return max(0, hi - lo + 1);
+}
+__device__ __forceinline__ long clip_rows(int len, int win, int shift, bool whole) {
+  if (whole || len < win) return len;
+  return long((len - win) / shift + 1) * win;
+}
+// stage 1 with multiplicities: lengths[b] <= T valid frames (null: T), whole[b] != 0: saved whole (test split)
+__global__ void clip_stats_windows_kernel(const float* mel, const int* lengths, const unsigned char* whole, int B, int T,
+                                          int F, int win, int shift, double* ws) {
+  GRID_STRIDE(i, long(B) * F) {
+    const int f = i % F;
+    const long b = i / F;
+    const float* p = mel + b * T * F + f;
+    const int len = lengths ? min(lengths[b], T) : T;
+    const bool wh = whole && whole[b];
+    double s = 0.0, ss = 0.0, mn = INFINITY, mx = -INFINITY;
+    for (int t = 0; t < len; ++t) {
+      const int m = frame_mult(t, len, win, shift, wh);
+      if (m == 0) continue;
+      const double v = p[size_t(t) * F];
+      s += m * v;
+      ss += m * v * v;
+      mn = fmin(mn, v);
+      mx = fmax(mx, v);
+    }
+    double* o = ws + i * 4;
+    o[0] = s; o[1] = ss; o[2] = mn; o[3] = mx;
+  }
+}
+__global__ void speaker_stats_windows_kernel(const double* ws, const int* spk, const int* lengths,
+                                             const unsigned char* whole, int B, int T, int F, int S, int win, int shift,
+                                             float* stats) {
+  GRID_STRIDE(i, long(S) * F) {
+    const int f = i % F, sp = i / F;
+    double s = 0.0, ss = 0.0, mn = INFINITY, mx = -INFINITY;
+    long n = 0;
+    for (int b = 0; b < B; ++b) {
+      if ((spk ? spk[b] : 0) != sp) continue;
+      const double* o = ws + (size_t(b) * F + f) * 4;
+      s += o[0]; ss += o[1]; mn = fmin(mn, o[2]); mx = fmax(mx, o[3]);
+      n += clip_rows(lengths ? min(lengths[b], T) : T, win, shift, whole && whole[b]);
+    }
+    float* out = stats + size_t(sp) * 4 * F;
+    if (n == 0) {   // speaker without clips in this batch: identity statistics
+      out[f] = 0.f; out[F + f] = 1.f; out[2 * F + f] = 0.f; out[3 * F + f] = 1.f;
+      continue;
+    }
+    const double m = s / double(n);
+    double var = ss / double(n) - m * m;
+    var = var < 0 ? 0 : var;
+    out[f] = float(m); out[F + f] = float(sqrt(var)); out[2 * F + f] = float(mn); out[3 * F + f] = float(mx);
+  }
+}
 // stage 2: one thread per (speaker, mel bin) combines its clips in clip order -> stats[s][{mean,std,min,max}][f]
 __global__ void speaker_stats_kernel(const double* ws, const int* spk, int B, int T, int F, int S, float* stats) {
   GRID_STRIDE(i, long(S) * F) {
@@ -684,6 +750,40 @@ __global__ void adam_kernel(float* p, const float* g, float* m, float* v, long n
   }
 }
 
+// The same two updates with the learning rate and the step count read from DEVICE memory, so the optimiser can
+// live inside a captured HIP graph: a scheduler (StepLR / ReduceLROnPlateau, training_cloak_with_grl.py:418,421)
+// changes the rate by writing the scalar between replays, and Adam's bias corrections follow the device counter
+// (incremented by sept_counter_add in the same graph).  SGD needs no first-step flag: with a zero momentum
+// buffer momentum * 0 + d = d is what torch does on its first step.
+__global__ void sgd_dev_kernel(float* p, const float* g, float* buf, long n, const float* lr_dev, float momentum,
+                               float wd, float gscale) {
+  const float lr = *lr_dev;
+  GRID_STRIDE(i, n) {
+    float d = g[i] * gscale + wd * p[i];
+    if (momentum != 0.f) {
+      const float b = momentum * buf[i] + d;
+      buf[i] = b;
+      d = b;
+    }
+    p[i] -= lr * d;
+  }
+}
+__global__ void adam_dev_kernel(float* p, const float* g, float* m, float* v, long n, const float* lr_dev, float b1,
+                                float b2, float eps, float wd, const long long* step_dev, float gscale) {
+  const float lr = *lr_dev;
+  const float step = float(*step_dev);
+  const float bc1 = 1.0f - powf(b1, step);
+  const float bc2_sqrt = sqrtf(1.0f - powf(b2, step));
+  GRID_STRIDE(i, n) {
+    const float d = g[i] * gscale + wd * p[i];
+    const float mi = b1 * m[i] + (1.f - b1) * d;
+    const float vi = b2 * v[i] + (1.f - b2) * d * d;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+  }
+}
+
 }  // namespace
 
 #define ST(s) static_cast<hipStream_t>(s)
@@ -696,7 +796,20 @@ extern "C" int sept_cloak_forward(const float* x, const float* locs, const float
   SEPT_REQUIRE(x && locs && rhos && eps && xn, SEPT_ERR_INVALID, "sept_cloak_forward: null argument");
   const long total = long(B) * n_per;
   hipLaunchKernelGGL(cloak_fwd_kernel, dim3(blocks_for(total)), dim3(kThreads), 0, ST(stream), x, locs, rhos, eps,
-                     mask, min_scale, max_scale, xn, n_per, total);
+                     0L, mask, min_scale, max_scale, xn, n_per, total);
+  return sept::launch_check("cloak_fwd_kernel");
+}
+
+extern "C" int sept_cloak_forward_rows(const float* x, const float* locs, const float* rhos, const float* eps,
+                                       int eps_rows, const float* mask, float min_scale, float max_scale, float* xn,
+                                       int B, long n_per, void* stream) {
+  SEPT_REQUIRE(B >= 0 && n_per > 0 && (eps_rows == 1 || eps_rows == B), SEPT_ERR_INVALID,
+               "sept_cloak_forward_rows: B=%d n=%ld eps_rows=%d (1 or B)", B, n_per, eps_rows);
+  if (B == 0) return SEPT_OK;
+  SEPT_REQUIRE(x && locs && rhos && eps && xn, SEPT_ERR_INVALID, "sept_cloak_forward_rows: null argument");
+  const long total = long(B) * n_per;
+  hipLaunchKernelGGL(cloak_fwd_kernel, dim3(blocks_for(total)), dim3(kThreads), 0, ST(stream), x, locs, rhos, eps,
+                     eps_rows == 1 ? 0L : n_per, mask, min_scale, max_scale, xn, n_per, total);
   return sept::launch_check("cloak_fwd_kernel");
 }
 
@@ -728,6 +841,13 @@ extern "C" int sept_scale(const float* x, float a, float* y, long n, void* strea
   SEPT_REQUIRE(x && y && n > 0, SEPT_ERR_INVALID, "sept_scale: bad argument");
   hipLaunchKernelGGL(scale_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, ST(stream), x, a, y, n);
   return sept::launch_check("scale_kernel");
+}
+
+extern "C" int sept_fill(float* y, float value, long n, void* stream) {
+  if (n == 0) return SEPT_OK;
+  SEPT_REQUIRE(y && n > 0, SEPT_ERR_INVALID, "sept_fill: bad argument");
+  hipLaunchKernelGGL(fill_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, ST(stream), y, value, n);
+  return sept::launch_check("fill_kernel");
 }
 
 extern "C" int sept_scale_dev(const float* x, const float* scalar_dev, float* y, long n, void* stream) {
@@ -960,6 +1080,18 @@ extern "C" int sept_speaker_stats(const float* mel_btf, const int* spk, int B, i
   return sept::launch_check("speaker_stats_kernel");
 }
 
+extern "C" int sept_speaker_stats_windows(const float* mel_btf, const int* spk, const int* lengths,
+                                          const unsigned char* whole_clip, int B, int T, int F, int S, int win, int shift,
+                                          double* ws, float* stats, void* stream) {
+  SEPT_REQUIRE(mel_btf && ws && stats && B > 0 && T > 0 && F > 0 && S > 0 && win > 0 && shift > 0, SEPT_ERR_INVALID,
+               "sept_speaker_stats_windows: bad argument");
+  hipLaunchKernelGGL(clip_stats_windows_kernel, dim3(blocks_for(long(B) * F)), dim3(kThreads), 0, ST(stream), mel_btf,
+                     lengths, whole_clip, B, T, F, win, shift, ws);
+  hipLaunchKernelGGL(speaker_stats_windows_kernel, dim3(blocks_for(long(S) * F)), dim3(kThreads), 0, ST(stream), ws, spk,
+                     lengths, whole_clip, B, T, F, S, win, shift, stats);
+  return sept::launch_check("speaker_stats_windows_kernel");
+}
+
 extern "C" int sept_window_norm_spk(const float* mel_btf, const float* stats, const int* spk, int mode, float* out,
                                     int B, int T, int F, int win, int shift, int nwin, void* stream) {
   if (B == 0) return SEPT_OK;
@@ -1032,4 +1164,24 @@ extern "C" int sept_adam_step(float* p, const float* g, float* m, float* v, long
   hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, ST(stream), p, g, m, v, n, lr, beta1, beta2,
                      eps, weight_decay, bc1, bc2_sqrt, grad_scale);
   return sept::launch_check("adam_kernel");
+}
+
+extern "C" int sept_sgd_step_dev(float* p, const float* g, float* momentum_buf, long n, const float* lr_dev,
+                                 float momentum, float weight_decay, float grad_scale, void* stream) {
+  if (n == 0) return SEPT_OK;
+  SEPT_REQUIRE(p && g && lr_dev && n > 0 && (momentum == 0.f || momentum_buf), SEPT_ERR_INVALID,
+               "sept_sgd_step_dev: bad argument");
+  hipLaunchKernelGGL(sgd_dev_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, ST(stream), p, g, momentum_buf, n, lr_dev,
+                     momentum, weight_decay, grad_scale);
+  return sept::launch_check("sgd_dev_kernel");
+}
+
+extern "C" int sept_adam_step_dev(float* p, const float* g, float* m, float* v, long n, const float* lr_dev,
+                                  float beta1, float beta2, float eps, float weight_decay, const long long* step_dev,
+                                  float grad_scale, void* stream) {
+  if (n == 0) return SEPT_OK;
+  SEPT_REQUIRE(p && g && m && v && lr_dev && step_dev && n > 0, SEPT_ERR_INVALID, "sept_adam_step_dev: bad argument");
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, ST(stream), p, g, m, v, n, lr_dev, beta1,
+                     beta2, eps, weight_decay, step_dev, grad_scale);
+  return sept::launch_check("adam_dev_kernel");
 }

@@ -15,8 +15,6 @@ except ImportError:
     import _paths  # noqa: F401
     from reversal_gradient import GradientReversal
 
-import os
-
 import torch
 import torch.nn as nn
 
@@ -36,13 +34,15 @@ class cloak_noise(nn.Module):
         self.device = device
         self.normal = torch.distributions.normal.Normal(0, 0.1)
         self.eps = None  # test hook: fixed epsilon instead of a fresh draw
+        self.eps_per_row = False   # set by the batched test() loops (sept_amd/inference.py): one draw per window
 
-    def _epsilon(self):
+    def _epsilon(self, rows=1):
         if self.eps is not None:
             return self.eps.to(self.rhos.device, torch.float32).contiguous()
         # Normal(0, 0.1) from the device's 'eps' Philox stream: same seed on every rank, so a
         # data-parallel job sees the ONE epsilon per step the reference broadcasts over the batch
-        return SF.ops.rng(self.rhos.device, "eps").normal(tuple(self.rhos.shape), 0.0, 0.1)
+        shape = tuple(self.rhos.shape) if rows == 1 else (rows,) + tuple(self.rhos.shape[1:])
+        return SF.ops.rng(self.rhos.device, "eps").normal(shape, 0.0, 0.1)
 
     def scales(self):
         return SF.ScalesFn.apply(self.rhos, float(self.min_scale), float(self.max_scale))
@@ -58,7 +58,8 @@ class cloak_noise(nn.Module):
         m = None if mask is None else mask.to(self.rhos.device, torch.float32).contiguous()
         x = input.float()
         shape = x.shape
-        xn = SF.CloakFn.apply(x.reshape(shape[0], -1), self.locs, self.rhos, self._epsilon(), m,
+        xn = SF.CloakFn.apply(x.reshape(shape[0], -1), self.locs, self.rhos,
+                              self._epsilon(shape[0] if self.eps_per_row else 1), m,
                               float(self.min_scale), float(self.max_scale))
         return xn.view(shape)
 
@@ -95,19 +96,6 @@ class two_d_cnn_lstm_syn(nn.Module):
         return preds, noisy
 
 
-# run the emotion and the gender branch of the GRL step on two HIP streams (SEPT_CONCURRENT=0 disables)
-CONCURRENT_BRANCHES = os.environ.get("SEPT_CONCURRENT", "1") != "0"
-_STREAMS = {}
-
-
-def _branch_streams(device):
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
-    if key not in _STREAMS:
-        _STREAMS[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
-        SF.NO_WGRAD_FORK.update(st.cuda_stream for st in _STREAMS[key])   # see functional.WGRAD_STREAM
-    return _STREAMS[key]
-
-
 class two_d_cnn_lstm_syn_with_grl(nn.Module):
     def __init__(self, original_model, gender_model, noise_model, grl_lambda):
         super().__init__()
@@ -120,36 +108,24 @@ class two_d_cnn_lstm_syn_with_grl(nn.Module):
 
     def forward(self, input_var, global_feature=None, mask=None, grl=False, pooling=None):
         x = input_var.float()
-        x = self.intermed(x) if mask is None else self.intermed(x, mask)
-        noisy = x.detach()
         pool = _pool_arg(pooling)
         att = self.original_model.att   # the reference keys BOTH branches on the emotion model's flag (:171, :208)
-        if not (CONCURRENT_BRANCHES and x.is_cuda):
-            preds1 = self.original_model.hip_logits(x, 'emotion', pool, global_feature=global_feature, att=att)
-            # gender branch: the GradientReversal module sits in front of its conv stack
-            xr = self.gender_model.conv[0](x)
-            preds2 = self.gender_model.hip_logits(xr, 'gender', pool, global_feature=global_feature, att=att)
-            return preds1, preds2, noisy
-        # The two branches only share the noisy input: each runs on its own HIP stream (forward here,
-        # backward on the same streams through autograd), so the latency-bound kernels of one (GRU
-        # steps, small GEMMs, reductions) fill the gaps of the other's.  Kernels stay deterministic;
-        # only their interleaving changes.
-        cur = torch.cuda.current_stream(x.device)
-        s1, s2 = _branch_streams(x.device)
-        s1.wait_stream(cur)
-        s2.wait_stream(cur)
-        capturing = torch.cuda.is_current_stream_capturing()   # graph-private memory needs no stream records
-        if not capturing:
-            x.record_stream(s1)
-            x.record_stream(s2)
-        with torch.cuda.stream(s1):
-            preds1 = self.original_model.hip_logits(x, 'emotion', pool, global_feature=global_feature, att=att)
-        with torch.cuda.stream(s2):
-            xr = self.gender_model.conv[0](x)
-            preds2 = self.gender_model.hip_logits(xr, 'gender', pool, global_feature=global_feature, att=att)
-        cur.wait_stream(s1)
-        cur.wait_stream(s2)
-        if not capturing:
-            preds1.record_stream(cur)
-            preds2.record_stream(cur)
+        noise = self.intermed
+        if x.is_cuda and not x.requires_grad and x.dim() == 4 and x.shape[1] == 1:
+            # one autograd node for cloak -> (emotion trunk || GRL -> gender trunk): two HIP streams inside, one
+            # cloak backward kernel fed by both branches' input gradients (sept_amd/functional.py: GrlPairFn)
+            m = None if mask is None else mask.to(x.device, torch.float32).contiguous()
+            P1 = SF.trunk_params(self.original_model, 'emotion', att)
+            P2 = SF.trunk_params(self.gender_model, 'gender', att)
+            pl1, pl2 = SF._param_list(P1), SF._param_list(P2)
+            cfg = (float(noise.min_scale), float(noise.max_scale), float(self.gender_model.conv[0].lambda_))
+            eps = noise._epsilon(x.shape[0] if noise.eps_per_row else 1)
+            return SF.GrlPairFn.apply(x, noise.locs, noise.rhos, eps, m, cfg, P1, P2, pool, global_feature, len(pl1),
+                                      *pl1, *pl2)
+        # general composition (an input that itself needs a gradient): cloak, then the two trunks one after the other
+        x = noise(x) if mask is None else noise(x, mask)
+        noisy = x.detach()
+        preds1 = self.original_model.hip_logits(x, 'emotion', pool, global_feature=global_feature, att=att)
+        xr = self.gender_model.conv[0](x)   # the GradientReversal module sits in front of the gender conv stack
+        preds2 = self.gender_model.hip_logits(xr, 'gender', pool, global_feature=global_feature, att=att)
         return preds1, preds2, noisy

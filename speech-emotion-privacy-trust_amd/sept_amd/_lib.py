@@ -63,10 +63,13 @@ SIGNATURES = {
     "sept_gru_forward": (c_int, [c_void_p] * 7 + [c_int] * 3 + [c_void_p]),
     "sept_gru_backward": (c_int, [c_void_p] * 8 + [c_int] * 3 + [c_void_p]),
     "sept_cloak_forward": (c_int, [c_void_p] * 5 + [c_float, c_float, c_void_p, c_int, c_long, c_void_p]),
+    "sept_cloak_forward_rows": (c_int, [c_void_p] * 4 + [c_int, c_void_p, c_float, c_float, c_void_p, c_int, c_long,
+                                        c_void_p]),
     "sept_cloak_scales": (c_int, [c_void_p, c_float, c_float, c_void_p, c_void_p, c_long, c_void_p]),
     "sept_cloak_backward": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_float, c_float,
                                     c_float, c_void_p, c_void_p, c_void_p, c_int, c_long, c_void_p]),
     "sept_scale": (c_int, [c_void_p, c_float, c_void_p, c_long, c_void_p]),
+    "sept_fill": (c_int, [c_void_p, c_float, c_long, c_void_p]),
     "sept_mul": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
     "sept_relu_dropout_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
     "sept_relu_dropout_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
@@ -94,6 +97,7 @@ SIGNATURES = {
                                        c_void_p]),
     "sept_speaker_stats_workspace_doubles": (c_size_t, [c_int, c_int]),
     "sept_speaker_stats": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "sept_speaker_stats_windows": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p, c_void_p, c_void_p]),
     "sept_window_norm_spk": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                      c_int, c_void_p]),
     "sept_add_normal": (c_int, [c_void_p, c_void_p, c_long, c_float, c_ulonglong, c_void_p, c_ulonglong, c_void_p]),
@@ -124,6 +128,9 @@ SIGNATURES = {
                               c_void_p]),
     "sept_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float, c_float,
                                c_float, c_int, c_float, c_void_p]),
+    "sept_sgd_step_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_float, c_float, c_float, c_void_p]),
+    "sept_adam_step_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_float, c_float, c_float,
+                                   c_float, c_void_p, c_float, c_void_p]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

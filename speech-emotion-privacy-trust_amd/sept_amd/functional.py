@@ -102,8 +102,10 @@ def trunk_params(model, head: str, att="model"):
     if not isinstance(rnn, (torch.nn.GRU, torch.nn.LSTM)):
         raise NotImplementedError("the HIP path implements rnn_cell 'gru' and 'lstm'")
     if rnn.hidden_size not in (64, 128) or rnn.num_layers != 2 or not rnn.bidirectional:
-        raise NotImplementedError("the HIP recurrences support hidden 64 (the trainer's config) or 128 (the class "
-                                  "default), 2 layers, bidirectional")
+        raise NotImplementedError(
+            f"rnn hidden_size={rnn.hidden_size} num_layers={rnn.num_layers} bidirectional={rnn.bidirectional}: the HIP "
+            "recurrences (sept_gru_* / sept_lstm_*) support hidden 64 (the trainers' config) or 128 (the class "
+            "default) with 2 bidirectional layers; there is no fallback for other shapes")
     att = model.att if att == "model" else att
     if att not in (None, "self_att"):
         raise ValueError(f"unknown attention mode {att!r}")
@@ -298,11 +300,29 @@ def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None, gfeat=Non
     return logits, (S if need_grad else None)
 
 
+def grad_out(param):
+    """Where a weight gradient should be WRITTEN: a fresh view of the parameter's slot in its trainer's flat
+    gradient buffer (FlatParams registers `_sept_flat` on the parameter), or None (the op allocates).  A fresh
+    view object per call, so autograd's AccumulateGrad can adopt it as .grad without a copy."""
+    slot = getattr(param, "_sept_flat", None)
+    if slot is None or not param.requires_grad:
+        return None
+    fp, off, n = slot
+    return fp.grad[off:off + n].view(param.shape)
+
+
+def _into(out, src):
+    """src copied into the flat slot `out` when there is one"""
+    return src if out is None else ops.copy_into(out, src.contiguous())
+
+
 def trunk_backward(S, P, dlogits, need_wgrad=True, need_dx=True):
     """Returns (dx (B,H,W) fp32 or None, grads: dict parameter-tensor-id -> gradient) for one
-    network.  With need_wgrad False (frozen model) only the data path is evaluated."""
+    network.  With need_wgrad False (frozen model) only the data path is evaluated.  Weight gradients are
+    written straight into the flat gradient buffer of the trainer that owns the parameters (grad_out)."""
     B, T = S.B, S.T
     grads = {}
+    gout = grad_out if need_wgrad else (lambda p: None)
 
     def put(param, g):
         if need_wgrad and param is not None and param.requires_grad:
@@ -321,12 +341,12 @@ def trunk_backward(S, P, dlogits, need_wgrad=True, need_dx=True):
                     n = h.weight.shape[0]
                     dl = dlogits[:, c0:c0 + n]
                     c0 += n
-                    put(h.weight, ops.linear_backward_weight(dl, S.d1a))
-                    put(h.bias, ops.colsum(dl))
-                put(P.dense1.weight, ops.linear_backward_weight(d_d1, S.z))
-                put(P.dense1.bias, ops.colsum(d_d1))
+                    put(h.weight, ops.linear_backward_weight(dl, S.d1a, out=gout(h.weight)))
+                    put(h.bias, ops.colsum(dl, out=gout(h.bias)))
+                put(P.dense1.weight, ops.linear_backward_weight(d_d1, S.z, out=gout(P.dense1.weight)))
+                put(P.dense1.bias, ops.colsum(d_d1, out=gout(P.dense1.bias)))
             sq.small(head_wgrads, dlogits, d_d1, S.d1a, S.z)
-        return _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq)
+        return _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq, gout)
     d_d1a, c0 = None, 0
     for h in P.heads:
         n = h.weight.shape[0]
@@ -338,13 +358,13 @@ def trunk_backward(S, P, dlogits, need_wgrad=True, need_dx=True):
             ops.gemm_raw(dl, dl.stride(0), 1, h.weight, h.weight.shape[1], 1, d_d1a, d_d1a.stride(0), B,
                          h.weight.shape[1], n, beta=1.0)
         if need_wgrad:
-            put(h.weight, ops.linear_backward_weight(dl, S.d1a))
-            put(h.bias, ops.colsum(dl))
+            put(h.weight, ops.linear_backward_weight(dl, S.d1a, out=gout(h.weight)))
+            put(h.bias, ops.colsum(dl, out=gout(h.bias)))
     d_d1 = ops.relu_dropout_backward(d_d1a, S.d1, S.dmask)
     dz = ops.linear_backward_input(d_d1, P.dense1.weight)
     if need_wgrad:
-        put(P.dense1.weight, ops.linear_backward_weight(d_d1, S.z))
-        put(P.dense1.bias, ops.colsum(d_d1))
+        put(P.dense1.weight, ops.linear_backward_weight(d_d1, S.z, out=gout(P.dense1.weight)))
+        put(P.dense1.bias, ops.colsum(d_d1, out=gout(P.dense1.bias)))
     if dz.shape[1] != S.zdim:   # the appended global features are inputs: no gradient needed
         dz = dz[:, :S.zdim].contiguous()
     Hh = S.Hh
@@ -356,17 +376,17 @@ def trunk_backward(S, P, dlogits, need_wgrad=True, need_dx=True):
         ds2 = dscores.view(B * T, -1)
         d_a1 = ops.tanh_backward(ops.linear_backward_input(ds2, P.att2.weight), S.att.a1t)
         if need_wgrad:
-            put(P.att2.weight, ops.linear_backward_weight(ds2, S.att.a1t))
-            put(P.att1.weight, ops.linear_backward_weight(d_a1, x2))
+            put(P.att2.weight, ops.linear_backward_weight(ds2, S.att.a1t, out=gout(P.att2.weight)))
+            put(P.att1.weight, ops.linear_backward_weight(d_a1, x2, out=gout(P.att1.weight)))
             if P.att2.bias is not None:   # deep variant: Linear with bias
-                put(P.att2.bias, ops.colsum(ds2))
+                put(P.att2.bias, ops.colsum(ds2, out=gout(P.att2.bias)))
             if P.att1.bias is not None:
-                put(P.att1.bias, ops.colsum(d_a1))
+                put(P.att1.bias, ops.colsum(d_a1, out=gout(P.att1.bias)))
         w1 = P.att1.weight
         ops.gemm_raw(d_a1, d_a1.stride(0), 1, w1, w1.shape[1], 1, dout, H2, B * T, H2, w1.shape[0], beta=1.0)
     else:
         dout = ops.mean_t_backward(dz, T) if S.pooling == "mean" else dz.view(B, T, H2)
-    return _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq)
+    return _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq, gout)
 
 
 # Weight gradients are off the critical path of the backward pass (nothing downstream reads them until
@@ -393,11 +413,44 @@ NO_WGRAD_FORK = set()
 _WG_STREAMS = {}
 _DEFERRED = {"on": False, "pending": []}
 
+# HIP-graph capture and side streams.  On ROCm 7.2 hipStreamEndCapture aborts the PROCESS (core dump, no error
+# code) when a forked stream is joined into another FORKED stream inside a capture:
+#     origin -> s1 (s1.wait_stream(origin)) -> wg (wg.wait_stream(s1)); s1.wait_stream(wg)      aborts
+#     origin -> s1 -> wg; origin.wait_stream(wg); origin.wait_stream(s1)                           works
+#     origin -> wg1, origin -> wg2; origin joins both                                             works
+# (tools/repro_capture_nested_join.py; gpurun_out/cap_*.log of round 1).  So under capture a side stream may
+# only be used when its join lands on the capture's ORIGIN stream.  The trainers' capture() methods publish that
+# stream through capture_origin(); everything here that forks checks fork_allowed() and otherwise runs in line --
+# same kernels, same results, one queue -- instead of recording a topology that kills the process.
+_CAPTURE = {"origin": None}
+
+
+class capture_origin:
+    """with capture_origin(): ... -- marks the current stream as the origin of a HIP-graph capture."""
+
+    def __enter__(self):
+        self.prev = _CAPTURE["origin"]
+        _CAPTURE["origin"] = torch.cuda.current_stream().cuda_stream
+        return self
+
+    def __exit__(self, *exc):
+        _CAPTURE["origin"] = self.prev
+        return False
+
+
+def fork_allowed(device, join_on_current=True):
+    """May the caller fork a side stream off the CURRENT stream (and join it back there)?  Always outside a
+    capture; inside one only when the current stream is the published capture origin."""
+    if device.type != "cuda" or not torch.cuda.is_current_stream_capturing():
+        return True
+    return _CAPTURE["origin"] is not None and torch.cuda.current_stream(device).cuda_stream == _CAPTURE["origin"]
+
 
 def backward(loss):
     """loss.backward() for the trainers: branch networks may leave small weight gradients on side streams;
-    they are joined into the current stream here, before the caller touches any .grad."""
-    _DEFERRED["on"] = WGRAD_STREAM
+    they are joined into the current stream here, before the caller touches any .grad.  Under a capture
+    the deferred join is only recorded when this stream is the capture origin (see above)."""
+    _DEFERRED["on"] = WGRAD_STREAM and fork_allowed(loss.device)
     try:
         loss.backward()
     finally:
@@ -419,6 +472,8 @@ class _SideQueue:
         self.nested = cur in NO_WGRAD_FORK
         if self.nested and not _DEFERRED["on"]:
             return
+        if not self.nested and not fork_allowed(device):
+            return   # capturing on a non-origin stream: the join below would be a nested one -- stay in line
         key = (device.index, cur)
         if key not in _WG_STREAMS:
             _WG_STREAMS[key] = torch.cuda.Stream(device=device)
@@ -448,7 +503,7 @@ class _SideQueue:
             self.keep.clear()
 
 
-def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq):
+def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq, gout):
     """The recurrent layers and the conv stack of trunk_backward, from the gradient of the last recurrent output."""
     B, T = S.B, S.T
     Hh = S.Hh
@@ -473,13 +528,16 @@ def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq):
                 for d, tag in ((0, ""), (1, "_reverse")):
                     gh = dgh2[:, d * G:(d + 1) * G]
                     dwih = dwcat[d * G:(d + 1) * G]
+                    wih, whh = getattr(r, "weight_ih" + sfx + tag), getattr(r, "weight_hh" + sfx + tag)
+                    bih, bhh = getattr(r, "bias_ih" + sfx + tag), getattr(r, "bias_hh" + sfx + tag)
                     if layer == 0:
-                        dwih = ops.permute_cols(dwih, S.C, S.Wd, inverse=True)
-                    put(getattr(r, "weight_ih" + sfx + tag), dwih)
-                    put(getattr(r, "weight_hh" + sfx + tag),
-                        ops.linear_backward_weight(gh, hp2[:, d * Hh:(d + 1) * Hh]))
-                    put(getattr(r, "bias_ih" + sfx + tag), dbih[d * G:(d + 1) * G])
-                    put(getattr(r, "bias_hh" + sfx + tag), dbhh[d * G:(d + 1) * G])
+                        dwih = ops.permute_cols(dwih, S.C, S.Wd, inverse=True, out=gout(wih))
+                    else:
+                        dwih = _into(gout(wih), dwih)
+                    put(wih, dwih)
+                    put(whh, ops.linear_backward_weight(gh, hp2[:, d * Hh:(d + 1) * Hh], out=gout(whh)))
+                    put(bih, _into(gout(bih), dbih[d * G:(d + 1) * G]))
+                    put(bhh, _into(gout(bhh), dbhh[d * G:(d + 1) * G]))
             sq.small(rnn_wgrads, dgi2, dgh2, hp2, Gs.inp)
         # gradient wrt the layer input: dgi [W_if; W_ir]  (one product, reduction length 2G)
         odt = torch.float32 if layer == 1 else torch.bfloat16
@@ -501,23 +559,29 @@ def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq):
         dpre, dgamma, dbeta = ops.bn_relu_pool_backward(dact, blk.pre, blk.mean, blk.invstd, bn.weight, bn.bias,
                                                         blk.drop, blk.pool, need_param_grads=want_bn,
                                                         sync_group=_SYNC_BN["group"], sync=blk.sync,
-                                                        y=blk.out if BN_POOLED_SUMS else None)
+                                                        y=blk.out if BN_POOLED_SUMS else None,
+                                                        out_gamma=gout(bn.weight) if want_bn else None,
+                                                        out_beta=gout(bn.bias) if want_bn else None)
         if want_bn:
             put(bn.weight, dgamma)
             put(bn.bias, dbeta)
         if li == 0:
             if need_wgrad and cv.weight.requires_grad:
-                dw, db = sq.big(lambda dpre=dpre: ops.conv1_backward_weight(S.x, dpre), dpre, S.x)
+                dw, db = sq.big(lambda dpre=dpre: ops.conv1_backward_weight(S.x, dpre, out_w=gout(cv.weight),
+                                                                            out_b=gout(cv.bias)), dpre, S.x)
                 put(cv.weight, dw)
                 put(cv.bias, db)
             if need_dx:
                 dx = ops.conv1_backward_data(dpre, cv.weight)
         else:
             if need_wgrad and cv.weight.requires_grad:
-                put(cv.weight, sq.big(lambda blk=blk, dpre=dpre: ops.conv5x5_backward_weight(blk.inp, dpre), dpre, blk.inp))
+                put(cv.weight, sq.big(lambda blk=blk, dpre=dpre: ops.conv5x5_backward_weight(blk.inp, dpre,
+                                                                                             out=gout(cv.weight)),
+                                      dpre, blk.inp))
                 # the conv bias feeds straight into a training-mode BatchNorm, whose backward has
                 # zero channel sum by construction: d(bias) == 0 (the reference gets rounding noise)
-                put(cv.bias, torch.zeros_like(cv.bias))
+                ob = gout(cv.bias)
+                put(cv.bias, ops.fill(ob if ob is not None else torch.empty_like(cv.bias), 0.0))
             wtd = _cached("convdgrad", cv.weight, lambda: ops.conv5x5_prep_weights(cv.weight, 1))
             dact = ops.conv5x5(dpre, wtd)
     sq.finish()
@@ -590,6 +654,7 @@ class CloakFn(torch.autograd.Function):
                                min_scale, max_scale)
         ctx.save_for_backward(rhos.detach(), eps, mask if mask is not None else torch.empty(0))
         ctx.has_mask = mask is not None
+        ctx.per_row = eps.numel() != rhos.numel()
         ctx.cfg = (float(min_scale), float(max_scale))
         ctx.need = (locs.requires_grad, rhos.requires_grad)
         return xn
@@ -597,9 +662,122 @@ class CloakFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dxn):
         rhos, eps, mask = ctx.saved_tensors
+        if ctx.per_row:
+            raise SeptError("per-window epsilon is an inference mode (test() loops); training draws one epsilon per step")
         dlocs, drhos = ops.cloak_backward(dxn.contiguous(), None, 0.0, rhos, eps, mask if ctx.has_mask else None,
                                           ctx.cfg[0], ctx.cfg[1], need_locs=ctx.need[0], need_rhos=ctx.need[1])
         return None, dlocs, drhos, None, None, None, None
+
+
+# run the emotion and the gender branch of the GRL step on two HIP streams (SEPT_CONCURRENT=0 disables)
+CONCURRENT_BRANCHES = os.environ.get("SEPT_CONCURRENT", "1") != "0"
+_BRANCH_STREAMS = {}
+
+
+def branch_streams(device):
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _BRANCH_STREAMS:
+        _BRANCH_STREAMS[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+        NO_WGRAD_FORK.update(st.cuda_stream for st in _BRANCH_STREAMS[key])   # see WGRAD_STREAM above
+    return _BRANCH_STREAMS[key]
+
+
+class GrlPairFn(torch.autograd.Function):
+    """The whole body of two_d_cnn_lstm_syn_with_grl.forward (cloak_models.py:157-226) as ONE autograd node:
+        xn = cloak(x);  preds1 = emotion_trunk(xn);  preds2 = gender_trunk(GradientReversal(xn))
+    Forward and backward run the two trunks on two HIP streams (they only share xn), joined on the caller's
+    stream inside this node -- so under a HIP-graph capture every join lands on the capture origin.  The
+    backward hands BOTH branches' input gradients to one cloak kernel, sept_cloak_backward(dxa, dxb, -lambda):
+    no gradient-reversal scale pass, no autograd accumulation add (three full-tensor passes in round 1).
+    forward(ctx, x, locs, rhos, eps, mask, cfg, P1, P2, pooling, gfeat, n1, *params): cfg = (min_scale, max_scale,
+    grl_lambda); params = the n1 tensors of the emotion trunk, then the gender trunk's."""
+
+    @staticmethod
+    def forward(ctx, x, locs, rhos, eps, mask, cfg, P1, P2, pooling, gfeat, n1, *params):
+        smin, smax, lam = cfg
+        shape = x.shape
+        x2 = x.detach().float().contiguous().view(shape[0], -1)
+        xn = ops.cloak_forward(x2, locs.detach(), rhos.detach(), eps, mask, smin, smax)
+        xw = xn.view(shape[0], shape[-2], shape[-1])
+        need = any(ctx.needs_input_grad)
+        dev = x.device
+        two = CONCURRENT_BRANCHES and fork_allowed(dev)
+        if two:
+            cur = torch.cuda.current_stream(dev)
+            s1, s2 = branch_streams(dev)
+            s1.wait_stream(cur)
+            s2.wait_stream(cur)
+            capturing = torch.cuda.is_current_stream_capturing()   # graph-private memory needs no stream records
+            if not capturing:
+                xn.record_stream(s1)
+                xn.record_stream(s2)
+            with torch.cuda.stream(s1):
+                l1, S1 = trunk_forward(xw, P1, pooling, need_grad=need, gfeat=gfeat)
+            with torch.cuda.stream(s2):
+                l2, S2 = trunk_forward(xw, P2, pooling, need_grad=need, gfeat=gfeat)
+            cur.wait_stream(s1)
+            cur.wait_stream(s2)
+            if not capturing:
+                l1.record_stream(cur)
+                l2.record_stream(cur)
+        else:
+            l1, S1 = trunk_forward(xw, P1, pooling, need_grad=need, gfeat=gfeat)
+            l2, S2 = trunk_forward(xw, P2, pooling, need_grad=need, gfeat=gfeat)
+        ctx.S, ctx.P, ctx.two = (S1, S2), (P1, P2), two
+        ctx.params, ctx.n1, ctx.cfg = params, n1, cfg
+        ctx.cloak = (locs, rhos, eps, mask)
+        ctx.need_cloak = (locs.requires_grad, rhos.requires_grad)
+        ctx.need_w = (any(p.requires_grad for p in params[:n1]), any(p.requires_grad for p in params[n1:]))
+        noisy = xn.view(shape)
+        ctx.mark_non_differentiable(noisy)     # the reference returns input.detach() (:162)
+        return l1, l2, noisy
+
+    @staticmethod
+    def backward(ctx, d1, d2, _dnoisy):
+        (S1, S2), (P1, P2) = ctx.S, ctx.P
+        locs, rhos, eps, mask = ctx.cloak
+        smin, smax, lam = ctx.cfg
+        need_dx = any(ctx.need_cloak)
+        dev = d1.device
+        two = ctx.two and fork_allowed(dev)
+        prev = _DEFERRED["on"]
+        if two:
+            cur = torch.cuda.current_stream(dev)
+            s1, s2 = branch_streams(dev)
+            s1.wait_stream(cur)
+            s2.wait_stream(cur)
+            _DEFERRED["on"] = WGRAD_STREAM     # the branches' small weight gradients fork; joined HERE, on `cur`
+            try:
+                with torch.cuda.stream(s2):    # the gender branch first: its recurrent chain is the critical path
+                    dx2, g2 = trunk_backward(S2, P2, d2, need_wgrad=ctx.need_w[1], need_dx=need_dx)
+                with torch.cuda.stream(s1):
+                    dx1, g1 = trunk_backward(S1, P1, d1, need_wgrad=ctx.need_w[0], need_dx=need_dx)
+            finally:
+                _DEFERRED["on"] = prev
+            cur.wait_stream(s1)
+            cur.wait_stream(s2)
+            for wg, _keep in _DEFERRED["pending"]:
+                cur.wait_stream(wg)
+            _DEFERRED["pending"].clear()
+        else:
+            _DEFERRED["on"] = False
+            try:
+                dx2, g2 = trunk_backward(S2, P2, d2, need_wgrad=ctx.need_w[1], need_dx=need_dx)
+                dx1, g1 = trunk_backward(S1, P1, d1, need_wgrad=ctx.need_w[0], need_dx=need_dx)
+            finally:
+                _DEFERRED["on"] = prev
+        ctx.S = None
+        dlocs = drhos = None
+        if need_dx:
+            B = dx1.shape[0]
+            dlocs, drhos = ops.cloak_backward(dx1.view(B, -1), dx2.view(B, -1), -float(lam), rhos.detach(), eps, mask,
+                                              smin, smax, need_locs=ctx.need_cloak[0], need_rhos=ctx.need_cloak[1],
+                                              out_locs=grad_out(locs) if ctx.need_cloak[0] else None,
+                                              out_rhos=None)   # rhos may get a second term (scale loss): autograd adds
+        grads = dict(g1)
+        grads.update(g2)
+        gp = tuple(grads.get(p) if p.requires_grad else None for p in ctx.params)
+        return (None, dlocs, drhos, None, None, None, None, None, None, None, None) + gp
 
 
 class ScalesFn(torch.autograd.Function):

@@ -3,7 +3,11 @@
 utterance is cut into win_len-frame windows every 50 frames (test_len = int((T - win_len) / 50)
 + 1), each window goes through the model in eval mode, the softmax outputs are averaged and the
 arg-max is the utterance's prediction.  The reference runs one window per forward; here all
-windows of all utterances go through the HIP kernels in one batch."""
+windows of all utterances go through the HIP kernels in one batch -- with one cloak epsilon PER WINDOW
+(`cloak_noise.eps_per_row`), because each of the reference's per-window forwards draws its own
+(cloak_models.py:45-50), and with `global_feature` repeated per window as the reference passes it (:79-83)."""
+import contextlib
+
 import torch
 
 from . import ops
@@ -11,8 +15,22 @@ from . import ops
 SHIFT_LEN = 50  # training_cloak_with_grl.py:37
 
 
+@contextlib.contextmanager
+def _per_window_epsilon(model):
+    noise = getattr(model, "intermed", None)
+    prev = getattr(noise, "eps_per_row", None)
+    if prev is not None:
+        noise.eps_per_row = True
+    try:
+        yield
+    finally:
+        if prev is not None:
+            noise.eps_per_row = prev
+
+
 @torch.no_grad()
-def sliding_window_predict(model, features, win_len=200, mask=None, pooling="mean", which="emotion"):
+def sliding_window_predict(model, features, win_len=200, mask=None, pooling="mean", which="emotion",
+                           global_feature=None):
     """features (B, T, F) or (B, 1, T, F) fp32 CUDA, T >= win_len (all utterances of one call share
     T; group by length upstream).  `model` is a cloak wrapper (returns (emo, gender, noisy) or
     (pred, noisy)) or a baseline classifier.  Returns (prediction (B,) int64, mean softmax
@@ -25,16 +43,18 @@ def sliding_window_predict(model, features, win_len=200, mask=None, pooling="mea
     nwin = (T - win_len) // SHIFT_LEN + 1
     windows = ops.window_norm(features.float().contiguous(), None, None, win_len, SHIFT_LEN)  # (B*nwin, win, F)
     x = windows.view(B * nwin, 1, win_len, F)
+    gf = None if global_feature is None else global_feature.repeat_interleave(nwin, dim=0)
     was_training = model.training
     model.eval()
     try:
-        if hasattr(model, "gender_model"):
-            preds, preds_grl, _ = model(x, mask=mask, grl=False, pooling=pooling)
-            logits = preds if which == "emotion" else preds_grl
-        elif hasattr(model, "intermed"):
-            logits, _ = model(x, mask=mask, pooling=pooling)
-        else:
-            logits = model(x)
+        with _per_window_epsilon(model):
+            if hasattr(model, "gender_model"):
+                preds, preds_grl, _ = model(x, global_feature=gf, mask=mask, grl=False, pooling=pooling)
+                logits = preds if which == "emotion" else preds_grl
+            elif hasattr(model, "intermed"):
+                logits, _ = model(x, global_feature=gf, mask=mask, pooling=pooling)
+            else:
+                logits = model(x) if gf is None else model(x, gf)
     finally:
         model.train(was_training)
     probs, pred = ops.softmax_mean(logits.float(), nwin)
@@ -59,7 +79,7 @@ def cloak_evaluation_predict(cloak_model, baseline_model, adversary_model, featu
     added, optionally masked), the NOISY window through the clean emotion model and through the gender
     adversary; softmax, mean over the utterance's windows, arg-max.  Returns
     ((emotion prediction, probabilities), (adversary prediction, probabilities)).  All windows of all
-    utterances share one forward here, i.e. one noise draw, where the reference draws one per window."""
+    utterances share one forward; each window gets its own noise draw, as in the reference's loop."""
     if features.dim() == 4:
         features = features[:, 0]
     B, T, F = features.shape
@@ -74,7 +94,8 @@ def cloak_evaluation_predict(cloak_model, baseline_model, adversary_model, featu
         m.eval()
     try:
         # only the cloak's noisy output is consumed by this loop (the wrapper's own predictions are unused)
-        noisy = (cloak_model.intermed(x) if mask is None else cloak_model.intermed(x, mask)).detach()
+        with _per_window_epsilon(cloak_model):
+            noisy = (cloak_model.intermed(x) if mask is None else cloak_model.intermed(x, mask)).detach()
         logits = baseline_model(noisy) if gf is None else baseline_model(noisy, gf)
         adv_logits = adversary_model(noisy) if gf is None else adversary_model(noisy, gf)
     finally:

@@ -156,12 +156,12 @@ def conv1_backward_data(dy, w):
     return dx
 
 
-def conv1_backward_weight(x, dy, need_bias=True):
+def conv1_backward_weight(x, dy, need_bias=True, out_w=None, out_b=None):
     require_cuda(x, dy)
     B, H, W = x.shape
     ws = workspace("conv1_wgrad", lib.sept_conv1_workspace_floats(), x.device)
-    dw = torch.empty((32, 1, 5, 5), dtype=torch.float32, device=x.device)
-    db = torch.empty(32, dtype=torch.float32, device=x.device) if need_bias else None
+    dw = torch.empty((32, 1, 5, 5), dtype=torch.float32, device=x.device) if out_w is None else out_w
+    db = (torch.empty(32, dtype=torch.float32, device=x.device) if out_b is None else out_b) if need_bias else None
     check(lib.sept_conv1_backward_weight(x.data_ptr(), dy.data_ptr(), ws.data_ptr(), dw.data_ptr(), _p(db), B, H, W,
                                          _s(x)), "sept_conv1_backward_weight")
     return dw, db
@@ -217,7 +217,7 @@ def bn_relu_pool_forward(x, mean, invstd, gamma, beta, dropscale=None, pool=2):
 
 
 def bn_relu_pool_backward(dy, x, mean, invstd, gamma, beta, dropscale=None, pool=2, need_param_grads=True,
-                          sync_group=None, sync=False, y=None):
+                          sync_group=None, sync=False, y=None, out_gamma=None, out_beta=None):
     """y: the pooled output bn_relu_pool_forward returned for the same x (then the channel sums are taken
     from the pooled tensors alone; see include/sept.h).  With sync=True the (sum dy, sum dy*xhat) pair is all-reduced between the reduce and the apply pass
     (sync-BN); dgamma / dbeta stay the local sums -- the data-parallel gradient average finishes them."""
@@ -228,8 +228,10 @@ def bn_relu_pool_backward(dy, x, mean, invstd, gamma, beta, dropscale=None, pool
         raise SeptError(f"bn_relu_pool_backward: y must be the contiguous bf16 pooled output, got {tuple(y.shape)} {y.dtype}")
     ws = workspace("bn", lib.sept_bn_workspace_floats(C), x.device)
     dx = torch.empty_like(x)
-    dgamma = torch.empty(C, dtype=torch.float32, device=x.device) if need_param_grads else None
-    dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if need_param_grads else None
+    dgamma = dbeta = None
+    if need_param_grads:
+        dgamma = torch.empty(C, dtype=torch.float32, device=x.device) if out_gamma is None else out_gamma
+        dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if out_beta is None else out_beta
     if sync:
         sums = torch.empty(2 * C, dtype=torch.float32, device=x.device)
         check(lib.sept_bn_relu_pool_backward_reduce(dy.data_ptr(), x.data_ptr(), _p(y), mean.data_ptr(), invstd.data_ptr(),
@@ -249,13 +251,13 @@ def bn_relu_pool_backward(dy, x, mean, invstd, gamma, beta, dropscale=None, pool
     return dx, dgamma, dbeta
 
 
-def conv5x5_backward_weight(x, dy):
+def conv5x5_backward_weight(x, dy, out=None):
     """x (B,H,W,cin) bf16, dy (B,H,W,cout) bf16 -> dW (cout,cin,5,5) fp32."""
     require_cuda(x, dy)
     B, H, W, cin = x.shape
     cout = dy.shape[-1]
     ws = workspace("conv_wgrad", lib.sept_conv5x5_wgrad_workspace_floats(cin, cout), x.device)
-    dw = torch.empty((cout, cin, 5, 5), dtype=torch.float32, device=x.device)
+    dw = torch.empty((cout, cin, 5, 5), dtype=torch.float32, device=x.device) if out is None else out
     h = TIMER.start(f"conv5x5_wgrad<{cin},{cout}>") if TIMER is not None else None
     check(lib.sept_conv5x5_backward_weight(x.data_ptr(), dy.data_ptr(), ws.data_ptr(), dw.data_ptr(), B, H, W, cin,
                                            cout, _s(x)), "sept_conv5x5_backward_weight")
@@ -401,6 +403,13 @@ def cloak_forward(x, locs, rhos, eps, mask, min_scale, max_scale):
     B = x.shape[0]
     n_per = locs.numel()
     xn = torch.empty_like(x)
+    if eps.numel() != n_per:   # one epsilon per row (batched sliding-window inference)
+        if eps.numel() != B * n_per:
+            raise SeptError(f"cloak_forward: epsilon has {eps.numel()} elements, expected {n_per} or {B} x {n_per}")
+        check(lib.sept_cloak_forward_rows(x.data_ptr(), locs.data_ptr(), rhos.data_ptr(), eps.data_ptr(), B, _p(mask),
+                                          float(min_scale), float(max_scale), xn.data_ptr(), B, n_per, _s(x)),
+              "sept_cloak_forward_rows")
+        return xn
     check(lib.sept_cloak_forward(x.data_ptr(), locs.data_ptr(), rhos.data_ptr(), eps.data_ptr(), _p(mask),
                                  float(min_scale), float(max_scale), xn.data_ptr(), B, n_per, _s(x)),
           "sept_cloak_forward")
@@ -417,15 +426,27 @@ def cloak_scales(rhos, min_scale, max_scale, want_scales=True, want_mean=False):
 
 
 def cloak_backward(dxa, dxb, gscale_b, rhos, eps, mask, min_scale, max_scale, scale_lambda=0.0, scale_mean=None,
-                   need_locs=True, need_rhos=True):
+                   need_locs=True, need_rhos=True, out_locs=None, out_rhos=None):
     B = dxa.shape[0]
     n_per = rhos.numel()
-    dlocs = torch.empty_like(rhos) if need_locs else None
-    drhos = torch.empty_like(rhos) if need_rhos else None
+    dlocs = (torch.empty_like(rhos) if out_locs is None else out_locs) if need_locs else None
+    drhos = (torch.empty_like(rhos) if out_rhos is None else out_rhos) if need_rhos else None
     check(lib.sept_cloak_backward(dxa.data_ptr(), _p(dxb), float(gscale_b), rhos.data_ptr(), eps.data_ptr(), _p(mask),
                                   float(min_scale), float(max_scale), float(scale_lambda), _p(scale_mean), _p(dlocs),
                                   _p(drhos), B, n_per, _s(dxa)), "sept_cloak_backward")
     return dlocs, drhos
+
+
+def fill(t, value=0.0):
+    """t[...] = value (contiguous fp32) through the HIP fill kernel."""
+    check(lib.sept_fill(t.data_ptr(), float(value), t.numel(), _s(t)), "sept_fill")
+    return t
+
+
+def copy_into(dst, src):
+    """dst[...] = src (contiguous fp32, same numel) through the HIP scale kernel."""
+    check(lib.sept_scale(src.data_ptr(), 1.0, dst.data_ptr(), src.numel(), _s(src)), "sept_scale")
+    return dst
 
 
 def scale(x, a, out=None):
@@ -569,6 +590,23 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=
                              float(grad_scale), _s(p)), "sept_adam_step")
 
 
+def sgd_step_dev(p, g, buf, lr_dev, momentum, weight_decay, grad_scale=1.0):
+    """SGD with the learning rate in a 0-dim fp32 device tensor (graph-capturable; buf starts as zeros)."""
+    check(lib.sept_sgd_step_dev(p.data_ptr(), g.data_ptr(), _p(buf), p.numel(), lr_dev.data_ptr(), float(momentum),
+                                float(weight_decay), float(grad_scale), _s(p)), "sept_sgd_step_dev")
+
+
+def adam_step_dev(p, g, m, v, lr_dev, beta1, beta2, eps, weight_decay, step_dev, grad_scale=1.0):
+    """Adam with the learning rate (fp32) and the step count (int64, >= 1) in 0-dim device tensors."""
+    check(lib.sept_adam_step_dev(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr_dev.data_ptr(),
+                                 float(beta1), float(beta2), float(eps), float(weight_decay), step_dev.data_ptr(),
+                                 float(grad_scale), _s(p)), "sept_adam_step_dev")
+
+
+def counter_add(counter, inc=1):
+    check(lib.sept_counter_add(counter.data_ptr(), int(inc), _s(counter)), "sept_counter_add")
+
+
 def window_norm(mel_btf, mean=None, std=None, win=200, shift=50):
     """mel (B, T, F) fp32 -> (B*nwin, win, F) normalised windows; nwin = int((T - win)/shift) + 1
     (training_cloak_with_grl.py:71), 1 zero-padded window when T < win."""
@@ -658,17 +696,28 @@ class Rng:
 _RNGS = {}
 
 
+def _derive_seed(base, name):
+    seed = int(base)
+    if name == "dropout" and torch.distributed.is_available() and torch.distributed.is_initialized():
+        seed = seed * 1000003 + 7919 * (torch.distributed.get_rank() + 1)
+    if name == "eps":
+        seed = seed ^ 0x5EED5EED
+    return seed
+
+
 def rng(device, name="dropout", seed=None) -> Rng:
     """Per-(device, name) Philox stream.  'eps' is seeded identically on every rank (shared cloak
-    epsilon); 'dropout' mixes in the rank so shards draw different masks."""
+    epsilon); 'dropout' mixes in the rank so shards draw different masks.  The base seed is `seed` when given
+    (trainers pass theirs and pin it) or torch's: a later torch.manual_seed() re-keys the streams at their next
+    use, so seeding after a first forward still gives a reproducible run."""
     key = (str(device), name)
     r = _RNGS.get(key)
-    if r is None or seed is not None:
-        if seed is None:
-            seed = torch.initial_seed()
-            if name == "dropout" and torch.distributed.is_available() and torch.distributed.is_initialized():
-                seed = seed * 1000003 + 7919 * (torch.distributed.get_rank() + 1)
-            if name == "eps":
-                seed = seed ^ 0x5EED5EED
-        r = _RNGS[key] = Rng(seed, device)
+    if seed is not None:
+        r = _RNGS[key] = Rng(_derive_seed(seed, name), device)
+        r.base, r.pinned = int(seed), True
+        return r
+    base = torch.initial_seed()
+    if r is None or (not r.pinned and r.base != base):
+        r = _RNGS[key] = Rng(_derive_seed(base, name), device)
+        r.base, r.pinned = base, False
     return r

@@ -12,9 +12,17 @@ WIN_LEN, SHIFT_LEN = 200, 50
 MODES = {"znorm": 0, "min_max": 1}
 
 
-def speaker_stats(mel_btf: torch.Tensor, spk: torch.Tensor = None, n_speakers: int = 1) -> torch.Tensor:
+def speaker_stats(mel_btf: torch.Tensor, spk: torch.Tensor = None, n_speakers: int = 1, population: str = "windows",
+                  lengths: torch.Tensor = None, whole_clip: torch.Tensor = None, win=WIN_LEN, shift=SHIFT_LEN) -> torch.Tensor:
     """mel (B, T, F) fp32, spk (B) int32 speaker index per clip -> stats (S, 4, F) = mean, std, min, max
-    (np.nanmean / nanstd / nanmin / nanmax over all frames of a speaker, :360-367)."""
+    (np.nanmean / nanstd / nanmin / nanmax, :360-367).
+
+    population='windows' (default) is the reference's: its statistics run over the rows of the SAVED items
+    (:26-27), so a frame counts once per 200/50 window that contains it, frames behind a clip's last window never,
+    and the clips of test-split speakers (`whole_clip[b]` true: saved whole, :55-59) or clips shorter than a window
+    count each frame once.  `lengths` (B) gives the valid frames of zero-padded ragged clips.
+    population='frames' weights every frame of every clip once (what an online pipeline without the window
+    bookkeeping would compute; not the reference's numbers)."""
     require_cuda(mel_btf)
     B, T, F = mel_btf.shape
     mel_btf = mel_btf.float().contiguous()
@@ -22,6 +30,21 @@ def speaker_stats(mel_btf: torch.Tensor, spk: torch.Tensor = None, n_speakers: i
         spk = spk.to(device=mel_btf.device, dtype=torch.int32).contiguous()
     ws = torch.empty(lib.sept_speaker_stats_workspace_doubles(B, F), dtype=torch.float64, device=mel_btf.device)
     stats = torch.empty((n_speakers, 4, F), dtype=torch.float32, device=mel_btf.device)
+    if population == "windows":
+        if lengths is not None:
+            lengths = lengths.to(device=mel_btf.device, dtype=torch.int32).contiguous()
+        if whole_clip is not None:
+            whole_clip = whole_clip.to(device=mel_btf.device, dtype=torch.uint8).contiguous()
+        check(lib.sept_speaker_stats_windows(mel_btf.data_ptr(), spk.data_ptr() if spk is not None else None,
+                                             lengths.data_ptr() if lengths is not None else None,
+                                             whole_clip.data_ptr() if whole_clip is not None else None, B, T, F, n_speakers,
+                                             int(win), int(shift), ws.data_ptr(), stats.data_ptr(),
+                                             current_stream_ptr(mel_btf.device)), "sept_speaker_stats_windows")
+        return stats
+    if population != "frames":
+        raise ValueError(f"population must be 'windows' or 'frames', got {population!r}")
+    if lengths is not None or whole_clip is not None:
+        raise ValueError("lengths / whole_clip belong to population='windows'")
     check(lib.sept_speaker_stats(mel_btf.data_ptr(), spk.data_ptr() if spk is not None else None, B, T, F, n_speakers,
                                  ws.data_ptr(), stats.data_ptr(), current_stream_ptr(mel_btf.device)), "sept_speaker_stats")
     return stats

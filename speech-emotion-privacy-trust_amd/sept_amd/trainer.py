@@ -23,6 +23,9 @@ def _advance_rng(device):
 class FlatParams:
     """Packs the trainable parameters into one flat fp32 buffer (parameters become views), so
     the optimiser is one kernel launch and data-parallel needs one all-reduce over one buffer.
+    The gradient buffer has the same layout; every parameter carries its slot (`_sept_flat`), and the
+    backward kernels WRITE their weight gradients into it (functional.grad_out) -- nothing is packed
+    afterwards.
 
     Parameters that receive no gradient (heads / attention matrices the forward never touches)
     are skipped by torch.optim -- no weight decay, no momentum.  The first gather_grads() finds
@@ -48,29 +51,41 @@ class FlatParams:
             v = flat[off:off + n].view_as(p)
             v.copy_(p.data)
             p.data = v
+            p._sept_flat = (self, off, n)
             self.views.append((off, n))
             off += n
         self.flat = flat
 
+    def grad_view(self, i):
+        off, n = self.views[i]
+        return self.grad[off:off + n].view(self.params[i].shape)
+
     def gather_grads(self):
-        """Pack the autograd-produced gradients into the flat gradient buffer (one launch) and
-        expose them as views."""
+        """After backward: make every active parameter's .grad the view of its slot.  The kernels have already
+        written there; a gradient that arrived as a separate tensor (autograd summed two contributions, or the
+        first step ran before the active set was known) is copied in -- one small launch each, none in steady state
+        except the cloak's rhos."""
         if not self._settled:
             self._settled = True
             active = [p for p in self.params if p.grad is not None]
             if len(active) < len(self.params):
-                grads = {id(p): p.grad for p in active}
+                grads = {id(p): p.grad.clone() for p in active}   # the slots are about to move
                 self.params = active + [p for p in self.params if p.grad is None]
                 self.n_active = sum(p.numel() for p in active)
                 self._pack()
                 for p in active:
                     p.grad = grads[id(p)]
             self._n_act_params = len(active)
-        act = self.params[:self._n_act_params]
-        torch.cat([p.grad.reshape(-1) if p.grad is not None else torch.zeros(p.numel(), device=self.flat.device)
-                   for p in act], out=self.grad[:self.n_active])
-        for p, (off, n) in zip(act, self.views):
-            p.grad = self.grad[off:off + n].view_as(p)
+        for i in range(self._n_act_params):
+            p = self.params[i]
+            v = self.grad_view(i)
+            g = p.grad
+            if g is None:
+                ops.fill(v, 0.0) if v.is_cuda else v.zero_()
+            elif g.data_ptr() != v.data_ptr():
+                # (host tensors: the packing logic is exercised on the CPU by tests/test_host_logic.py -- a copy, no compute)
+                ops.copy_into(v, g.detach().float().contiguous()) if v.is_cuda else v.copy_(g.detach())
+            p.grad = v
         for p in self.params[self._n_act_params:]:
             if p.grad is not None:
                 raise RuntimeError("a parameter without a gradient in the first step received one later; "
@@ -81,26 +96,173 @@ class FlatParams:
             p.grad = None
 
 
-class GrlTrainer:
-    def __init__(self, cloak_model, optimizer="sgd", lr=None, momentum=0.9, weight_decay=1e-4, betas=(0.9, 0.98),
-                 eps=1e-9, gender_lambda=0.1, scale_lamda=0.0, suppression=False, process_group=None, sync_bn=False):
-        self.model = cloak_model
-        self.sync_bn = sync_bn   # BatchNorm statistics of the GLOBAL batch (extra tiny all-reduces); default: per rank
-        self.flat = FlatParams(cloak_model.parameters())  # filter(requires_grad), as :417/:420
+class SeptOptimizer(torch.optim.Optimizer):
+    """The handle torch's learning-rate schedulers need (StepLR(10, 0.5) for SGD, ReduceLROnPlateau for Adam:
+    training_cloak_with_grl.py:418,421): a torch.optim.Optimizer whose single param group carries `lr`; the
+    trainer reads it before every step / replay and writes a changed value to the device scalar the HIP optimiser
+    kernels read.  step() runs the trainer's fused update; zero_grad() clears the flat-buffer views."""
+
+    def __init__(self, trainer):
+        self._trainer = trainer
+        super().__init__([trainer.flat.flat], {"lr": trainer.lr})
+
+    def step(self, closure=None):
+        self._trainer.optimizer_step()
+
+    def zero_grad(self, set_to_none=True):
+        self._trainer.flat.zero_grad()
+
+
+class _TrainerBase:
+    def _init_optim(self, optimizer, lr, defaults, momentum, weight_decay, betas, eps, process_group, seed):
         self.kind = optimizer
-        if optimizer == "sgd":       # :417  SGD(lr=0.001, momentum=0.9, weight_decay=1e-4)
-            self.lr = 1e-3 if lr is None else lr
-        elif optimizer == "adam":    # :420  Adam(lr=0.0005, weight_decay=1e-4, betas=(0.9, 0.98), eps=1e-9)
-            self.lr = 5e-4 if lr is None else lr
-        else:
+        if optimizer not in defaults:
             raise ValueError(f"unknown optimizer {optimizer}")
         self.momentum, self.weight_decay, self.betas, self.eps = momentum, weight_decay, betas, eps
-        self.gender_lambda, self.scale_lamda, self.suppression = gender_lambda, scale_lamda, suppression
+        dev = self.flat.flat.device
+        self._lr = float(defaults[optimizer] if lr is None else lr)
+        self.lr_dev = torch.empty((), dtype=torch.float32, device=dev)
+        ops.fill(self.lr_dev, self._lr)
+        self.step_dev = torch.zeros((), dtype=torch.int64, device=dev)   # Adam's t, incremented on the device
         self.steps = 0
+        self._state = None
         self.pg = process_group
         self.world = 1
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
+        self.optimizer = SeptOptimizer(self)
+        self._seed_rng(seed)
+
+    # ---- learning rate: a host attribute mirrored in a device scalar (graph replays read the scalar) ----
+    @property
+    def lr(self):
+        return self._lr
+
+    @lr.setter
+    def lr(self, value):
+        value = float(value)
+        if value != self._lr:
+            self._lr = value
+            ops.fill(self.lr_dev, value)
+        if self.optimizer.param_groups[0]["lr"] != value:
+            self.optimizer.param_groups[0]["lr"] = value
+
+    def _sync_lr(self):
+        """pick up a rate a scheduler wrote into the optimizer handle"""
+        v = self.optimizer.param_groups[0]["lr"]
+        if v != self._lr:
+            self.lr = v
+
+    def _seed_rng(self, seed):
+        """Pin the Philox streams of this device.  The cloak epsilon must be the SAME tensor on every rank (one
+        draw per step for the whole global batch): rank 0's base seed is broadcast and adopted, so
+        the common `manual_seed(base + rank)` idiom cannot silently give each shard its own epsilon."""
+        dev = self.flat.flat.device
+        base = int(torch.initial_seed() if seed is None else seed)
+        if self.world > 1:
+            backend = torch.distributed.get_backend(self.pg)
+            t = torch.tensor([base], dtype=torch.int64, device=dev if "nccl" in str(backend) else "cpu")
+            torch.distributed.broadcast(t, src=torch.distributed.get_global_rank(self.pg, 0) if self.pg is not None else 0,
+                                        group=self.pg)
+            base = int(t.item())
+        self.seed = base
+        if seed is not None or self.world > 1:
+            ops.rng(dev, "eps", seed=base)
+            ops.rng(dev, "dropout", seed=base)     # mixes the rank in: shards draw different masks
+
+    def broadcast_buffers(self, src=0):
+        """BatchNorm running statistics follow each rank's own shard when sync_bn is off; before a checkpoint or an
+        evaluation pass that should agree across ranks, adopt rank `src`'s."""
+        if self.world == 1:
+            return
+        for b in self.model.buffers():
+            if b.is_floating_point() or b.dtype == torch.int64:
+                torch.distributed.broadcast(b, src=src, group=self.pg)
+
+    def _ensure_state(self):
+        if self._state is None:
+            w = self.flat.flat[:self.flat.n_active]
+            self._state = (torch.zeros_like(w), torch.zeros_like(w) if self.kind == "adam" else None)
+
+    def optimizer_step(self):
+        """One update of the parameters that received a gradient (the active prefix of the flat buffer); state is
+        created at the first call, when that set is known.  Learning rate and step count live on the device, so
+        the same launches can be part of a captured graph."""
+        f = self.flat
+        w, g = f.flat[:f.n_active], f.grad[:f.n_active]
+        gscale = 1.0 / self.world
+        self._ensure_state()
+        self.steps += 1
+        ops.counter_add(self.step_dev, 1)
+        if self.kind == "sgd":
+            ops.sgd_step_dev(w, g, self._state[0], self.lr_dev, self.momentum, self.weight_decay, gscale)
+        else:
+            ops.adam_step_dev(w, g, self._state[0], self._state[1], self.lr_dev, self.betas[0], self.betas[1],
+                              self.eps, self.weight_decay, self.step_dev, gscale)
+        SF.invalidate_weight_cache()  # parameters changed through raw pointers
+
+    def _allreduce_grads(self):
+        """The one exchange of a data-parallel step: sum of the active prefix of the flat gradient buffer over the
+        ranks (the optimiser divides by the world size).  ONE message: 943 238 floats (3.8 MB) at 80 mels, 1 257 350
+        (5.0 MB) at 128 -- tens of microseconds over xGMI against a step of milliseconds.  It is not split into
+        buckets overlapped with the backward pass: the backward pass is one HIP-graph launch here, so an overlap would
+        need the collective INSIDE the captured graph, which this build does not rely on."""
+        f = self.flat
+        torch.distributed.all_reduce(f.grad[:f.n_active], group=self.pg)
+
+    def _capture(self, body):
+        """Record `body()` (features / forward / loss / backward) plus gradient placement -- and, on a single rank,
+        the optimiser update -- into a HIP graph; returns replay()."""
+        if self.steps < 1:
+            raise RuntimeError("capture() needs at least one eager warm-up step (first-use setup, active-set discovery)")
+        self.model.train()
+        self.flat.zero_grad()
+        self._sync_lr()
+        self._ensure_state()
+        graph = torch.cuda.CUDAGraph()
+        in_graph_update = self.world == 1
+        # the derived operands of the TRAINABLE weights (bf16 conv operands, packed GRU matrices) must be rebuilt
+        # INSIDE the graph on every replay: drop whatever an earlier eager forward left in the cache so the capture
+        # misses, and drop the capture's (graph-private, never executed) entries afterwards so eager code rebuilds.
+        SF.invalidate_weight_cache()
+        # thread_local: other threads (e.g. the RCCL watchdog of a process group polling its events) may keep
+        # calling the runtime while this thread captures
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"), SF.capture_origin():
+            out = body()
+            self.flat.gather_grads()
+            if in_graph_update:
+                self.optimizer_step()
+        if in_graph_update:
+            self.steps -= 1            # the capture enqueued nothing
+        SF.invalidate_weight_cache()
+
+        def replay():
+            self._sync_lr()
+            graph.replay()
+            if in_graph_update:
+                self.steps += 1
+                SF.invalidate_weight_cache()
+            else:
+                self._allreduce_grads()
+                self.optimizer_step()
+            return out
+
+        replay.graph = graph
+        return replay
+
+
+class GrlTrainer(_TrainerBase):
+    def __init__(self, cloak_model, optimizer="sgd", lr=None, momentum=0.9, weight_decay=1e-4, betas=(0.9, 0.98),
+                 eps=1e-9, gender_lambda=0.1, scale_lamda=0.0, suppression=False, process_group=None, sync_bn=False,
+                 seed=None):
+        self.model = cloak_model
+        self.sync_bn = sync_bn   # BatchNorm statistics of the GLOBAL batch (extra tiny all-reduces); default: per rank
+        self.flat = FlatParams(cloak_model.parameters())  # filter(requires_grad), as :417/:420
+        # :417  SGD(lr=0.001, momentum=0.9, weight_decay=1e-4);  :420  Adam(lr=0.0005, weight_decay=1e-4,
+        # betas=(0.9, 0.98), eps=1e-9)
+        self._init_optim(optimizer, lr, {"sgd": 1e-3, "adam": 5e-4}, momentum, weight_decay, betas, eps, process_group,
+                         seed)
+        self.gender_lambda, self.scale_lamda, self.suppression = gender_lambda, scale_lamda, suppression
 
     def loss(self, preds, preds_grl, labels_emo, labels_gen, weights, training=True):
         noise = self.model.intermed
@@ -109,23 +271,14 @@ class GrlTrainer:
         return SF.GrlStepLossFn.apply(preds, preds_grl, labels_emo, labels_gen, w, self.gender_lambda,
                                       self.scale_lamda, rhos, float(noise.min_scale), float(noise.max_scale))
 
-    def optimizer_step(self):
-        """One update of the parameters that received a gradient (the active prefix of the flat
-        buffer); state is created at the first call, when that set is known."""
-        f = self.flat
-        w, g = f.flat[:f.n_active], f.grad[:f.n_active]
-        gscale = 1.0 / self.world
-        self.steps += 1
-        if self.kind == "sgd":
-            if self.steps == 1:
-                self.buf = torch.zeros_like(w)
-            ops.sgd_step(w, g, self.buf, self.lr, self.momentum, self.weight_decay, self.steps == 1, gscale)
-        else:
-            if self.steps == 1:
-                self.m, self.v = torch.zeros_like(w), torch.zeros_like(w)
-            ops.adam_step(w, g, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps,
-                          self.weight_decay, self.steps, gscale)
-        SF.invalidate_weight_cache()  # parameters changed through raw pointers
+    def _forward_backward(self, features, labels_emo, labels_gen, weights, mask=None, pooling="mean",
+                          global_feature=None):
+        _advance_rng(features.device)
+        SF.set_sync_bn(self.sync_bn and self.world > 1, self.pg)
+        preds, preds_grl, _ = self.model(features, global_feature=global_feature, mask=mask, grl=False, pooling=pooling)
+        loss = self.loss(preds, preds_grl, labels_emo, labels_gen, weights, training=True)
+        SF.backward(loss)
+        return loss.detach(), preds.detach(), preds_grl.detach()
 
     def train_step(self, features, labels_emo, labels_gen, weights=None, mask=None, pooling="mean",
                    global_feature=None):
@@ -133,18 +286,22 @@ class GrlTrainer:
         (loss, preds, preds_grl); loss is a 0-dim device tensor (no host sync here)."""
         self.model.train()
         self.flat.zero_grad()
-        _advance_rng(features.device)
-        SF.set_sync_bn(self.sync_bn and self.world > 1, self.pg)
-        preds, preds_grl, _ = self.model(features, global_feature=global_feature, mask=mask, grl=False, pooling=pooling)
-        loss = self.loss(preds, preds_grl, labels_emo, labels_gen, weights, training=True)
-        SF.backward(loss)
+        self._sync_lr()
+        out = self._forward_backward(features, labels_emo, labels_gen, weights, mask, pooling, global_feature)
         self.flat.gather_grads()
         if self.world > 1:
             # the loss is a mean over the local shard (:150-151), so averaging equal shards gives
             # the global-batch gradient; the scale term is batch independent and survives averaging
-            torch.distributed.all_reduce(self.flat.grad[:self.flat.n_active], group=self.pg)
+            self._allreduce_grads()
         self.optimizer_step()
-        return loss.detach(), preds.detach(), preds_grl.detach()
+        return out
+
+    def capture(self, features, labels_emo, labels_gen, weights=None, mask=None, pooling="mean"):
+        """Record ONE step over the given STATIC input tensors into a HIP graph; returns replay().  On a single
+        rank the optimiser (SGD or Adam: rate and step count are device scalars) is part of the graph; with a
+        process group the graph ends at the gradients, and replay() then runs the all-reduce and the update.
+        Refill the inputs with copy_() between replays; call after at least one eager step."""
+        return self._capture(lambda: self._forward_backward(features, labels_emo, labels_gen, weights, mask, pooling))
 
     @torch.no_grad()
     def eval_step(self, features, labels_emo, labels_gen, mask=None, pooling="mean", global_feature=None):
@@ -153,71 +310,43 @@ class GrlTrainer:
         return self.loss(preds, preds_grl, labels_emo, labels_gen, None, training=False), preds, preds_grl
 
 
-class BaselineTrainer:
+class BaselineTrainer(_TrainerBase):
     """The baseline / adversary training step (training/training_adversary_baselines.py:165-185,
     :424-429): a single classifier (two_d_cnn_lstm, deep_two_d_cnn_lstm or one_d_cnn_lstm), loss
-    sum_i w_i CE_i / B, SGD(lr 1e-4, m 0.9, wd 1e-4) or Adam(lr 5e-5, wd 1e-4, betas (0.9, 0.98),
-    eps 1e-9), one gradient all-reduce per step when sharded."""
+    sum_i w_i CE_i / B, SGD(lr 1e-4, m 0.9, wd 1e-4) + StepLR(5) or Adam(lr 5e-5, wd 1e-4, betas (0.9, 0.98),
+    eps 1e-9) + ReduceLROnPlateau, one gradient all-reduce per step when sharded."""
 
     def __init__(self, model, optimizer="sgd", lr=None, momentum=0.9, weight_decay=1e-4, betas=(0.9, 0.98),
-                 eps=1e-9, process_group=None):
+                 eps=1e-9, process_group=None, seed=None):
         self.model = model
         self.flat = FlatParams(model.parameters())
-        self.kind = optimizer
-        if optimizer == "sgd":
-            self.lr = 1e-4 if lr is None else lr
-        elif optimizer == "adam":
-            self.lr = 5e-5 if lr is None else lr
-        else:
-            raise ValueError(f"unknown optimizer {optimizer}")
-        self.momentum, self.weight_decay, self.betas, self.eps = momentum, weight_decay, betas, eps
-        self.steps, self.pg, self.world = 0, process_group, 1
-        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
-            self.world = torch.distributed.get_world_size(process_group)
+        self._init_optim(optimizer, lr, {"sgd": 1e-4, "adam": 5e-5}, momentum, weight_decay, betas, eps, process_group,
+                         seed)
 
-    optimizer_step = GrlTrainer.optimizer_step
-
-    def train_step(self, features, labels, weights=None):
-        self.model.train()
-        self.flat.zero_grad()
+    def _forward_backward(self, features, labels, weights):
         _advance_rng(features.device)
         preds = self.model(features)
         loss = SF.GrlStepLossFn.apply(preds, None, labels, None, weights, 0.0, 0.0, None, 0.0, 0.0)
         SF.backward(loss)
-        self.flat.gather_grads()
-        if self.world > 1:
-            torch.distributed.all_reduce(self.flat.grad[:self.flat.n_active], group=self.pg)
-        self.optimizer_step()
         return loss.detach(), preds.detach()
 
-    def capture(self, features, labels, weights=None):
-        """Record forward + loss + backward + gradient packing of ONE step over the given STATIC input
-        tensors into a HIP graph; returns `replay()` (graph launch, then the all-reduce and the optimiser
-        kernel eagerly).  Call after at least one eager step; refill the inputs with copy_() between
-        replays.  SGD only, as FusedPipeline.capture.  At the reference's 32 windows per step the eager
-        step is bound by its ~100 launches; the replay is not."""
-        if self.kind != "sgd" or self.steps < 1:
-            raise RuntimeError("capture() needs optimizer='sgd' and at least one eager warm-up step")
+    def train_step(self, features, labels, weights=None):
         self.model.train()
         self.flat.zero_grad()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            _advance_rng(features.device)
-            preds = self.model(features)
-            loss = SF.GrlStepLossFn.apply(preds, None, labels, None, weights, 0.0, 0.0, None, 0.0, 0.0)
-            SF.backward(loss)
-            self.flat.gather_grads()
-            out = (loss.detach(), preds.detach())
+        self._sync_lr()
+        out = self._forward_backward(features, labels, weights)
+        self.flat.gather_grads()
+        if self.world > 1:
+            self._allreduce_grads()
+        self.optimizer_step()
+        return out
 
-        def replay():
-            graph.replay()
-            if self.world > 1:
-                torch.distributed.all_reduce(self.flat.grad[:self.flat.n_active], group=self.pg)
-            self.optimizer_step()
-            return out
-
-        replay.graph = graph
-        return replay
+    def capture(self, features, labels, weights=None):
+        """Record forward + loss + backward (+ the optimiser on a single rank) of ONE step over the given STATIC
+        input tensors into a HIP graph; returns `replay()`.  Call after at least one eager step; refill the inputs
+        with copy_() between replays.  At the reference's 32 windows per step the eager step is bound by its ~100
+        launches; the replay is not."""
+        return self._capture(lambda: self._forward_backward(features, labels, weights))
 
 
 class FusedPipeline:
@@ -243,37 +372,16 @@ class FusedPipeline:
                                        weights_w)
 
     def capture(self, wav, labels_emo_w, labels_gen_w, weights_w=None):
-        """Record features + forward + loss + backward + gradient packing of ONE step into a HIP
-        graph (torch.cuda.CUDAGraph) over the given STATIC input tensors; returns `replay()`,
-        which launches the graph, then the gradient all-reduce and the optimiser kernel eagerly
-        (the collective and the step counter stay outside the graph).  Call after a few eager
-        warm-up steps (first-use setup such as LDS limits and workspaces happens there); refill
-        the static tensors with copy_() between replays.  SGD only (Adam's bias correction is a
-        host-side function of the step count)."""
+        """Record features + forward + loss + backward (+ the optimiser update on a single rank) of ONE step into a
+        HIP graph (torch.cuda.CUDAGraph) over the given STATIC input tensors; returns `replay()`.  With a process
+        group the gradient all-reduce and the optimiser kernel follow the graph launch (the collective stays outside
+        the graph).  Call after a few eager warm-up steps (first-use setup such as LDS limits and workspaces happens
+        there); refill the static tensors with copy_() between replays.  SGD and Adam alike."""
         tr = self.trainer
-        if tr.kind != "sgd" or tr.steps < 1:
-            raise RuntimeError("capture() needs optimizer='sgd' and at least one eager warm-up step")
-        tr.model.train()
-        tr.flat.zero_grad()
-        graph = torch.cuda.CUDAGraph()
-        # thread_local: other threads (e.g. the RCCL watchdog of a process group polling its events) may keep
-        # calling the runtime while this thread captures
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            _advance_rng(wav.device)
+
+        def body():
             x = self.features(wav)
-            preds, preds_grl, _ = tr.model(x.view(x.shape[0], 1, self.win, self.n_mels), mask=None, grl=False,
-                                           pooling="mean")
-            loss = tr.loss(preds, preds_grl, labels_emo_w, labels_gen_w, weights_w, training=True)
-            SF.backward(loss)
-            tr.flat.gather_grads()
-            out = (loss.detach(), preds.detach(), preds_grl.detach())
+            return tr._forward_backward(x.view(x.shape[0], 1, self.win, self.n_mels), labels_emo_w, labels_gen_w,
+                                        weights_w)
 
-        def replay():
-            graph.replay()
-            if tr.world > 1:
-                torch.distributed.all_reduce(tr.flat.grad[:tr.flat.n_active], group=tr.pg)
-            tr.optimizer_step()
-            return out
-
-        replay.graph = graph
-        return replay
+        return tr._capture(body)

@@ -81,3 +81,45 @@ def test_two_ranks_with_sync_bn_equal_global_batch_step():
         worst = max(worst, rel)
         assert rel < 3e-2, (n, rel)     # the same update up to bf16 / summation-order noise
     assert worst > 0.0                   # and the two code paths really are different computations
+
+
+def _worker_captured(rank, world, port, ret):
+    """each rank: eager x3 on one model, eager x1 + capture + replay x2 on a twin; both with the gradient
+    all-reduce (gloo) between the backward pass and the optimiser kernel"""
+    import torch.distributed as dist
+    from sept_amd.trainer import GrlTrainer
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    per = B // world
+    sl = slice(rank * per, (rank + 1) * per)
+    x = closed_form_input(B, W, F)[sl].cuda()
+    le, lg, w = (t[sl].cuda() for t in closed_form_labels(B))
+    out = []
+    for use_graph in (False, True):
+        tr = GrlTrainer(_build(), optimizer="sgd", lr=0.05, gender_lambda=0.1, scale_lamda=0.05, seed=1234 + rank)
+        assert tr.world == 2 and tr.seed == 1234          # rank 0's seed was adopted: ONE epsilon for the global batch
+        tr.train_step(x, le, lg, w)
+        step = tr.capture(x, le, lg, w) if use_graph else (lambda: tr.train_step(x, le, lg, w))
+        step(), step()
+        torch.cuda.synchronize()
+        out.append(tr.flat.flat.clone().cpu())
+    ret[rank] = (bool(torch.equal(out[0], out[1])), out[1])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_captured_step_equals_eager_and_ranks_stay_in_step():
+    """The data-parallel form of the captured step (graph up to the gradients, then all-reduce + optimiser): bit-equal
+    to the eager data-parallel step on each rank, and both ranks hold identical parameters afterwards."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_captured, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert ret[0][0] and ret[1][0]
+    assert torch.equal(ret[0][1], ret[1][1])

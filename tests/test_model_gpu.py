@@ -4,8 +4,15 @@ oracle with the same closed-form weights.
 
 Tolerances: the conv stack computes on bf16 MFMA (fp32 accumulate) and keeps bf16
 activations, as BASELINE.json config 3 prescribes; the north-star criterion is "identical
-emotion/gender argmax on fixed seeds".  Logits are additionally held to 3e-2 absolute
-(logit scale ~0.1-1), gradients to 5 % of their norm (cosine > 0.995)."""
+emotion/gender argmax on fixed seeds".  Two references, two bounds:
+  * the REFERENCE goldens / the fp32 oracle: logits within LOGIT_RTOL (1 %) of the largest golden
+    |logit| (the closed-form weights give logits of scale 1-4 that depend on the input, see
+    tests/closed_form.py), identical arg-max on every row whose reference margin exceeds 0.1 -- and at
+    least 3/4 of the rows of every golden must be such rows, so the check cannot pass vacuously;
+  * the oracle with the HIP path's bf16 storage points simulated (oracle.model_oracle.simulate_bf16):
+    both sides then take the same max-pool decisions, so logits are held to SIM_ATOL = 5e-3 absolute,
+    arg-max on all decided rows, and EVERY gradient -- also those behind the conv stack -- to
+    cosine > 0.995 and 5 % of its norm."""
 import os
 
 import numpy as np
@@ -19,7 +26,9 @@ from tests.closed_form import (closed_form_eps, closed_form_input, closed_form_l
 
 pytestmark = pytest.mark.gpu
 B, W = 8, 200
-LOGIT_ATOL = 3e-2
+LOGIT_RTOL = 1e-2     # x max(1, largest |golden logit|): bf16 conv stack against an fp32 reference
+SIM_ATOL = 5e-3       # absolute, against the bf16-storage simulation of the oracle
+MARGIN = 0.1          # rows whose reference top-2 margin exceeds this must agree in arg-max
 
 
 @pytest.fixture(scope="module")
@@ -60,13 +69,21 @@ def zero_dropout(mod):
             m.dropout = 0.0
 
 
-def close_logits(got, want):
+def close_logits(got, want, argmax=None, atol=None, min_decided=0.75):
+    """|got - want| bound + identical arg-max on the decided rows; `argmax` = the reference's recorded
+    decision vector (golden), checked literally.  Returns the fraction of decided rows."""
     got, want = got.detach().float().cpu().numpy(), np.asarray(want)
     assert got.shape == want.shape
-    assert np.abs(got - want).max() < LOGIT_ATOL, np.abs(got - want).max()
+    tol = atol if atol is not None else LOGIT_RTOL * max(1.0, float(np.abs(want).max()))
+    err = float(np.abs(got - want).max())
+    assert err < tol, (err, tol)
     margin = np.sort(want, axis=1)[:, -1] - np.sort(want, axis=1)[:, -2]
-    decided = margin > 2 * LOGIT_ATOL          # near-ties cannot be decided at bf16 precision
-    assert (got.argmax(1) == want.argmax(1))[decided].all()
+    decided = margin > MARGIN
+    assert decided.mean() >= min_decided, ("too few decided rows for a meaningful arg-max check", margin)
+    assert (got.argmax(1) == want.argmax(1))[decided].all(), (got.argmax(1), want.argmax(1), margin)
+    if argmax is not None:
+        assert np.array_equal(np.asarray(argmax), want.argmax(1))
+        assert np.array_equal(got.argmax(1)[decided], np.asarray(argmax)[decided])
     return decided.mean()
 
 
@@ -77,7 +94,20 @@ def test_baseline_eval_vs_reference(F, G):
         m = mk(F, pred).eval()
         with torch.no_grad():
             y = m(x)
-        close_logits(y, G[f"f{F}_{key}_eval_logits"])
+        close_logits(y, G[f"f{F}_{key}_eval_logits"], argmax=G[f"f{F}_{key}_eval_logits_argmax"])
+
+
+def test_goldens_detect_a_broken_trunk(G):
+    """The goldens have teeth: a conv stack that returns plausible but wrong activations (conv2 zeroed, so
+    only its bias reaches BatchNorm) must FAIL the same check the real model passes."""
+    F = 80
+    x = closed_form_input(B, W, F).cuda()
+    m = mk(F, "emotion").eval()
+    with torch.no_grad():
+        close_logits(m(x), G["f80_emo_eval_logits"], argmax=G["f80_emo_eval_logits_argmax"])
+        m.conv[5].weight.zero_()
+        with pytest.raises(AssertionError):
+            close_logits(m(x), G["f80_emo_eval_logits"])
 
 
 @pytest.mark.parametrize("F", [80, 128])
@@ -86,11 +116,11 @@ def test_grl_eval_vs_reference(F, G):
     grl = build_grl(F).eval()
     with torch.no_grad():
         p1, p2, nz = grl(x, mask=None, grl=False, pooling="mean")
-        close_logits(p1, G[f"f{F}_grl_eval_emo"])
-        close_logits(p2, G[f"f{F}_grl_eval_gen"])
+        close_logits(p1, G[f"f{F}_grl_eval_emo"], argmax=G[f"f{F}_grl_eval_emo_argmax"])
+        close_logits(p2, G[f"f{F}_grl_eval_gen"], argmax=G[f"f{F}_grl_eval_gen_argmax"])
         p1, p2, nz = grl(x, mask=mask, grl=False, pooling="mean")
-        close_logits(p1, G[f"f{F}_grl_eval_emo_masked"])
-        close_logits(p2, G[f"f{F}_grl_eval_gen_masked"])
+        close_logits(p1, G[f"f{F}_grl_eval_emo_masked"], argmax=G[f"f{F}_grl_eval_emo_masked_argmax"])
+        close_logits(p2, G[f"f{F}_grl_eval_gen_masked"], argmax=G[f"f{F}_grl_eval_gen_masked_argmax"])
         np.testing.assert_allclose(nz.reshape(-1)[:64].cpu().numpy(), G[f"f{F}_grl_noisy_masked_slice"], rtol=1e-5,
                                    atol=1e-6)
     assert nz.shape == x.shape and not nz.requires_grad
@@ -101,7 +131,7 @@ def _cos(a, b):
     return float((a @ b) / (a.norm() * b.norm() + 1e-30))
 
 
-def _oracle_grl(F, state=None):
+def _oracle_grl(F, state=None, sim=False):
     emo, gen = mk_oracle(F, "emotion"), mk_oracle(F, "gender")
     noise = mo.cloak_noise(torch.zeros(1, W, F), torch.ones(1, W, F), torch.tensor(0.01), torch.tensor(10.0), "cpu")
     noise.load_state_dict(closed_form_state(noise, prefix="noise."))
@@ -110,7 +140,7 @@ def _oracle_grl(F, state=None):
     zero_dropout(ref)
     if state is not None:
         ref.load_state_dict(state)
-    return ref
+    return mo.simulate_bf16(ref, sim)
 
 
 def _grad_report(grl, ref):
@@ -134,16 +164,31 @@ def _is_conv_stack(name):
     return name.startswith("intermed.") or ".conv." in name
 
 
+def _sim_step_check(grl, x, le, lg, wts, state=None, F=80, logits=None, min_decided=0.75):
+    """The HIP step (already run: `logits` = its (p1, p2), gradients in .grad) against the oracle with the HIP
+    path's bf16 storage points simulated: same max-pool decisions on both sides, so logits are held to SIM_ATOL
+    and every gradient -- conv stack, cloak locs / rhos included -- to cosine > 0.995 and 5 % of its norm."""
+    ref = _oracle_grl(F, state, sim=True)
+    q1, q2, _ = ref(x.cpu(), mask=None, grl=False, pooling="mean")
+    mo.grl_step_loss(q1, q2, le, lg, wts, 0.1, 0.05, ref).backward()
+    close_logits(logits[0], q1.detach().numpy(), atol=SIM_ATOL, min_decided=min_decided)
+    close_logits(logits[1], q2.detach().numpy(), atol=SIM_ATOL, min_decided=min_decided)
+    rep = _grad_report(grl, ref)
+    assert any(_is_conv_stack(n) for n in rep) and "intermed.locs" in rep and "intermed.rhos" in rep
+    for name, (c, rel) in rep.items():
+        if _is_conv_stack(name):
+            assert c > 0.995 and rel < 5e-2, (name, c, rel)
+        else:
+            assert c > 0.999 and rel < 0.03, (name, c, rel)
+    return rep
+
+
 @pytest.mark.parametrize("F", [80, 128])
 def test_grl_train_step_vs_reference(F, G):
-    """One train-mode step with dropout off and epsilon injected, closed-form weights/inputs:
-    logits and loss against the REFERENCE goldens; gradients against the reference-pinned CPU
-    oracle.  Everything downstream of the conv stack (GRU, dense, heads, last BatchNorm) must
-    agree tightly.  Gradients inside / behind the bf16 conv stack (anything after a max-pool) are compared
-    loosely here: the closed-form signal is smooth, so max-pool windows are full of near-ties
-    and a bf16-rounded activation picks a different (equally valid) arg-max than fp32 does,
-    which moves gradient mass between neighbouring pixels.  test_grl_train_step_rough_data
-    bounds the same quantities on non-smooth data."""
+    """One train-mode step with dropout off and epsilon injected, closed-form weights/inputs: logits, arg-max and
+    loss against the REFERENCE goldens; every gradient against the reference-pinned CPU oracle with the bf16
+    storage points of the HIP path simulated (see _sim_step_check) -- an indexing error in a data-gradient or
+    BatchNorm-backward kernel cannot hide behind max-pool near-ties any more."""
     from sept_amd import functional as SF
     x = closed_form_input(B, W, F).cuda()
     le, lg, wts = closed_form_labels(B)
@@ -154,17 +199,10 @@ def test_grl_train_step_vs_reference(F, G):
     loss = SF.GrlStepLossFn.apply(p1, p2, le.cuda(), lg.cuda(), wts.cuda(), 0.1, 0.05, grl.intermed.rhos, 0.01, 10.0)
     loss.backward()
     k = f"f{F}_"
-    close_logits(p1, G[k + "train_emo"])
-    close_logits(p2, G[k + "train_gen"])
-    assert loss.item() == pytest.approx(float(G[k + "train_loss"]), abs=2e-2)
-    ref = _oracle_grl(F)
-    q1, q2, _ = ref(x.cpu(), mask=None, grl=False, pooling="mean")
-    mo.grl_step_loss(q1, q2, le, lg, wts, 0.1, 0.05, ref).backward()
-    for name, (c, rel) in _grad_report(grl, ref).items():
-        if _is_conv_stack(name):
-            assert c > 0.8, (name, c, rel)
-        else:
-            assert c > 0.999 and rel < 0.03, (name, c, rel)
+    close_logits(p1, G[k + "train_emo"], argmax=G[k + "train_emo_argmax"])
+    close_logits(p2, G[k + "train_gen"], argmax=G[k + "train_gen_argmax"])
+    assert loss.item() == pytest.approx(float(G[k + "train_loss"]), abs=1e-2)
+    _sim_step_check(grl, x, le, lg, wts, None, F, (p1, p2))
     assert all(p.grad is None for p in grl.original_model.parameters())
     # BatchNorm running statistics were updated for BOTH networks (F8)
     np.testing.assert_allclose(grl.original_model.conv[1].running_mean.cpu().numpy(), G[k + "emo_bn1_running_mean"],
@@ -175,7 +213,7 @@ def test_grl_train_step_vs_reference(F, G):
 
 
 def _randomise(grl, seed):
-    """Replace the (smooth, ill-conditioned) closed-form weights by seeded random ones of the same scale."""
+    """Replace the closed-form weights by seeded random ones of the same scale."""
     torch.manual_seed(seed)
     sd = {}
     for key, v in grl.state_dict().items():
@@ -187,9 +225,8 @@ def _randomise(grl, seed):
 
 
 def test_grl_train_step_rough_data():
-    """Same step on non-smooth (seeded random) inputs and weights, where arg-max ties are rare:
-    every gradient of the HIP path must point the way the fp32 oracle's does.  The residual is
-    the bf16 activation / gradient rounding of the MFMA conv stack (BASELINE config 3)."""
+    """Same step on seeded random inputs and weights: logits against the fp32 oracle (1 %), then the simulated-bf16
+    oracle for the tight logit / gradient bounds."""
     from sept_amd import functional as SF
     F = 80
     torch.manual_seed(5)
@@ -202,22 +239,20 @@ def test_grl_train_step_rough_data():
     SF.GrlStepLossFn.apply(p1, p2, le.cuda(), lg.cuda(), wts.cuda(), 0.1, 0.05, grl.intermed.rhos, 0.01,
                            10.0).backward()
     ref = _oracle_grl(F, sd)
-    q1, q2, _ = ref(x, mask=None, grl=False, pooling="mean")
-    mo.grl_step_loss(q1, q2, le, lg, wts, 0.1, 0.05, ref).backward()
-    close_logits(p1, q1.detach().numpy())
-    close_logits(p2, q2.detach().numpy())
-    for name, (c, rel) in _grad_report(grl, ref).items():
-        if _is_conv_stack(name):
-            assert c > 0.98 and rel < 0.2, (name, c, rel)
-        else:
-            assert c > 0.999 and rel < 0.03, (name, c, rel)
+    with torch.no_grad():
+        q1, q2, _ = ref(x, mask=None, grl=False, pooling="mean")
+    close_logits(p1, q1.numpy(), min_decided=0.5)
+    close_logits(p2, q2.numpy(), min_decided=0.5)
+    _sim_step_check(grl, x, le, lg, wts, sd, F, (p1, p2), min_decided=0.5)
 
 
 @pytest.mark.parametrize("Bn,F", [(1, 80), (3, 40), (13, 80), (37, 128)])
 def test_grl_train_step_ragged_batches(Bn, F):
     """The last batch of an epoch is ragged (DataLoader without drop_last, training scripts :401-415 of the
     reference's cloak training): batch sizes that are not multiples of any tile, down to a single window,
-    and the feature sizes the reference extracts (40 / 80 / 128).  Seeded random data, oracle comparison."""
+    and the feature sizes the reference extracts (40 / 80 / 128).  Seeded random data; fp32 oracle for the logits,
+    simulated-bf16 oracle for the gradients.  (A batch of ONE window has degenerate BatchNorm statistics in the
+    last block -- 25 x F/8 values per channel -- so its bounds are the looser ones.)"""
     from sept_amd import functional as SF
     torch.manual_seed(11 + Bn)
     x = torch.randn(Bn, 1, W, F)
@@ -229,13 +264,13 @@ def test_grl_train_step_ragged_batches(Bn, F):
     assert p1.shape == (Bn, 4) and p2.shape == (Bn, 2)
     SF.GrlStepLossFn.apply(p1, p2, le.cuda(), lg.cuda(), wts.cuda(), 0.1, 0.05, grl.intermed.rhos, 0.01,
                            10.0).backward()
-    ref = _oracle_grl(F, sd)
+    ref = _oracle_grl(F, sd, sim=True)
     q1, q2, _ = ref(x, mask=None, grl=False, pooling="mean")
     mo.grl_step_loss(q1, q2, le, lg, wts, 0.1, 0.05, ref).backward()
-    close_logits(p1, q1.detach().numpy())
-    close_logits(p2, q2.detach().numpy())
+    close_logits(p1, q1.detach().numpy(), atol=2 * SIM_ATOL, min_decided=0.0)
+    close_logits(p2, q2.detach().numpy(), atol=2 * SIM_ATOL, min_decided=0.0)
     for name, (c, rel) in _grad_report(grl, ref).items():
-        assert c > (0.9 if _is_conv_stack(name) else 0.995), (name, c, rel)
+        assert c > (0.99 if _is_conv_stack(name) else 0.995), (name, c, rel)
 
 
 def test_syn_and_deep_variants():
@@ -296,15 +331,19 @@ def test_sliding_window_inference_matches_reference_loop():
     grl = build_grl(F).eval()
     ref = _oracle_grl(F).eval()
     ref.load_state_dict({k: v.cpu() for k, v in grl.state_dict().items()})
-    pred, probs = sliding_window_predict(grl, feats.cuda(), win_len=200, mask=None, pooling="mean")
-    assert pred.shape == (3,) and probs.shape == (3, 4)
     test_len = int((T - 200) / 50) + 1
     assert test_len == 7
+    # the reference's loop draws a fresh epsilon in every per-window forward: inject one per window on both sides
+    eps_w = torch.randn(3 * test_len, 200, F) * 0.1
+    grl.intermed.eps = eps_w.cuda()
+    pred, probs = sliding_window_predict(grl, feats.cuda(), win_len=200, mask=None, pooling="mean")
+    assert pred.shape == (3,) and probs.shape == (3, 4)
     for b in range(3):
         plist = []
         with torch.no_grad():
             for i in range(test_len):
                 w = feats[b:b + 1, :, i * 50:i * 50 + 200, :]
+                ref.intermed.eps = eps_w[b * test_len + i:b * test_len + i + 1]
                 p1, _, _ = ref(w, mask=None, grl=False, pooling="mean")
                 plist.append(torch.softmax(p1, dim=1)[0].numpy())
         mean_p = np.mean(np.array(plist), axis=0)
@@ -313,6 +352,16 @@ def test_sliding_window_inference_matches_reference_loop():
             assert int(pred[b]) == int(np.argmax(mean_p))
     gp, gprobs = sliding_window_predict(grl, feats.cuda(), which="gender")
     assert gprobs.shape == (3, 2) and torch.allclose(gprobs.sum(1), torch.ones(3, device="cuda"), atol=1e-5)
+    # without an injected epsilon every window gets its own Philox draw: the noisy windows of one call differ
+    grl.intermed.eps = None
+    from sept_amd.inference import _per_window_epsilon
+    with torch.no_grad(), _per_window_epsilon(grl):
+        z = torch.zeros(4, 1, 200, F, device="cuda")
+        nz = grl.intermed(z)
+    assert not torch.equal(nz[0], nz[1]) and 0.005 < float((nz[0] - nz[1]).std()) < 0.1
+    with torch.no_grad():
+        nz1 = grl.intermed(z)                      # training-style call: ONE epsilon broadcast over the batch
+    assert torch.equal(nz1[0], nz1[1])
 
 
 def test_graph_replay_equals_eager_step():
@@ -479,11 +528,11 @@ def test_attention_global_feature_multitask_vs_reference(GA):
     F = 80
     x, gf = closed_form_input(B, W, F).cuda(), closed_form_gfeat(B).cuda()
     with torch.no_grad():
-        close_logits(_mk_opt("emotion", "self_att", 1, "attg.").eval()(x, gf), GA["att_gf_eval_logits"])
-        close_logits(_mk_opt("gender", "self_att", 0, "att.").eval()(x), GA["att_eval_logits"])
+        close_logits(_mk_opt("emotion", "self_att", 1, "attg.").eval()(x, gf), GA["att_gf_eval_logits"], argmax=GA["att_gf_eval_logits_argmax"])
+        close_logits(_mk_opt("gender", "self_att", 0, "att.").eval()(x), GA["att_eval_logits"], argmax=GA["att_eval_logits_argmax"])
         p1, p2 = _mk_opt("multitask", None, 1, "multi.").eval()(x, gf)
-        close_logits(p1, GA["multi_gf_eval_emo"])
-        close_logits(p2, GA["multi_gf_eval_gen"])
+        close_logits(p1, GA["multi_gf_eval_emo"], argmax=GA["multi_gf_eval_emo_argmax"])
+        close_logits(p2, GA["multi_gf_eval_gen"], argmax=GA["multi_gf_eval_gen_argmax"])
     with pytest.raises(Exception):        # dense1 was built for 128 + 88 inputs
         _mk_opt("emotion", None, 1, "attg.").eval()(x)
     # the class-default constructor (hidden 128, global_feature=1) runs on the HIP path too
@@ -491,7 +540,7 @@ def test_attention_global_feature_multitask_vs_reference(GA):
     m = bm.two_d_cnn_lstm(1, F, 64)
     m.load_state_dict(closed_form_state(m, prefix="defaults."))
     with torch.no_grad():
-        close_logits(m.cuda().eval()(x, gf), GA["defaults_eval_logits"])
+        close_logits(m.cuda().eval()(x, gf), GA["defaults_eval_logits"], argmax=GA["defaults_eval_logits_argmax"])
 
 
 def test_hidden_128_backward_matches_oracle():
@@ -517,8 +566,8 @@ def test_hidden_128_backward_matches_oracle():
 
 def test_grl_step_with_attention_vs_reference(GA):
     """GRL wrapper with attention in both branches (cloak_models.py:178-186, 215-223): train-mode
-    logits / loss against the REFERENCE goldens, gradients against the reference-pinned oracle
-    (attention, dense and GRU parameters tightly; conv stack as in test_grl_train_step_vs_reference)."""
+    logits / arg-max / loss against the REFERENCE goldens, every gradient against the reference-pinned oracle
+    with the bf16 storage points simulated (as test_grl_train_step_vs_reference)."""
     from model import cloak_models as cm
     from sept_amd import functional as SF
     F = 80
@@ -537,20 +586,22 @@ def test_grl_step_with_attention_vs_reference(GA):
         zero_dropout(m)
         return m
 
-    grl, ref = build(False), build(True)
+    grl, ref = build(False), mo.simulate_bf16(build(True))
     p1, p2, _ = grl(x.cuda(), mask=None, grl=False, pooling="mean")
     loss = SF.GrlStepLossFn.apply(p1, p2, le.cuda(), lg.cuda(), wts.cuda(), 0.1, 0.05, grl.intermed.rhos, 0.01, 10.0)
     loss.backward()
-    close_logits(p1, GA["grl_att_train_emo"])
-    close_logits(p2, GA["grl_att_train_gen"])
-    assert loss.item() == pytest.approx(float(GA["grl_att_train_loss"]), abs=2e-2)
+    close_logits(p1, GA["grl_att_train_emo"], argmax=GA["grl_att_train_emo_argmax"])
+    close_logits(p2, GA["grl_att_train_gen"], argmax=GA["grl_att_train_gen_argmax"])
+    assert loss.item() == pytest.approx(float(GA["grl_att_train_loss"]), abs=1e-2)
     q1, q2, _ = ref(x, mask=None, grl=False, pooling="mean")
     mo.grl_step_loss(q1, q2, le, lg, wts, 0.1, 0.05, ref).backward()
+    close_logits(p1, q1.detach().numpy(), atol=SIM_ATOL)
+    close_logits(p2, q2.detach().numpy(), atol=SIM_ATOL)
     rep = _grad_report(grl, ref)
     assert "gender_model.att_linear1.weight" in rep and "gender_model.att_linear2.weight" in rep
     for name, (c, rel) in rep.items():
         if _is_conv_stack(name):
-            assert c > 0.8, (name, c, rel)
+            assert c > 0.995 and rel < 5e-2, (name, c, rel)
         else:
             assert c > 0.999 and rel < 0.03, (name, c, rel)
 
@@ -592,13 +643,16 @@ def test_cloak_evaluation_predict_and_suppression_mask():
     thr = np.nanpercentile(scales.detach().cpu().numpy(), 30)
     want_mask = (scales.detach().cpu().numpy() <= thr).astype(np.float32)
     assert np.array_equal(mask.cpu().numpy(), want_mask) and 0.25 < 1 - want_mask.mean() < 0.75 or want_mask.mean() in (0.0, 1.0)
-    (pred, probs), (apred, aprobs) = cloak_evaluation_predict(grl, base, adv, feats.cuda(), mask=mask)
     nwin = int((T - 200) / 50) + 1
+    eps_w = torch.randn(2 * nwin, 200, F) * 0.1      # one epsilon per window, as the reference's loop draws them
+    grl.intermed.eps = eps_w.cuda()
+    (pred, probs), (apred, aprobs) = cloak_evaluation_predict(grl, base, adv, feats.cuda(), mask=mask)
     for b in range(2):
         pl, al = [], []
         with torch.no_grad():
             for i in range(nwin):
                 w = feats[b:b + 1, :, i * 50:i * 50 + 200, :]
+                ref.intermed.eps = eps_w[b * nwin + i:b * nwin + i + 1]
                 _, _, noisy = ref(w, mask=mask.cpu(), grl=False, pooling="mean")
                 pl.append(torch.softmax(base_o(noisy), 1)[0].numpy())
                 al.append(torch.softmax(adv_o(noisy), 1)[0].numpy())
@@ -621,35 +675,27 @@ def test_deep_tmp_lstm_model_vs_reference(GA):
     m.load_state_dict(sd), ref.load_state_dict(sd)
     m = m.cuda()
     with torch.no_grad():
-        close_logits(m.eval()(x.cuda()), GA["tmp_lstm_eval_logits"])
+        close_logits(m.eval()(x.cuda()), GA["tmp_lstm_eval_logits"], argmax=GA["tmp_lstm_eval_logits_argmax"])
     m.train(), ref.train()
     zero_dropout(m), zero_dropout(ref)
     loss = torch.nn.functional.cross_entropy(m(x.cuda()), le.view(-1).cuda())
     assert float(loss) == pytest.approx(float(GA["tmp_lstm_train_loss"]), abs=2e-2)
-    # gradients: default torch initialisation and non-smooth data.  (The closed-form sine weights make this
-    # 4-block network ill-conditioned -- with them even the GRU twin agrees with fp32 only to cos 0.8-0.95 -- and
-    # smooth inputs are full of max-pool near-ties, see test_grl_train_step_rough_data.)  The recurrence itself
-    # is held tightly by test_lstm_layer_forward_backward.
-    torch.manual_seed(3)
-    ref = mo.deep_two_d_cnn_lstm_tmp(1, F, 64, **kw).train()
-    m = bm.deep_two_d_cnn_lstm_tmp(1, F, 64, **kw)
-    m.load_state_dict(ref.state_dict())
-    m = m.cuda().train()
-    zero_dropout(m), zero_dropout(ref)
-    torch.manual_seed(17)
-    xr = torch.randn(B, 1, W, F)
-    torch.nn.functional.cross_entropy(m(xr.cuda()), le.view(-1).cuda()).backward()
-    torch.nn.functional.cross_entropy(ref(xr), le.view(-1)).backward()
+    # gradients: closed-form weights, closed-form data, against the oracle with the bf16 storage points simulated
+    # (4 bf16 conv blocks upstream of a 25-step recurrence: with an fp32 twin the max-pool decisions differ and the
+    # smallest cosine moved between 0.96 and 0.98 with the data seed)
+    mo.simulate_bf16(ref)
+    m.zero_grad()
+    torch.nn.functional.cross_entropy(m(x.cuda()), le.view(-1).cuda()).backward()
+    torch.nn.functional.cross_entropy(ref(x), le.view(-1)).backward()
     got, want = dict(m.named_parameters()), dict(ref.named_parameters())
+    checked = 0
     for name, w in want.items():
         if w.grad is None or name.endswith(("conv.0.bias", "conv.5.bias", "conv.10.bias", "conv.15.bias")):
             continue   # conv biases in front of a train-mode BatchNorm: zero gradient up to rounding
-        c = _cos(got[name].grad.cpu(), w.grad)
-        # 4 bf16 conv blocks upstream of a 25-step recurrence: which max-pool element wins flips with the last
-        # bit of a BatchNorm mean, so the smallest cosine moves with the data seed and with the summation order of
-        # the statistics -- seeds 17/18/19: 0.980 / 0.968 / 0.983 with the separate statistics pass, 0.960 /
-        # 0.967 / 0.983 with the conv-epilogue statistics; every other parameter 0.97-0.998
-        assert c > 0.95, (name, c)
+        g = got[name].grad.cpu()
+        assert _cos(g, w.grad) > 0.995 and float((g - w.grad).norm() / w.grad.norm()) < 5e-2, name
+        checked += 1
+    assert checked >= 30
 
 
 def test_reference_style_training_loop_runs_unchanged():
@@ -715,3 +761,118 @@ def test_baseline_trainer_graph_replay_equals_eager():
         torch.cuda.synchronize()
         res.append(tr.flat.flat.clone())
     assert torch.equal(res[0], res[1])
+
+
+def test_capture_after_eval_forward_replays_fresh_operands():
+    """train_step -> eval_step -> capture -> 2 replays must equal 3 eager steps bit for bit.  The eval
+    forward refreshes the derived-operand cache (bf16 conv operands, packed GRU matrices) right before the capture;
+    without the invalidation in capture() the graph would record NO prep kernels and every replay would run against
+    operands frozen at capture time.  Also: an eager forward right after capture() must not read the capture's
+    never-executed graph-private operands."""
+    from sept_amd.trainer import FusedPipeline, GrlTrainer
+    F = 80
+    torch.manual_seed(3)
+    wav = (torch.randn(2, 48000) * 0.1).cuda()
+    le, lg = torch.tensor([0, 0, 0, 3, 3, 3]).cuda(), torch.tensor([1, 1, 1, 0, 0, 0]).cuda()
+    w = torch.ones(6).cuda()
+    mean, std = torch.full((F,), -20.0).cuda(), torch.full((F,), 12.0).cuda()
+    results = []
+    for use_graph in (False, True):
+        grl = build_grl(F).train()
+        zero_dropout(grl)
+        tr = GrlTrainer(grl, optimizer="sgd", lr=0.05)
+        pipe = FusedPipeline(tr, n_mels=F, mean=mean, std=std)
+        pipe.train_step(wav, le, lg, w)
+        x = pipe.features(wav).view(6, 1, 200, F)
+        ev0 = tr.eval_step(x, le, lg)[1].clone()               # eager forward: fills the cache with fresh operands
+        if use_graph:
+            step = pipe.capture(wav, le, lg, w)
+            ev1 = tr.eval_step(x, le, lg)[1].clone()           # eager forward between capture() and the first replay
+            assert torch.equal(ev0, ev1)
+            step(), step()
+        else:
+            pipe.train_step(wav, le, lg, w), pipe.train_step(wav, le, lg, w)
+        torch.cuda.synchronize()
+        results.append((tr.flat.flat.clone(), tr.eval_step(x, le, lg)[1].clone()))
+    assert torch.equal(results[0][0], results[1][0])
+    assert torch.equal(results[0][1], results[1][1])
+
+
+def test_capture_on_non_origin_stream_stays_in_line():
+    """The capture guard (functional.fork_allowed): a network whose backward runs on a FORKED stream inside a
+    HIP-graph capture must not fork its weight-gradient side stream there (the nested join aborts
+    hipStreamEndCapture on ROCm 7.2, tools/repro_capture_nested_join.py) -- it runs in line and the replay gives the
+    eager result.  The GRL wrapper called from a forked stream likewise serialises its two branches."""
+    from sept_amd import functional as SF
+    F = 80
+    x = closed_form_input(B, W, F).cuda()
+    le = closed_form_labels(B)[0].view(-1).cuda()
+    m = mk(F, "emotion").train()
+    zero_dropout(m)
+    torch.nn.functional.cross_entropy(m(x), le).backward()                 # eager reference (+ first-use setup)
+    want = m.conv[5].weight.grad.clone()
+    m.zero_grad()
+    grl = build_grl(F).train()
+    zero_dropout(grl)
+    p1, _, _ = grl(x, mask=None, grl=False, pooling="mean")
+    want_p1 = p1.detach().clone()
+    side = torch.cuda.Stream()
+    SF.invalidate_weight_cache()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"), SF.capture_origin():
+        origin = torch.cuda.current_stream()
+        assert SF.fork_allowed(x.device)
+        side.wait_stream(origin)
+        with torch.cuda.stream(side):
+            assert not SF.fork_allowed(x.device)
+            loss = torch.nn.functional.cross_entropy(m(x), le)
+            loss.backward()
+            q1, _, _ = grl(x, mask=None, grl=False, pooling="mean")
+        origin.wait_stream(side)
+    SF.invalidate_weight_cache()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(m.conv[5].weight.grad, want)
+    assert torch.equal(q1.detach(), want_p1)
+
+
+@pytest.mark.parametrize("kind", ["sgd", "adam"])
+def test_captured_step_with_optimizer_and_scheduler_equals_eager(kind):
+    """training_cloak_with_grl.py:416-421: SGD + StepLR / Adam + ReduceLROnPlateau.  The captured step carries the
+    optimiser (rate and Adam's step count are device scalars); a torch scheduler drives `trainer.optimizer` between
+    replays.  Replay == eager, bit for bit, under a changing rate."""
+    from sept_amd.trainer import GrlTrainer
+    F = 80
+    x = closed_form_input(B, W, F).cuda()
+    le, lg, wts = (t.cuda() for t in closed_form_labels(B))
+    res = []
+    for use_graph in (False, True):
+        grl = build_grl(F).train()
+        zero_dropout(grl)
+        tr = GrlTrainer(grl, optimizer=kind, lr=0.02 if kind == "sgd" else 5e-3, gender_lambda=0.1, scale_lamda=0.05)
+        sched = torch.optim.lr_scheduler.StepLR(tr.optimizer, step_size=1, gamma=0.5) if kind == "sgd" else \
+            torch.optim.lr_scheduler.ReduceLROnPlateau(tr.optimizer, mode="min", patience=0, factor=0.5)
+        tr.train_step(x, le, lg, wts)
+        step = tr.capture(x, le, lg, wts) if use_graph else (lambda: tr.train_step(x, le, lg, wts))
+        lrs = []
+        for it in range(3):
+            sched.step() if kind == "sgd" else sched.step(1.0 + it)     # a "validation loss" that never improves
+            step()
+            lrs.append(tr.lr)
+        torch.cuda.synchronize()
+        assert lrs[0] > lrs[-1] and float(tr.lr_dev) == pytest.approx(lrs[-1])
+        assert int(tr.step_dev) == 4 == tr.steps
+        res.append((tr.flat.flat.clone(), lrs))
+    assert res[0][1] == res[1][1]
+    assert torch.equal(res[0][0], res[1][0])
+
+
+def test_recurrent_shapes_outside_the_hip_path_say_what_is_supported():
+    """baseline_models.py:191-193 builds any rnn_cell / hidden / layers; the HIP recurrences cover 2 bidirectional
+    layers of hidden 64 or 128 -- anything else must fail with a message naming the supported set, never silently."""
+    from model import baseline_models as bm
+    x = closed_form_input(2, W, 80).cuda()
+    for kw in (dict(lstm_hidden_size=32), dict(num_layers_lstm=1), dict(bidirectional=False)):
+        m = bm.two_d_cnn_lstm(1, 80, 64, **dict(dict(lstm_hidden_size=64, num_layers_lstm=2, global_feature=0), **kw))
+        with pytest.raises(NotImplementedError, match="hidden 64 .* or 128"):
+            m.cuda().eval()(x)

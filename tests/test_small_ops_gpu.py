@@ -219,6 +219,36 @@ def test_optimizer_steps_match_torch(kind):
         assert torch.allclose(p.cpu(), ref.detach(), rtol=1e-5, atol=1e-7), step
 
 
+@pytest.mark.parametrize("kind", ["sgd", "adam"])
+def test_device_state_optimizer_steps_match_torch_with_a_schedule(kind):
+    """sept_sgd_step_dev / sept_adam_step_dev: learning rate and Adam's step count live on the device (so the
+    update can sit inside a captured graph); driven by a StepLR schedule they follow torch.optim + StepLR."""
+    from sept_amd import ops
+    g = torch.Generator().manual_seed(2)
+    p0 = torch.randn(1000, generator=g)
+    ref = p0.clone().requires_grad_()
+    opt = torch.optim.SGD([ref], lr=1e-3, momentum=0.9, weight_decay=1e-4) if kind == "sgd" else \
+        torch.optim.Adam([ref], lr=5e-4, weight_decay=1e-4, betas=(0.9, 0.98), eps=1e-9)
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=2, gamma=0.5)
+    p = p0.clone().cuda()
+    b1, b2 = torch.zeros_like(p), torch.zeros_like(p)
+    lr_dev = torch.empty((), device="cuda")
+    step_dev = torch.zeros((), dtype=torch.int64, device="cuda")
+    for step in range(1, 7):
+        gr = torch.randn(1000, generator=g)
+        ref.grad = gr.clone()
+        ops.fill(lr_dev, opt.param_groups[0]["lr"])
+        opt.step()
+        sched.step()
+        ops.counter_add(step_dev, 1)
+        if kind == "sgd":
+            ops.sgd_step_dev(p, (2 * gr).cuda(), b1, lr_dev, 0.9, 1e-4, grad_scale=0.5)
+        else:
+            ops.adam_step_dev(p, (2 * gr).cuda(), b1, b2, lr_dev, 0.9, 0.98, 1e-9, 1e-4, step_dev, grad_scale=0.5)
+        assert torch.allclose(p.cpu(), ref.detach(), rtol=1e-5, atol=1e-7), step
+    assert int(step_dev) == 6 and float(lr_dev) == pytest.approx(opt.param_groups[0]["lr"] * 2)   # 3 halvings due, 2 applied
+
+
 def test_philox_dropout_and_normal_statistics():
     """sept_dropout_mask / sept_normal: right distribution, reproducible for equal (seed, counter),
     fresh after begin_step(), different sub-streams per call site."""
@@ -253,7 +283,7 @@ def test_preprocess_speaker_stats_window_norm_and_augmentation():
     B, T, F, S = 6, 301, 40, 3
     mel = torch.randn(B, T, F, generator=g) * 9 - 30
     spk = torch.tensor([0, 2, 0, 1, 2, 2], dtype=torch.int32)
-    stats = pp.speaker_stats(mel.cuda(), spk.cuda(), S).cpu().numpy()
+    stats = pp.speaker_stats(mel.cuda(), spk.cuda(), S, population="frames").cpu().numpy()
     m = mel.double().numpy()
     for s_ in range(S):
         rows = m[(spk == s_).numpy()].reshape(-1, F)
@@ -284,6 +314,49 @@ def test_preprocess_speaker_stats_window_norm_and_augmentation():
     xa, la = pp.balance_by_augmentation(x, labels, generator=torch.Generator().manual_seed(1))
     assert xa.shape[0] == 120 and torch.bincount(la.cpu()).tolist() == [40, 40, 40]
     assert float(xa[:64].abs().max()) == 0.0 and float(xa[64:].std()) == pytest.approx(0.05, rel=5e-2)
+
+
+def test_speaker_stats_follow_the_reference_population():
+    """preprocess_adversary_data.py:20-83, 356-381 restated in oracle/preprocess_oracle.py: the statistics run over
+    the rows of the SAVED windows (multiplicity 0-4 per frame), test-split clips whole and once, short clips once;
+    ragged clips (zero-padded to one T with `lengths`), then znorm / min-max of the stored items (zeros for the
+    padding BEFORE the normalisation)."""
+    import numpy as np
+    from oracle import preprocess_oracle as po
+    from sept_amd import preprocess as pp
+    rng = np.random.default_rng(5)
+    F, T = 24, 420
+    lens = [420, 301, 200, 249, 120, 333, 199, 250]
+    spk = [0, 1, 0, 2, 1, 2, 0, 1]
+    test_speakers = {2}
+    clips = [rng.normal(-30, 9, size=(L, F)) * (1 + 0.2 * s_) for L, s_ in zip(lens, spk)]
+    want = po.speaker_statistics(clips, spk, test_speakers)
+    mel = torch.zeros(len(lens), T, F)
+    for b, c in enumerate(clips):
+        mel[b, :len(c)] = torch.from_numpy(c).float()
+    whole = torch.tensor([s_ in test_speakers for s_ in spk])
+    stats = pp.speaker_stats(mel.cuda(), torch.tensor(spk), 3, lengths=torch.tensor(lens), whole_clip=whole).cpu().numpy()
+    for s_ in range(3):
+        np.testing.assert_allclose(stats[s_, 0], want[s_]["mean"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(stats[s_, 1], want[s_]["std"], rtol=1e-5)
+        np.testing.assert_allclose(stats[s_, 2], want[s_]["min"], rtol=1e-6)
+        np.testing.assert_allclose(stats[s_, 3], want[s_]["max"], rtol=1e-6)
+    # the population really differs from "every frame once" (what round 1 computed)
+    frames = pp.speaker_stats(mel[:1].cuda(), None, 1, population="frames").cpu().numpy()
+    windows = pp.speaker_stats(mel[:1].cuda(), None, 1).cpu().numpy()
+    assert np.abs(frames[0, 0] - windows[0, 0]).max() > 1e-3
+    mult = po.frame_multiplicity(420)
+    assert mult.max() == 4 and mult[-20:].sum() == 0 and mult.sum() == 5 * 200
+    # windows of a full-length clip and of a short one, normalised with the reference-population statistics
+    st = torch.from_numpy(stats).cuda()
+    for norm in ("znorm", "min_max"):
+        for b in (0, 4):
+            L = lens[b]
+            w = pp.window_normalize(mel[b:b + 1, :L].contiguous().cuda(), st, torch.tensor([spk[b]]), norm).cpu().numpy()
+            items = po.saved_items(clips[b])
+            assert w.shape[0] == len(items)
+            for i, (_, stored) in enumerate(items):
+                np.testing.assert_allclose(w[i], po.normalise(stored, want[spk[b]], norm), rtol=3e-4, atol=3e-4)
 
 
 @pytest.mark.parametrize("B,T,H", [(7, 25, 64), (3, 2, 64), (1, 1, 64), (5, 25, 128), (2, 3, 128)])

@@ -128,6 +128,9 @@ def main():
     y = ref_rg.GradientReversalFunction.apply(z, 0.1)
     (y * torch.arange(1.0, 7.0).reshape(2, 3)).sum().backward()
     out["grl_kat_grad"] = z.grad.numpy()
+    # "identical emotion / gender argmax" (BASELINE.json north_star): the reference's decisions, recorded as such
+    for key in [k_ for k_, v in out.items() if getattr(v, "ndim", 0) == 2 and v.shape[0] == B and v.shape[1] in (2, 4)]:
+        out[key + "_argmax"] = out[key].argmax(1).astype(np.int64)
     path = os.path.join(ROOT, "tests", "golden", "model_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes;", len(out), "arrays")

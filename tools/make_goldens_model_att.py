@@ -106,6 +106,9 @@ def main():
         g = dict(grl.gender_model.named_parameters())[name].grad
         out["grl_att_grad_" + name] = sl(g)
         out["grl_att_gradnorm_" + name] = np.array(g.double().norm().item())
+    # "identical emotion / gender argmax" (BASELINE.json north_star): the reference's decisions, recorded as such
+    for key in [k_ for k_, v in out.items() if getattr(v, "ndim", 0) == 2 and v.shape[0] == B and v.shape[1] in (2, 4)]:
+        out[key + "_argmax"] = out[key].argmax(1).astype(np.int64)
     path = os.path.join(ROOT, "tests", "golden", "model_golden_att.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes;", len(out), "arrays")

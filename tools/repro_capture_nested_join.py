@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""DOCUMENTATION, not a test: the HIP-graph capture topology that aborts the process on ROCm 7.2 (gfx950)
+and the ones that do not.  Pure torch, no libsept.  Run one mode per process on a GPU box:
+
+    python tools/repro_capture_nested_join.py nested     # origin -> s1 -> wg, s1 joins wg    : core dump in
+                                                         #   hipStreamEndCapture (round-1 logs cap_nested / cap_both
+                                                         #   / cap_n4 / cap_n5: "the monitored command dumped core")
+    python tools/repro_capture_nested_join.py origin     # origin -> s1 -> wg, ORIGIN joins wg : works (cap_n1)
+    python tools/repro_capture_nested_join.py multifork  # origin -> wg1, origin -> wg2        : works (cap_multifork)
+
+What sept_amd does about it: functional.fork_allowed() -- inside a capture a side stream is only forked when its
+join lands on the capture's origin stream (published by capture_origin() in the trainers' capture()); any other
+caller runs in line.  tests/test_model_gpu.py::test_capture_on_non_origin_stream_stays_in_line exercises the guard.
+NEVER run the 'nested' mode inside a test run: it takes the process down."""
+import sys
+
+import torch
+
+
+def main(mode):
+    dev = torch.device("cuda")
+    a = torch.randn(1 << 20, device=dev)
+    s1, wg, wg2 = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        origin = torch.cuda.current_stream()
+        if mode in ("nested", "origin"):
+            s1.wait_stream(origin)
+            with torch.cuda.stream(s1):
+                b = a * 2
+                wg.wait_stream(s1)
+                with torch.cuda.stream(wg):
+                    c = b + 1
+                d = b - 1
+                if mode == "nested":
+                    s1.wait_stream(wg)        # a forked stream joins another forked stream: aborts at end of capture
+            if mode == "origin":
+                origin.wait_stream(wg)        # the same fork, joined at the origin: fine
+            origin.wait_stream(s1)
+            out = c + d
+        else:
+            wg.wait_stream(origin)
+            wg2.wait_stream(origin)
+            with torch.cuda.stream(wg):
+                c = a + 1
+            with torch.cuda.stream(wg2):
+                d = a - 1
+            origin.wait_stream(wg)
+            origin.wait_stream(wg2)
+            out = c + d
+    g.replay()
+    torch.cuda.synchronize()
+    print(mode, "ok", float(out.sum()))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "origin")
