@@ -251,6 +251,38 @@ int sept_cloak_backward(const float* dxa, const float* dxb, float gscale_b, cons
                         const float* mask, float min_scale, float max_scale, float scale_lambda,
                         const float* scale_mean, float* dlocs, float* drhos, int B, long n_per, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Layer 1 WITHOUT its pre-activation tensor (baseline_models.py:172-176: Conv2d(1, 32, 5, padding 2) ->
+ * BatchNorm2d -> ReLU -> MaxPool2d(2) -> Dropout2d).  conv1's output is 16x its input, so these entry points
+ * recompute it from x wherever it is needed instead of storing / re-reading it (H even, W % 16 == 0:
+ * sept_conv1_fused_supported; other shapes use the separate conv1 / BatchNorm entry points above).
+ *   sept_conv1_stats_only                  : BatchNorm statistics partials (as sept_conv1_forward_stats, no y)
+ *   sept_conv1_bn_relu_pool_forward        : y_pooled (B, H/2, W/2, 32) bf16 from x, with given mean / invstd
+ *   sept_conv1_bn_relu_pool_backward_reduce: partials[64][sept_conv1_stats_parts(B, H)] of (sum g, sum g * xhat)
+ *   sept_bn_bwd_sums_from_partials         : -> sums[2C] (+ dgamma, dbeta); all-reducible for sync-BN
+ *   sept_conv1_bn_relu_pool_backward_apply : dpre (B, H, W, 32) bf16, the gradient sept_conv1_backward_* consume
+ * wprep: sept_conv1_prep_floats() floats of scratch, as for sept_conv1_forward. */
+/* conv1's weights in operand form: every sept_conv1_* entry point builds it into `wprep` from (w, bias) unless called
+ * with w == NULL ("wprep is current"); sept_conv1_prep builds it explicitly so a caller can keep it across calls. */
+int sept_conv1_prep(const float* w, const float* bias, float* wprep, void* stream);
+int sept_conv1_fused_supported(int H, int W);
+int sept_conv1_stats_only(const float* x, const float* w, const float* bias, float* wprep, float* stats, int B, int H,
+                          int W, void* stream);
+int sept_conv1_bn_relu_pool_forward(const float* x, const float* w, const float* bias, float* wprep, const float* mean,
+                                    const float* invstd, const float* gamma, const float* beta, const float* dropscale,
+                                    void* y_pooled, int B, int H, int W, void* stream);
+int sept_conv1_bn_relu_pool_backward_reduce(const float* x, const float* w, const float* bias, float* wprep,
+                                            const void* dy_pooled, const float* mean, const float* invstd,
+                                            const float* gamma, const float* beta, const float* dropscale,
+                                            float* partials, int B, int H, int W, void* stream);
+int sept_bn_bwd_sums_from_partials(const float* partials, int nparts, int C, float* sums_out, float* dgamma,
+                                   float* dbeta, void* stream);
+int sept_conv1_bn_relu_pool_backward_apply(const float* x, const float* w, const float* bias, float* wprep,
+                                           const void* dy_pooled, const float* mean, const float* invstd,
+                                           const float* gamma, const float* beta, const float* dropscale,
+                                           const float* sums, double n_total, void* dpre, int B, int H, int W,
+                                           void* stream);
+
 /* y = a * x  (GradientReversalFunction.backward with a = -lambda, reversal_gradient.py:18-23) */
 int sept_scale(const float* x, float a, float* y, long n, void* stream);
 /* y[i] = value (zero gradients of conv biases in front of a train-mode BatchNorm; flat-buffer housekeeping) */

@@ -322,14 +322,16 @@ __global__ __launch_bounds__(256) void sept_bn_bwd_reduce_pooled_kernel(BnBwdArg
 }
 
 __global__ __launch_bounds__(256) void sept_bn_bwd_finalize_kernel(float* ws, int nparts, int C, float* dgamma,
-                                                                   float* dbeta, float* sums_out) {
+                                                                   float* dbeta, float* sums_out, bool in_ws = true) {
   const int c = blockIdx.x;  // one workgroup per channel
   double s1, s2;
   channel_totals(ws, nparts, C, c, s1, s2);
   if (threadIdx.x != 0) return;
-  float* sums = ws + size_t(kParts) * 2 * C;
-  sums[c] = float(s1);      // sum dy      (= dbeta)
-  sums[C + c] = float(s2);  // sum dy*xhat (= dgamma)
+  if (in_ws) {
+    float* sums = ws + size_t(kParts) * 2 * C;
+    sums[c] = float(s1);      // sum dy      (= dbeta)
+    sums[C + c] = float(s2);  // sum dy*xhat (= dgamma)
+  }
   if (dbeta) dbeta[c] = float(s1);
   if (dgamma) dgamma[c] = float(s2);
   if (sums_out) {
@@ -537,6 +539,16 @@ extern "C" int sept_bn_relu_pool_backward_reduce(const void* dy, const void* x, 
               gamma, beta, dropscale, ws, nullptr, B, H, W, C, pool, nullptr, 0.f};
   if (int e = bn_bwd_launch_reduce(a, dgamma, dbeta, sums, static_cast<hipStream_t>(stream))) return e;
   return sept::launch_check("sept_bn_relu_pool_backward_reduce");
+}
+
+// (sum g, sum g * xhat) from per-workgroup partials, TRANSPOSED [2C][nparts], left by a producer kernel
+// (sept_conv1_bn_relu_pool_backward_reduce): sums_out[2C], and the BatchNorm parameter gradients when asked for
+extern "C" int sept_bn_bwd_sums_from_partials(const float* partials, int nparts, int C, float* sums_out, float* dgamma,
+                                              float* dbeta, void* stream) {
+  SEPT_REQUIRE(partials && sums_out && nparts > 0 && C > 0, SEPT_ERR_INVALID, "sept_bn_bwd_sums_from_partials: bad argument");
+  hipLaunchKernelGGL(sept_bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     const_cast<float*>(partials), nparts, C, dgamma, dbeta, sums_out, false);
+  return sept::launch_check("sept_bn_bwd_sums_from_partials");
 }
 
 extern "C" int sept_bn_relu_pool_backward_apply(const void* dy, const void* x, const float* mean, const float* invstd,

@@ -15,7 +15,12 @@
 // zero-filled outside the image) are staged ONCE in LDS and reused by all 25 taps and all
 // output channels; weights stream through a double-buffered per-tap LDS tile (prefetched
 // into registers under the MFMAs, one barrier per tap).  Pixel stride in LDS is padded by
-// 16 B so the 16-lane groups of ds_read_b128 hit distinct banks.
+// 16 B so the 16-lane groups of ds_read_b128 hit distinct banks, and every staged ROW carries
+// kRowPad extra bytes: a 32-pixel MFMA block is 32 consecutive flattened pixels, so it wraps image
+// rows; with the 4 halo pixels between rows the 16-byte slot index of pixel q is 9q + 36r (+ const)
+// mod 16 for a 64-channel tile -- lanes 4, 12 or 20 pixels apart on different rows then share banks
+// (29-39 % of the LDS cycles were conflicts, r01 PMC).  12 extra slots per row make the row term
+// 48r = 0 mod 16 for every channel count in use (5, 9 or 17 slots per pixel): slot = 9q + const again.
 #include <algorithm>
 #include <cstdlib>
 
@@ -30,6 +35,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 constexpr int kTaps = 25;
+constexpr int kRowPad = 192;   // bytes appended to every staged input row (see the header comment)
 
 struct ConvArgs {
   const bf16* x;      // [B][H][W][CIN]
@@ -57,6 +63,7 @@ __host__ __device__ constexpr int conv_nr_max(int mt, int w) { return (mt + w - 
 // channel -- the statistics pass of the BatchNorm that follows, without reading the tensor back.  The output
 // tile goes through the LDS (free by then) and is summed by columns, which costs no registers: the 8-wave shapes
 // sit at the 128-VGPR limit that lets two workgroups share a CU.
+__host__ __device__ constexpr size_t conv_row_pitch(int w, int ps) { return size_t(w + 4) * ps + kRowPad; }
 __host__ __device__ constexpr size_t conv_stats_smem(int mt, int cout, int nthr) {
   return size_t(mt) * (cout * 2 + 8) + size_t(nthr / cout) * 2 * cout * sizeof(float);
 }
@@ -81,8 +88,9 @@ void sept_conv5x5_mfma_kernel(ConvArgs a) {
   constexpr int NG = (kTaps + TG - 1) / TG;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int W = a.W, H = a.H, HW = H * W, W4 = W + 4;
+  const int RP = W4 * PS + kRowPad;   // bytes per staged row
   unsigned char* tile = smem;
-  unsigned char* wbuf = smem + size_t(a.nr_max) * W4 * PS;
+  unsigned char* wbuf = smem + size_t(a.nr_max) * RP;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = (tid >> 6) % WP, nhalf = (tid >> 6) / WP;  // pixel group, output-channel slice
@@ -124,7 +132,7 @@ void sept_conv5x5_mfma_kernel(ConvArgs a) {
   for (int pb = 0; pb < PB; ++pb) {
     const int q = min(q0 + (wave * PB + pb) * 32 + (lane & 31), HW - 1);
     const int h = q / W, w = q - h * W;
-    lane_base[pb] = ((h - h_first) * W4 + w) * PS + (lane >> 5) * 16;
+    lane_base[pb] = (h - h_first) * RP + w * PS + (lane >> 5) * 16;
   }
   const int a_base = (nhalf * NB * 32 + (lane & 31)) * PSW + (lane >> 5) * 16;
 
@@ -150,7 +158,7 @@ void sept_conv5x5_mfma_kernel(ConvArgs a) {
       uint4 v = make_uint4(0, 0, 0, 0);
       if (h >= 0 && h < H && w >= 0 && w < W)
         v = *reinterpret_cast<const uint4*>(xb + (size_t(h) * W + w) * CINF + c * 8);
-      *reinterpret_cast<uint4*>(tile + size_t(px) * PS + c * 16) = v;
+      *reinterpret_cast<uint4*>(tile + size_t(row) * RP + col * PS + c * 16) = v;
     }
   }
   {
@@ -165,7 +173,7 @@ void sept_conv5x5_mfma_kernel(ConvArgs a) {
       const int tap = g * TG + tl;
       if (tap >= kTaps) break;
       const int kh = tap / 5, kw = tap - kh * 5;
-      const int tapoff = (kh * W4 + kw) * PS;
+      const int tapoff = kh * RP + kw * PS;
       const unsigned char* wb = wbuf + size_t(DBUF ? buf : tl) * COUT * PSW;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
@@ -366,7 +374,7 @@ const ConvVariant* conv_pick(int W, int cin, int cout, bool want_stats, size_t* 
     if (force_cs && v.cs != force_cs) continue;
     const int mt = 32 * v.pb * v.wp;
     const size_t ps = size_t(cin / v.cs) * 2 + 16;
-    const size_t smem = size_t(conv_nr_max(mt, W)) * (W + 4) * ps + size_t(v.tg == 0 ? 2 : v.tg) * cout * ps;
+    const size_t smem = size_t(conv_nr_max(mt, W)) * conv_row_pitch(W, int(ps)) + size_t(v.tg == 0 ? 2 : v.tg) * cout * ps;
     if (smem > 160 * 1024) continue;
     // measured on MI355X (tools/sweep_conv.py): what matters is whether TWO workgroups share a CU
     // (a third adds nothing); then the double-buffered form; then table order (tile shape)

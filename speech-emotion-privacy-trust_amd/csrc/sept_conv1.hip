@@ -108,7 +108,7 @@ constexpr int kStatLd = 33;   // floats per lane in the statistics exchange (odd
 // outputs in stats[workgroup][64] -- the BatchNorm that follows (baseline_models.py:173) then needs
 // no pass of its own over the 64 B/pixel tensor.  Each lane keeps running sums of its 16 channels
 // over its blocks; they meet once per workgroup in LDS, added in a fixed order.
-template <bool STATS>
+template <bool STATS, bool WRITE = true>
 __global__ __launch_bounds__(256) void sept_conv1_fwd_mfma_kernel(const float* __restrict__ x,
                                                                   const float* __restrict__ wprep,
                                                                   bf16* __restrict__ y, float* __restrict__ stats,
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void sept_conv1_fwd_mfma_kernel(const float* _
       const auto r1 = __builtin_amdgcn_permlane32_swap(pk[u][1], pk[u + 2][1], false, false);
       out[u] = make_uint4(r0[0], r1[0], r0[1], r1[1]);
     }
-    if (q < npx) {
+    if (WRITE && q < npx) {
       uint4* yp = reinterpret_cast<uint4*>(yb + size_t(q) * kC + 16 * half);
       yp[0] = out[0];
       yp[1] = out[1];
@@ -542,6 +542,217 @@ __global__ void sept_conv1_wgrad_mfma_finalize_kernel(const float* ws, int npart
     db[c] = float(s);
 }
 
+// ---- layer 1 without its pre-activation tensor ----------------------------------------------------
+// conv1's output is 16x larger than its input (32 bf16 channels per fp32 pixel): at 224 windows of 200 x 80 the
+// pre-BatchNorm tensor is 229 MB, and storing it made every pass around it an HBM stream (conv1 write, BatchNorm
+// read, backward read + gradient write: a third of the step's kernel time in round 1).  These kernels RECOMPUTE
+// conv1 from the 14 MB input wherever its output is needed (the same six MFMAs per 32 pixels, so the same bits):
+//   forward : a statistics-only pass (sept_conv1_fwd_mfma_kernel<true, false>: no store), then conv1 -> BatchNorm ->
+//             ReLU -> MaxPool 2x2 -> Dropout2d in registers, writing only the pooled tensor (1/4 of the pixels);
+//   backward: the two BatchNorm sums (sum g, sum g * xhat) by recomputation, then the gradient of the pre-activations
+//             (what conv1's weight / data gradients consume) from x, the pooled gradient and the sums.
+// A 32-pixel MFMA block is a 2-row x 16-column PATCH here, so the four pixels of a pooling window sit in lanes
+// c, c^1 (next column) and c^16, c^17 (next row) of the same 32-lane half: the window maximum and the arg-max
+// decision are two lane exchanges (quad-perm DPP and v_permlane16_swap), no LDS.  Needs W % 16 == 0 and H even.
+enum { kL1Fwd = 0, kL1BwdReduce = 1, kL1BwdApply = 2 };
+
+struct L1Args {
+  const float* x;       // [B][H][W]
+  const float* wprep;   // sept_conv1_prep_kernel output
+  const float *mean, *invstd, *gamma, *beta;   // [32]
+  const float* drop;    // [B][32] Dropout2d scale (0 or 1/(1-p)) or null
+  bf16* y;              // forward: pooled output [B][H/2][W/2][32]
+  const bf16* dy;       // backward: gradient of the pooled output
+  bf16* dpre;           // backward apply: gradient of the conv output [B][H][W][32]
+  const float* sums;    // backward apply: [64] = sum g, sum g * xhat
+  float inv_n;          // backward apply: 1 / (elements per channel the sums cover)
+  float* parts;         // backward reduce: transposed partials [64][workgroups]
+  int B, H, W;
+};
+
+__device__ __forceinline__ float lane_xor1(float v) {   // value of lane ^ 1 (quad_perm [1,0,3,2])
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float lane_xor16(float v) {  // value of lane ^ 16 (rows of 16 lanes swapped pairwise)
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);   // r[0] = rows {0,0,2,2}, r[1] = rows {1,1,3,3}
+  return __builtin_bit_cast(float, ((threadIdx.x >> 4) & 1) ? r[0] : r[1]);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void sept_conv1_l1_kernel(L1Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* tile = reinterpret_cast<float*>(smem);
+  const int H = a.H, W = a.W, W4 = W + 4, PW = W / 16;
+  const int b = blockIdx.y, h0 = blockIdx.x * kFwdRows;
+  const int nrows = min(kFwdRows, H - h0);   // even: H is
+  stage_x(a.x + size_t(b) * H * W, tile, h0, nrows + 4, H, W);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, c = lane & 31;
+  const float* wprep = a.wprep;
+  // weight fragments exactly as sept_conv1_fwd_mfma_kernel builds them (same products, same order, same bits)
+  bf16x8 whi[2], wlo[2];
+  int tapoff[2][8];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int t = 16 * ks + 8 * half + j;
+      const float wv = t < kTaps ? wprep[t * kC + c] : (t == kTaps ? wprep[kTaps * kC + c] : 0.f);
+      whi[ks][j] = (bf16)wv;
+      wlo[ks][j] = (bf16)(wv - float(whi[ks][j]));
+      tapoff[ks][j] = t < kTaps ? (t / 5) * W4 + t % 5 : 0;
+    }
+  // per-lane channel constants: register r <-> channel 8 * (r >> 2) + 4 * half + (r & 3)
+  float sc[16], sh[16], mu[16], is[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int ch = 8 * (r >> 2) + 4 * half + (r & 3);
+    mu[r] = a.mean[ch];
+    is[r] = a.invstd[ch];
+    sc[r] = a.gamma[ch] * is[r];
+    sh[r] = __builtin_fmaf(-mu[r], sc[r], a.beta[ch]);
+  }
+  float m1[MODE == kL1BwdApply ? 16 : 1], m2[MODE == kL1BwdApply ? 16 : 1];
+  if constexpr (MODE == kL1BwdApply) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ch = 8 * (r >> 2) + 4 * half + (r & 3);
+      m1[r] = a.sums[ch] * a.inv_n;
+      m2[r] = a.sums[kC + ch] * a.inv_n;
+    }
+  }
+  float s1[MODE == kL1BwdReduce ? 16 : 1], s2[MODE == kL1BwdReduce ? 16 : 1];
+  if constexpr (MODE == kL1BwdReduce) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s1[r] = s2[r] = 0.f;
+  }
+  float dr[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dr[r] = a.drop ? a.drop[size_t(b) * kC + 8 * (r >> 2) + 4 * half + (r & 3)] : 1.0f;
+  // this lane's place in its pooling window: q = 2 * (row in the pair) + (column parity), scan order of max_pool2d
+  const int myq = 2 * ((c >> 4) & 1) + (c & 1);
+  const bool h_first = (myq ^ 1) < myq, v_first = (myq ^ 2) < myq, d_first = (myq ^ 3) < myq;
+  __syncthreads();
+  const int Ho = H / 2, Wo = W / 2;
+  const int nblk = (nrows / 2) * PW;
+  for (int blk = wave; blk < nblk; blk += 4) {
+    const int rp = blk / PW, pc = blk - rp * PW;
+    const int hh = 2 * rp + ((c >> 4) & 1), ww = 16 * pc + (c & 15);
+    const float* tp = tile + hh * W4 + ww;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 xhi, xlo;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float xv = tp[tapoff[ks][j]];
+        if (ks == 1) xv = (half && j == 1) ? 1.0f : ((half && j > 1) ? 0.f : xv);
+        xhi[j] = (bf16)xv;
+        xlo[j] = (bf16)(xv - float(xhi[j]));
+      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo[ks], xhi, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[ks], xlo, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[ks], xhi, acc, 0, 0, 0);
+    }
+    const int ho = (h0 >> 1) + rp, wo = 8 * pc + ((c & 15) >> 1);
+    if constexpr (MODE == kL1Fwd) {
+      unsigned pk[4][2];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          bf16x2 t;
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int r = 4 * j + 2 * d + e;
+            const float v = float((bf16)acc[r]);                       // the pre-activation as the unfused path stores it
+            float m = fmaxf(__builtin_fmaf(v, sc[r], sh[r]), 0.f);     // BatchNorm + ReLU
+            m = fmaxf(m, lane_xor1(m));                                 // 2x2 window maximum
+            m = fmaxf(m, lane_xor16(m));
+            t[e] = (bf16)(m * dr[r]);
+          }
+          pk[j][d] = __builtin_bit_cast(unsigned, t);
+        }
+      uint4 out[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {   // lanes < 32 end up with channels 0..15, lanes >= 32 with 16..31 (as the conv1 forward)
+        const auto r0 = __builtin_amdgcn_permlane32_swap(pk[u][0], pk[u + 2][0], false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(pk[u][1], pk[u + 2][1], false, false);
+        out[u] = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+      }
+      if ((c & 17) == 0) {            // the window's first lane stores the pooled pixel
+        uint4* yp = reinterpret_cast<uint4*>(a.y + ((size_t(b) * Ho + ho) * Wo + wo) * kC + 16 * half);
+        yp[0] = out[0];
+        yp[1] = out[1];
+      }
+    } else {
+      // pooled gradient of this lane's window: 4 x (4 channels = 8 bytes)
+      const bf16* dyp = a.dy + ((size_t(b) * Ho + ho) * Wo + wo) * kC + 4 * half;
+      bf16x4 gq[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) gq[j] = *reinterpret_cast<const bf16x4*>(dyp + 8 * j);
+      unsigned pk[4][2];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          bf16x2 t;
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int r = 4 * j + 2 * d + e;
+            const float v = float((bf16)acc[r]);
+            const float rl = fmaxf(__builtin_fmaf(v, sc[r], sh[r]), 0.f);
+            // first maximum in window scan order wins (ATen max_pool2d), and only if the ReLU is active there
+            const float rh = lane_xor1(rl), rv = lane_xor16(rl), rd = lane_xor16(rh);
+            const bool win = rl > 0.f && (h_first ? rl > rh : rl >= rh) && (v_first ? rl > rv : rl >= rv) &&
+                             (d_first ? rl > rd : rl >= rd);
+            const float ge = win ? float(gq[j][2 * d + e]) * dr[r] : 0.f;
+            const float xhat = (v - mu[r]) * is[r];
+            if constexpr (MODE == kL1BwdReduce) {
+              s1[r] += ge;
+              s2[r] = __builtin_fmaf(ge, xhat, s2[r]);
+            } else {
+              t[e] = (bf16)(sc[r] * (ge - m1[r] - xhat * m2[r]));
+            }
+          }
+          if constexpr (MODE == kL1BwdApply) pk[j][d] = __builtin_bit_cast(unsigned, t);
+        }
+      if constexpr (MODE == kL1BwdApply) {
+        uint4 out[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const auto r0 = __builtin_amdgcn_permlane32_swap(pk[u][0], pk[u + 2][0], false, false);
+          const auto r1 = __builtin_amdgcn_permlane32_swap(pk[u][1], pk[u + 2][1], false, false);
+          out[u] = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+        }
+        uint4* dp = reinterpret_cast<uint4*>(a.dpre + ((size_t(b) * H + h0 + hh) * W + ww) * kC + 16 * half);
+        dp[0] = out[0];
+        dp[1] = out[1];
+      }
+    }
+  }
+  if constexpr (MODE == kL1BwdReduce) {
+    __syncthreads();   // the staged rows are no longer needed: the exchange reuses their LDS
+    float* ex = reinterpret_cast<float*>(smem);   // [256 lanes][kStatLd]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      ex[threadIdx.x * kStatLd + r] = s1[r];
+      ex[threadIdx.x * kStatLd + 16 + r] = s2[r];
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * kC) {
+      const int which = threadIdx.x / kC, ch = threadIdx.x % kC;
+      const int j = ch >> 3, hf = (ch >> 2) & 1, i = ch & 3;
+      float t = 0.f;
+      for (int w = 0; w < 4; ++w)
+        for (int l = 0; l < 32; ++l) t += ex[(w * 64 + hf * 32 + l) * kStatLd + which * 16 + 4 * j + i];
+      a.parts[size_t(threadIdx.x) * (size_t(gridDim.x) * gridDim.y) + size_t(blockIdx.y) * gridDim.x + blockIdx.x] = t;
+    }
+  }
+}
+
 }  // namespace
 
 // the MFMA path writes one raw [16][64] accumulator slab (1024 floats) per workgroup
@@ -558,7 +769,7 @@ extern "C" size_t sept_conv1_prep_floats(void) { return kPrepFloats; }
 namespace {
 int conv1_forward_impl(const float* x, const float* w, const float* bias, float* wprep, void* y, float* stats, int B,
                        int H, int W, hipStream_t st) {
-  hipLaunchKernelGGL(sept_conv1_prep_kernel, dim3((kTaps * kC + 255) / 256), dim3(256), 0, st, w, bias, wprep);
+  if (w) hipLaunchKernelGGL(sept_conv1_prep_kernel, dim3((kTaps * kC + 255) / 256), dim3(256), 0, st, w, bias, wprep);
   const size_t smem_m = std::max(sizeof(float) * size_t(kFwdRows + 4) * (W + 4), stats ? sizeof(float) * 256 * kStatLd : 0);
   static const bool scalar_fwd = getenv("SEPT_CONV1_SCALAR") != nullptr;
   if (smem_m <= 64 * 1024 && (!scalar_fwd || stats)) {
@@ -584,7 +795,7 @@ extern "C" int sept_conv1_forward(const float* x, const float* w, const float* b
                                   int W, void* stream) {
   if (int e = conv1_check("sept_conv1_forward", B, H, W)) return e;
   if (B == 0) return SEPT_OK;
-  SEPT_REQUIRE(x && w && y && wprep, SEPT_ERR_INVALID, "sept_conv1_forward: null argument");
+  SEPT_REQUIRE(x && y && wprep, SEPT_ERR_INVALID, "sept_conv1_forward: null argument");
   return conv1_forward_impl(x, w, bias, wprep, y, nullptr, B, H, W, static_cast<hipStream_t>(stream));
 }
 
@@ -595,7 +806,7 @@ extern "C" int sept_conv1_stats_parts(int B, int H) { return B * ((H + kFwdRows 
 extern "C" int sept_conv1_forward_stats(const float* x, const float* w, const float* bias, float* wprep, void* y,
                                         float* stats, int B, int H, int W, void* stream) {
   if (int e = conv1_check("sept_conv1_forward_stats", B, H, W)) return e;
-  SEPT_REQUIRE(B > 0 && x && w && y && wprep && stats, SEPT_ERR_INVALID, "sept_conv1_forward_stats: null argument / empty batch");
+  SEPT_REQUIRE(B > 0 && x && y && wprep && stats, SEPT_ERR_INVALID, "sept_conv1_forward_stats: null argument / empty batch");
   return conv1_forward_impl(x, w, bias, wprep, y, stats, B, H, W, static_cast<hipStream_t>(stream));
 }
 
@@ -603,10 +814,11 @@ extern "C" int sept_conv1_backward_data(const void* dy, const float* w, float* w
                                         int W, void* stream) {
   if (int e = conv1_check("sept_conv1_backward_data", B, H, W)) return e;
   if (B == 0) return SEPT_OK;
-  SEPT_REQUIRE(dy && w && dx && wprep, SEPT_ERR_INVALID, "sept_conv1_backward_data: null argument");
+  SEPT_REQUIRE(dy && dx && wprep, SEPT_ERR_INVALID, "sept_conv1_backward_data: null argument");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(sept_conv1_prep_kernel, dim3((kTaps * kC + 255) / 256), dim3(256), 0, st, w,
-                     static_cast<const float*>(nullptr), wprep);
+  if (w)
+    hipLaunchKernelGGL(sept_conv1_prep_kernel, dim3((kTaps * kC + 255) / 256), dim3(256), 0, st, w,
+                       static_cast<const float*>(nullptr), wprep);
   if (W * 4 <= 512 && H >= 1) {  // streaming MFMA form: a dy row fits two 16-byte chunks per lane
     const int NP = (W + 4 + 31) / 32 * 32;
     const size_t smem_s = size_t(2) * NP * kDyPS + size_t(kRing) * NP * kZS * sizeof(float);
@@ -653,4 +865,96 @@ extern "C" int sept_conv1_backward_weight(const float* x, const void* dy, float*
   const int n = kC * kTaps + kC;
   hipLaunchKernelGGL(sept_conv1_wgrad_finalize_kernel, dim3((n + 3) / 4), dim3(256), 0, st, ws, grid, dw, db);
   return sept::launch_check("sept_conv1_backward_weight");
+}
+
+// ---- layer 1 without the pre-activation tensor: entry points ----
+extern "C" int sept_conv1_fused_supported(int H, int W) {
+  return H > 0 && W > 0 && H % 2 == 0 && W % 16 == 0 && sizeof(float) * size_t(kFwdRows + 4) * (W + 4) <= 64 * 1024 &&
+         sizeof(float) * 256 * kStatLd <= 64 * 1024;
+}
+
+namespace {
+size_t l1_smem(int W) { return std::max(sizeof(float) * size_t(kFwdRows + 4) * (W + 4), sizeof(float) * 256 * kStatLd); }
+int l1_check(const char* who, int B, int H, int W) {
+  if (int e = conv1_check(who, B, H, W)) return e;
+  SEPT_REQUIRE(sept_conv1_fused_supported(H, W), SEPT_ERR_UNSUPPORTED,
+               "%s: H=%d W=%d (needs an even H and W %% 16 == 0; use the unfused entry points otherwise)", who, H, W);
+  return SEPT_OK;
+}
+}  // namespace
+
+// BatchNorm statistics partials of conv1's (bf16-rounded) output WITHOUT writing it: stats[64][sept_conv1_stats_parts(B, H)]
+extern "C" int sept_conv1_stats_only(const float* x, const float* w, const float* bias, float* wprep, float* stats, int B,
+                                     int H, int W, void* stream) {
+  if (int e = conv1_check("sept_conv1_stats_only", B, H, W)) return e;
+  SEPT_REQUIRE(B > 0 && x && wprep && stats, SEPT_ERR_INVALID, "sept_conv1_stats_only: null argument / empty batch");
+  const size_t smem_m = std::max(sizeof(float) * size_t(kFwdRows + 4) * (W + 4), sizeof(float) * 256 * kStatLd);
+  SEPT_REQUIRE(smem_m <= 64 * 1024, SEPT_ERR_UNSUPPORTED, "sept_conv1_stats_only: W=%d is too wide", W);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (w) hipLaunchKernelGGL(sept_conv1_prep_kernel, dim3((kTaps * kC + 255) / 256), dim3(256), 0, st, w, bias, wprep);
+  hipLaunchKernelGGL((sept_conv1_fwd_mfma_kernel<true, false>), dim3((H + kFwdRows - 1) / kFwdRows, B), dim3(256), smem_m, st,
+                     x, static_cast<const float*>(wprep), static_cast<bf16*>(nullptr), stats, B, H, W);
+  return sept::launch_check("sept_conv1_fwd_mfma_kernel<stats only>");
+}
+
+extern "C" int sept_conv1_bn_relu_pool_forward(const float* x, const float* w, const float* bias, float* wprep,
+                                               const float* mean, const float* invstd, const float* gamma,
+                                               const float* beta, const float* dropscale, void* y_pooled, int B, int H,
+                                               int W, void* stream) {
+  if (int e = l1_check("sept_conv1_bn_relu_pool_forward", B, H, W)) return e;
+  if (B == 0) return SEPT_OK;
+  SEPT_REQUIRE(x && wprep && mean && invstd && gamma && beta && y_pooled, SEPT_ERR_INVALID,
+               "sept_conv1_bn_relu_pool_forward: null argument");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (w) hipLaunchKernelGGL(sept_conv1_prep_kernel, dim3((kTaps * kC + 255) / 256), dim3(256), 0, st, w, bias, wprep);
+  L1Args a{};
+  a.x = x; a.wprep = wprep; a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.beta = beta; a.drop = dropscale;
+  a.y = static_cast<bf16*>(y_pooled); a.B = B; a.H = H; a.W = W;
+  hipLaunchKernelGGL(sept_conv1_l1_kernel<kL1Fwd>, dim3((H + kFwdRows - 1) / kFwdRows, B), dim3(256), l1_smem(W), st, a);
+  return sept::launch_check("sept_conv1_l1_kernel<forward>");
+}
+
+// partials[64][sept_conv1_stats_parts(B, H)] of (sum g, sum g * xhat), to be finished by sept_bn_bwd_sums_from_partials
+extern "C" int sept_conv1_bn_relu_pool_backward_reduce(const float* x, const float* w, const float* bias, float* wprep,
+                                                       const void* dy_pooled, const float* mean, const float* invstd,
+                                                       const float* gamma, const float* beta, const float* dropscale,
+                                                       float* partials, int B, int H, int W, void* stream) {
+  if (int e = l1_check("sept_conv1_bn_relu_pool_backward_reduce", B, H, W)) return e;
+  SEPT_REQUIRE(B > 0 && x && wprep && dy_pooled && mean && invstd && gamma && beta && partials, SEPT_ERR_INVALID,
+               "sept_conv1_bn_relu_pool_backward_reduce: null argument / empty batch");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (w) hipLaunchKernelGGL(sept_conv1_prep_kernel, dim3((kTaps * kC + 255) / 256), dim3(256), 0, st, w, bias, wprep);
+  L1Args a{};
+  a.x = x; a.wprep = wprep; a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.beta = beta; a.drop = dropscale;
+  a.dy = static_cast<const bf16*>(dy_pooled); a.parts = partials; a.B = B; a.H = H; a.W = W;
+  hipLaunchKernelGGL(sept_conv1_l1_kernel<kL1BwdReduce>, dim3((H + kFwdRows - 1) / kFwdRows, B), dim3(256), l1_smem(W), st, a);
+  return sept::launch_check("sept_conv1_l1_kernel<backward reduce>");
+}
+
+extern "C" int sept_conv1_bn_relu_pool_backward_apply(const float* x, const float* w, const float* bias, float* wprep,
+                                                      const void* dy_pooled, const float* mean, const float* invstd,
+                                                      const float* gamma, const float* beta, const float* dropscale,
+                                                      const float* sums, double n_total, void* dpre, int B, int H, int W,
+                                                      void* stream) {
+  if (int e = l1_check("sept_conv1_bn_relu_pool_backward_apply", B, H, W)) return e;
+  SEPT_REQUIRE(B > 0 && x && wprep && dy_pooled && mean && invstd && gamma && beta && sums && dpre && n_total > 0,
+               SEPT_ERR_INVALID, "sept_conv1_bn_relu_pool_backward_apply: null argument / empty batch");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (w) hipLaunchKernelGGL(sept_conv1_prep_kernel, dim3((kTaps * kC + 255) / 256), dim3(256), 0, st, w, bias, wprep);
+  L1Args a{};
+  a.x = x; a.wprep = wprep; a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.beta = beta; a.drop = dropscale;
+  a.dy = static_cast<const bf16*>(dy_pooled); a.dpre = static_cast<bf16*>(dpre); a.sums = sums;
+  a.inv_n = float(1.0 / n_total); a.B = B; a.H = H; a.W = W;
+  hipLaunchKernelGGL(sept_conv1_l1_kernel<kL1BwdApply>, dim3((H + kFwdRows - 1) / kFwdRows, B), dim3(256), l1_smem(W), st, a);
+  return sept::launch_check("sept_conv1_l1_kernel<backward apply>");
+}
+
+// The operand form of conv1's weights (sept_conv1_prep_floats() floats): built by every entry point above from
+// (w, bias) unless it is called with w == NULL, which means "wprep already holds it" -- a caller that keeps the
+// operands of unchanged weights (a frozen model: for good; a trainable one: per optimiser step) builds them once here.
+extern "C" int sept_conv1_prep(const float* w, const float* bias, float* wprep, void* stream) {
+  SEPT_REQUIRE(w && wprep, SEPT_ERR_INVALID, "sept_conv1_prep: null argument");
+  hipLaunchKernelGGL(sept_conv1_prep_kernel, dim3((kTaps * kC + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), w,
+                     bias, wprep);
+  return sept::launch_check("sept_conv1_prep_kernel");
 }

@@ -128,6 +128,13 @@ SIGNATURES = {
                               c_void_p]),
     "sept_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float, c_float,
                                c_float, c_int, c_float, c_void_p]),
+    "sept_conv1_prep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sept_conv1_fused_supported": (c_int, [c_int, c_int]),
+    "sept_conv1_stats_only": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p]),
+    "sept_conv1_bn_relu_pool_forward": (c_int, [c_void_p] * 10 + [c_int] * 3 + [c_void_p]),
+    "sept_conv1_bn_relu_pool_backward_reduce": (c_int, [c_void_p] * 11 + [c_int] * 3 + [c_void_p]),
+    "sept_bn_bwd_sums_from_partials": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sept_conv1_bn_relu_pool_backward_apply": (c_int, [c_void_p] * 11 + [c_double, c_void_p] + [c_int] * 3 + [c_void_p]),
     "sept_sgd_step_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_float, c_float, c_float, c_void_p]),
     "sept_adam_step_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_float, c_float, c_float,
                                    c_float, c_void_p, c_float, c_void_p]),

@@ -69,6 +69,14 @@ def _gru_cat_weights(wif, wir, bif, bir, layer, C, Wd):
     return wcat, bcat, wcatT
 
 
+def _conv1_operand(cv):
+    """conv1's weights + bias in operand form, rebuilt only when either parameter changed (one launch per optimiser
+    step for a trainable layer, one for good for a frozen one -- round 1 rebuilt it in every conv1 call, 5 per step)"""
+    if cv.bias is None:
+        return _cached("conv1prep", cv.weight, lambda: ops.conv1_prep(cv.weight, None))
+    return _cached_pair("conv1prep", cv.weight, cv.bias, lambda: ops.conv1_prep(cv.weight, cv.bias))
+
+
 def _nt_ok(K):
     return K % 32 == 0
 
@@ -179,13 +187,39 @@ def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None, gfeat=Non
         masks = _drop_masks(dev, specs)
     for li, (cv, bn, pool) in enumerate(zip(P.convs, P.bns, P.pools)):
         cout = cv.weight.shape[0]
+        if li == 0 and pool == 2 and not _SYNC_BN["on"] and ops.conv1_fused_supported(H, W) and \
+                (L1_FUSED == "always" or (L1_FUSED == "eval" and not bn.training and not need_grad)):
+            # layer 1 without its 32-channel pre-activation tensor (16x the input): conv1 -> BatchNorm -> ReLU -> pool
+            # -> dropout in registers.  With running statistics (inference) that is ONE pass (67 us where conv1 +
+            # BatchNorm take 57 + 44 at 224 windows).  In training it needs a statistics-only pass first and the
+            # backward pass recomputes conv1 twice more; measured (round 2, gpurun_out/r2f): each conv1 evaluation costs
+            # ~40 us of VALU work (im2col + hi/lo operand split), so four of them (43 + 67 + 196 + 192 us) lose to
+            # streaming the 229 MB tensor (70 + 44 + 41 + 85 us) -- SEPT_L1_FUSED=always keeps that form testable.
+            mom = bn.momentum if bn.momentum is not None else 0.1
+            c1p = _conv1_operand(cv)
+            if bn.training:
+                mean, invstd = ops.conv1_stats_only(x, cv.weight, cv.bias, bn.running_mean, bn.running_var,
+                                                    bn.num_batches_tracked, mom, bn.eps, prep=c1p)
+            else:
+                mean, invstd = ops.bn_eval_stats(bn.running_mean, bn.running_var, bn.eps)
+            drop = None
+            if train and (P.drop_ps[li] > 0 or "drop2d" in inj):
+                d2 = inj.get("drop2d")
+                drop = d2[li] if d2 is not None else masks[("c", li)]
+            out = ops.conv1_bn_relu_pool_forward(x, cv.weight, cv.bias, mean, invstd, bn.weight, bn.bias, drop, prep=c1p)
+            S.blocks.append(SimpleNamespace(inp=None, pre=None, out=out, mean=mean, invstd=invstd, drop=drop, pool=pool, h=h,
+                                            w=w, bn_train=bn.training, sync=False, l1_fused=True))
+            act = out
+            h, w = h // pool, w // pool
+            continue
         fused_stats = li == 0 and bn.training and not _SYNC_BN["on"] and W + 4 <= 512
         if fused_stats:   # conv1 leaves the statistics partials of its output: no BN pass over 64 B/pixel
             pre, mean, invstd = ops.conv1_forward_stats(x, cv.weight, cv.bias, bn.running_mean, bn.running_var,
                                                         bn.num_batches_tracked,
-                                                        bn.momentum if bn.momentum is not None else 0.1, bn.eps)
+                                                        bn.momentum if bn.momentum is not None else 0.1, bn.eps,
+                                                        prep=_conv1_operand(cv))
         elif li == 0:
-            pre = ops.conv1_forward(x, cv.weight, cv.bias)
+            pre = ops.conv1_forward(x, cv.weight, cv.bias, prep=_conv1_operand(cv))
         else:
             wt = _cached("convfwd", cv.weight, lambda: ops.conv5x5_prep_weights(cv.weight, 0))
             res = None
@@ -212,7 +246,7 @@ def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None, gfeat=Non
             drop = d2[li] if d2 is not None else masks[("c", li)]
         out = ops.bn_relu_pool_forward(pre, mean, invstd, bn.weight, bn.bias, drop, pool)
         S.blocks.append(SimpleNamespace(inp=act, pre=pre, out=out, mean=mean, invstd=invstd, drop=drop, pool=pool, h=h, w=w,
-                                        bn_train=bn.training, sync=_SYNC_BN["on"] and bn.training))
+                                        bn_train=bn.training, sync=_SYNC_BN["on"] and bn.training, l1_fused=False))
         act = out
         h, w = h // pool, w // pool
     # ---- GRU: (B, T=h, D = w*C) with NHWC feature order (w, c) ----
@@ -407,6 +441,9 @@ def trunk_backward(S, P, dlogits, need_wgrad=True, need_dx=True):
 WGRAD_STREAM = os.environ.get("SEPT_WGRAD_STREAM", "1") != "0"
 # BatchNorm backward: channel sums from the pooled tensors (SEPT_BN_POOLED=0: from every window of the pre-activations)
 BN_POOLED_SUMS = os.environ.get("SEPT_BN_POOLED", "1") != "0"
+# layer 1 (conv1 + BatchNorm + ReLU + pool) without its pre-activation tensor: "eval" (default) = only with running
+# statistics and no backward pass, "always" / "never" (SEPT_L1_FUSED=1 / 0) force it
+L1_FUSED = {"0": "never", "1": "always", "always": "always", "never": "never"}.get(os.environ.get("SEPT_L1_FUSED", "eval"), "eval")
 # BatchNorm statistics of the 5x5 conv layers from the conv kernel's epilogue (SEPT_CONV_STATS=0: a separate pass)
 CONV_FUSED_STATS = os.environ.get("SEPT_CONV_STATS", "1") != "0"
 NO_WGRAD_FORK = set()
@@ -556,12 +593,19 @@ def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq, go
         if not blk.bn_train:
             raise SeptError("backward through an eval-mode BatchNorm is not implemented on the HIP path")
         want_bn = need_wgrad and bn.weight.requires_grad
-        dpre, dgamma, dbeta = ops.bn_relu_pool_backward(dact, blk.pre, blk.mean, blk.invstd, bn.weight, bn.bias,
-                                                        blk.drop, blk.pool, need_param_grads=want_bn,
-                                                        sync_group=_SYNC_BN["group"], sync=blk.sync,
-                                                        y=blk.out if BN_POOLED_SUMS else None,
-                                                        out_gamma=gout(bn.weight) if want_bn else None,
-                                                        out_beta=gout(bn.bias) if want_bn else None)
+        if blk.l1_fused:
+            dpre, dgamma, dbeta = ops.conv1_bn_relu_pool_backward(S.x, cv.weight, cv.bias, dact, blk.mean, blk.invstd,
+                                                                  bn.weight, bn.bias, blk.drop, need_param_grads=want_bn,
+                                                                  out_gamma=gout(bn.weight) if want_bn else None,
+                                                                  out_beta=gout(bn.bias) if want_bn else None,
+                                                                  prep=_conv1_operand(cv))
+        else:
+            dpre, dgamma, dbeta = ops.bn_relu_pool_backward(dact, blk.pre, blk.mean, blk.invstd, bn.weight, bn.bias,
+                                                            blk.drop, blk.pool, need_param_grads=want_bn,
+                                                            sync_group=_SYNC_BN["group"], sync=blk.sync,
+                                                            y=blk.out if BN_POOLED_SUMS else None,
+                                                            out_gamma=gout(bn.weight) if want_bn else None,
+                                                            out_beta=gout(bn.bias) if want_bn else None)
         if want_bn:
             put(bn.weight, dgamma)
             put(bn.bias, dbeta)
@@ -572,7 +616,7 @@ def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq, go
                 put(cv.weight, dw)
                 put(cv.bias, db)
             if need_dx:
-                dx = ops.conv1_backward_data(dpre, cv.weight)
+                dx = ops.conv1_backward_data(dpre, cv.weight, prep=_conv1_operand(cv))
         else:
             if need_wgrad and cv.weight.requires_grad:
                 put(cv.weight, sq.big(lambda blk=blk, dpre=dpre: ops.conv5x5_backward_weight(blk.inp, dpre,

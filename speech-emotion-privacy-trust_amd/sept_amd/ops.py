@@ -115,28 +115,44 @@ def workspace(name: str, nfloats: int, device) -> torch.Tensor:
     return t
 
 
-def conv1_forward(x, w, bias=None):
+def conv1_prep(w, bias=None):
+    """conv1's weights in the operand form its kernels read (one tiny launch); pass it as `prep=` to the conv1 entry
+    points to skip their own rebuild -- functional.py keeps it per parameter version."""
+    require_cuda(w)
+    wp = torch.empty(lib.sept_conv1_prep_floats(), dtype=torch.float32, device=w.device)
+    check(lib.sept_conv1_prep(w.detach().data_ptr(), _p(bias), wp.data_ptr(), _s(w)), "sept_conv1_prep")
+    return wp
+
+
+def _c1w(x, w, prep, name="conv1_prep_fwd"):
+    """(weight pointer, operand buffer) for a conv1 entry point: a prepared operand replaces the rebuild"""
+    if prep is not None:
+        return 0, prep
+    return w.data_ptr(), workspace(name, lib.sept_conv1_prep_floats(), x.device)
+
+
+def conv1_forward(x, w, bias=None, prep=None):
     """x (B,H,W) fp32, w (32,1,5,5) fp32 -> (B,H,W,32) bf16."""
     require_cuda(x, w)
     B, H, W = x.shape
     y = torch.empty((B, H, W, 32), dtype=torch.bfloat16, device=x.device)
-    wp = workspace("conv1_prep_fwd", lib.sept_conv1_prep_floats(), x.device)
-    check(lib.sept_conv1_forward(x.data_ptr(), w.data_ptr(), _p(bias), wp.data_ptr(), y.data_ptr(), B, H, W, _s(x)),
+    wptr, wp = _c1w(x, w, prep)
+    check(lib.sept_conv1_forward(x.data_ptr(), wptr, _p(bias), wp.data_ptr(), y.data_ptr(), B, H, W, _s(x)),
           "sept_conv1_forward")
     return y
 
 
 def conv1_forward_stats(x, w, bias, bn_running_mean=None, bn_running_var=None, bn_num_batches_tracked=None,
-                        momentum=0.1, eps=1e-5):
+                        momentum=0.1, eps=1e-5, prep=None):
     """conv1 forward that also yields the batch statistics of its output: (y bf16 (B,H,W,32), mean, invstd);
     the following BatchNorm needs no statistics pass (and its running buffers are updated here)."""
     require_cuda(x, w)
     B, H, W = x.shape
     y = torch.empty((B, H, W, 32), dtype=torch.bfloat16, device=x.device)
-    wp = workspace("conv1_prep_fwd", lib.sept_conv1_prep_floats(), x.device)
+    wptr, wp = _c1w(x, w, prep)
     nparts = lib.sept_conv1_stats_parts(B, H)
     parts = workspace("conv1_stats", nparts * 64, x.device)
-    check(lib.sept_conv1_forward_stats(x.data_ptr(), w.data_ptr(), _p(bias), wp.data_ptr(), y.data_ptr(), parts.data_ptr(),
+    check(lib.sept_conv1_forward_stats(x.data_ptr(), wptr, _p(bias), wp.data_ptr(), y.data_ptr(), parts.data_ptr(),
                                        B, H, W, _s(x)), "sept_conv1_forward_stats")
     mean = torch.empty(32, dtype=torch.float32, device=x.device)
     invstd = torch.empty_like(mean)
@@ -146,12 +162,78 @@ def conv1_forward_stats(x, w, bias, bn_running_mean=None, bn_running_var=None, b
     return y, mean, invstd
 
 
-def conv1_backward_data(dy, w):
+def conv1_fused_supported(H, W):
+    return bool(lib.sept_conv1_fused_supported(int(H), int(W)))
+
+
+def conv1_stats_only(x, w, bias, bn_running_mean=None, bn_running_var=None, bn_num_batches_tracked=None, momentum=0.1,
+                     eps=1e-5, prep=None):
+    """Batch statistics of conv1's output without storing it: (mean, invstd); the running buffers are updated."""
+    require_cuda(x, w)
+    B, H, W = x.shape
+    wptr, wp = _c1w(x, w, prep)
+    nparts = lib.sept_conv1_stats_parts(B, H)
+    parts = workspace("conv1_stats", nparts * 64, x.device)
+    check(lib.sept_conv1_stats_only(x.data_ptr(), wptr, _p(bias), wp.data_ptr(), parts.data_ptr(), B, H, W, _s(x)),
+          "sept_conv1_stats_only")
+    mean = torch.empty(32, dtype=torch.float32, device=x.device)
+    invstd = torch.empty_like(mean)
+    check(lib.sept_bn_stats_from_partials(parts.data_ptr(), nparts, B * H * W, 32, mean.data_ptr(), invstd.data_ptr(),
+                                          _p(bn_running_mean), _p(bn_running_var), _p(bn_num_batches_tracked),
+                                          float(momentum), float(eps), _s(x)), "sept_bn_stats_from_partials")
+    return mean, invstd
+
+
+def conv1_bn_relu_pool_forward(x, w, bias, mean, invstd, gamma, beta, dropscale=None, prep=None):
+    """conv1 -> BatchNorm (given statistics) -> ReLU -> MaxPool 2x2 -> Dropout2d scale: x (B,H,W) fp32 ->
+    (B,H/2,W/2,32) bf16, the 32-channel pre-activation tensor never touching HBM."""
+    require_cuda(x, w, mean, invstd, gamma, beta)
+    B, H, W = x.shape
+    y = torch.empty((B, H // 2, W // 2, 32), dtype=torch.bfloat16, device=x.device)
+    wptr, wp = _c1w(x, w, prep)
+    check(lib.sept_conv1_bn_relu_pool_forward(x.data_ptr(), wptr, _p(bias), wp.data_ptr(), mean.data_ptr(),
+                                              invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _p(dropscale),
+                                              y.data_ptr(), B, H, W, _s(x)), "sept_conv1_bn_relu_pool_forward")
+    return y
+
+
+def conv1_bn_relu_pool_backward(x, w, bias, dy, mean, invstd, gamma, beta, dropscale=None, need_param_grads=True,
+                                sync_group=None, sync=False, out_gamma=None, out_beta=None, prep=None):
+    """Backward of the fused layer-1 block by recomputation: dy (B,H/2,W/2,32) bf16 -> (dpre (B,H,W,32) bf16, dgamma,
+    dbeta).  Two passes over x (14 MB at the bench shape) + dy instead of passes over the 229 MB pre-activations."""
+    require_cuda(x, w, dy)
+    B, H, W = x.shape
+    wptr, wp = _c1w(x, w, prep)
+    nparts = lib.sept_conv1_stats_parts(B, H)
+    parts = workspace("conv1_bwd_parts", nparts * 64, x.device)
+    check(lib.sept_conv1_bn_relu_pool_backward_reduce(x.data_ptr(), wptr, _p(bias), wp.data_ptr(), dy.data_ptr(),
+                                                      mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                                      _p(dropscale), parts.data_ptr(), B, H, W, _s(x)),
+          "sept_conv1_bn_relu_pool_backward_reduce")
+    sums = torch.empty(64, dtype=torch.float32, device=x.device)
+    dgamma = dbeta = None
+    if need_param_grads:
+        dgamma = torch.empty(32, dtype=torch.float32, device=x.device) if out_gamma is None else out_gamma
+        dbeta = torch.empty(32, dtype=torch.float32, device=x.device) if out_beta is None else out_beta
+    check(lib.sept_bn_bwd_sums_from_partials(parts.data_ptr(), nparts, 32, sums.data_ptr(), _p(dgamma), _p(dbeta), _s(x)),
+          "sept_bn_bwd_sums_from_partials")
+    world = _allreduce_sum(sums, sync_group) if sync else 1
+    dpre = torch.empty((B, H, W, 32), dtype=torch.bfloat16, device=x.device)
+    check(lib.sept_conv1_bn_relu_pool_backward_apply(x.data_ptr(), 0 if prep is not None else w.data_ptr(), _p(bias),
+                                                     wp.data_ptr(), dy.data_ptr(),
+                                                     mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                                     _p(dropscale), sums.data_ptr(), float(B) * H * W * world,
+                                                     dpre.data_ptr(), B, H, W, _s(x)),
+          "sept_conv1_bn_relu_pool_backward_apply")
+    return dpre, dgamma, dbeta
+
+
+def conv1_backward_data(dy, w, prep=None):
     require_cuda(dy, w)
     B, H, W, _ = dy.shape
     dx = torch.empty((B, H, W), dtype=torch.float32, device=dy.device)
-    wp = workspace("conv1_prep_bwd", lib.sept_conv1_prep_floats(), dy.device)
-    check(lib.sept_conv1_backward_data(dy.data_ptr(), w.data_ptr(), wp.data_ptr(), dx.data_ptr(), B, H, W, _s(dy)),
+    wptr, wp = _c1w(dy, w, prep, "conv1_prep_bwd")
+    check(lib.sept_conv1_backward_data(dy.data_ptr(), wptr, wp.data_ptr(), dx.data_ptr(), B, H, W, _s(dy)),
           "sept_conv1_backward_data")
     return dx
 

@@ -158,7 +158,7 @@ class _TrainerBase:
         draw per step for the whole global batch): rank 0's base seed is broadcast and adopted, so
         the common `manual_seed(base + rank)` idiom cannot silently give each shard its own epsilon."""
         dev = self.flat.flat.device
-        base = int(torch.initial_seed() if seed is None else seed)
+        base = int(torch.initial_seed() if seed is None else seed) & 0x7FFFFFFFFFFFFFFF   # fits the int64 broadcast
         if self.world > 1:
             backend = torch.distributed.get_backend(self.pg)
             t = torch.tensor([base], dtype=torch.int64, device=dev if "nccl" in str(backend) else "cpu")

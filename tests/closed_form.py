@@ -47,13 +47,13 @@ def closed_form_state(module: torch.nn.Module, prefix: str = "") -> dict:
             v = 1.0 + 0.3 * u
         elif "weight" in leaf and t.dim() == 1:        # BatchNorm gamma
             v = 1.0 + 0.3 * u
+        elif leaf == "locs":                            # cloak_noise: (1, W, F) tensors, not matrices
+            v = 0.2 * u
+        elif leaf == "rhos":
+            v = -2.0 + 0.5 * u                          # scales() between 0.07 and 0.5
         elif t.dim() >= 2:                              # conv / linear / recurrent matrices
             kind = ("conv" if "conv" in name else "rnn" if "rnn" in name else "head" if "pred_" in name else "dense")
             v = u * (GAINS[kind] * math.sqrt(3.0 / t[0].numel()))
-        elif leaf == "locs":
-            v = 0.2 * u
-        elif leaf == "rhos":
-            v = -2.0 + 0.5 * u
         else:                                           # biases, BatchNorm beta
             v = 0.1 * u
         out[name] = v.to(t.dtype)

@@ -197,3 +197,50 @@ def test_conv5x5_forward_with_fused_bn_statistics(B, H, W, cin, cout):
     # the data-gradient shapes (cin > cout) have no statistics form
     assert ops.conv5x5_forward_stats(torch.zeros(1, 8, 8, 64, dtype=torch.bfloat16).cuda(),
                                      torch.zeros(25, 32, 64, dtype=torch.bfloat16).cuda(), None) is None
+
+
+@pytest.mark.parametrize("B,H,W", [(3, 200, 80), (2, 200, 128), (2, 34, 16), (5, 16, 48)])
+@pytest.mark.parametrize("drop", [False, True])
+def test_layer1_without_preactivation_tensor_equals_the_separate_kernels(B, H, W, drop):
+    """conv1 -> BatchNorm -> ReLU -> MaxPool 2x2 -> Dropout2d by recomputation (sept_conv1_stats_only,
+    sept_conv1_bn_relu_pool_forward / _backward_reduce / _backward_apply) against the separate conv1 + BatchNorm
+    kernels, which the tests above hold to torch: same statistics, same pooled output, same gradient of the
+    pre-activations, same dgamma / dbeta -- including a channel with a tiny and one with a negative gamma."""
+    from sept_amd import ops
+    assert ops.conv1_fused_supported(H, W)
+    assert not ops.conv1_fused_supported(H + 1, W) and not ops.conv1_fused_supported(H, W + 8)
+    g = torch.Generator().manual_seed(H * W)
+    x = (torch.randn(B, H, W, generator=g) * 1.2 + 0.1).cuda()
+    w = (torch.randn(32, 1, 5, 5, generator=g) * 0.2).cuda()
+    bias = (torch.randn(32, generator=g) * 0.1).cuda()
+    gamma = 1 + 0.3 * torch.randn(32, generator=g)
+    gamma[3], gamma[20] = 1e-5, -0.7
+    gamma, beta = gamma.cuda(), (0.2 * torch.randn(32, generator=g)).cuda()
+    dmask = ((torch.rand(B, 32, generator=g) > 0.2).float() * 1.25).cuda() if drop else None
+    dy = torch.randn(B, H // 2, W // 2, 32, generator=g).bfloat16().cuda()
+    # the separate kernels
+    rm, rv, nbt = torch.zeros(32).cuda(), torch.ones(32).cuda(), torch.zeros((), dtype=torch.int64).cuda()
+    pre, mean, invstd = ops.conv1_forward_stats(x, w, bias, rm, rv, nbt)
+    y = ops.bn_relu_pool_forward(pre, mean, invstd, gamma, beta, dmask, 2)
+    dpre, dgamma, dbeta = ops.bn_relu_pool_backward(dy, pre, mean, invstd, gamma, beta, dmask, 2)
+    # by recomputation
+    rm2, rv2, nbt2 = torch.zeros(32).cuda(), torch.ones(32).cuda(), torch.zeros((), dtype=torch.int64).cuda()
+    mean2, invstd2 = ops.conv1_stats_only(x, w, bias, rm2, rv2, nbt2)
+    assert torch.equal(mean, mean2) and torch.equal(invstd, invstd2) and torch.equal(rm, rm2) and torch.equal(rv, rv2)
+    assert int(nbt2) == 1
+    y2 = ops.conv1_bn_relu_pool_forward(x, w, bias, mean, invstd, gamma, beta, dmask)
+    assert y2.shape == y.shape
+    differ = (y2.float() - y.float()).abs() > 0
+    # the two paths fold the BatchNorm affine slightly differently (fma placement): a result may round the other way
+    assert differ.float().mean() < 1e-3, float(differ.float().mean())
+    assert ((y2.float() - y.float()).abs() <= y.float().abs() * 2 ** -7 + 1e-6).all()
+    dpre2, dgamma2, dbeta2 = ops.conv1_bn_relu_pool_backward(x, w, bias, dy, mean, invstd, gamma, beta, dmask)
+    assert dpre2.shape == dpre.shape
+    sg, sb = float(dgamma.abs().max()), float(dbeta.abs().max())
+    assert torch.allclose(dgamma2, dgamma, rtol=1e-3, atol=1e-4 * sg), (dgamma2 - dgamma).abs().max()
+    assert torch.allclose(dbeta2, dbeta, rtol=1e-3, atol=1e-4 * sb), (dbeta2 - dbeta).abs().max()
+    d, d2 = dpre.float(), dpre2.float()
+    # a window whose maximum is decided differently (the affine's last bit) moves one gradient to a neighbour
+    moved = ((d - d2).abs() > d.abs() * 2 ** -6 + 1e-3 * float(d.abs().max())).float().mean()
+    assert moved < 1e-3, float(moved)
+    assert float((d - d2).norm() / d.norm()) < 2e-2

@@ -74,6 +74,11 @@ def test_two_ranks_with_sync_bn_equal_global_batch_step():
     worst = 0.0
     for n in full:
         d_full, d_dp = full[n] - before[n], dp[n] - before[n]
+        if n.endswith(("conv.1.0.bias", "conv.1.5.bias", "conv.1.10.bias")):
+            # a conv bias in front of a train-mode BatchNorm: zero gradient up to summation noise, so the update is
+            # weight decay plus that noise -- compared absolutely (lr 0.05 x noise of ~1e-5)
+            assert float((d_dp - d_full).abs().max()) < 5e-6, n
+            continue
         if float(d_full.norm()) < 1e-9:
             assert float(d_dp.norm()) < 1e-6, n
             continue
