@@ -262,6 +262,21 @@ int sept_cloak_backward(const float* dxa, const float* dxb, float gscale_b, cons
  *   sept_bn_bwd_sums_from_partials         : -> sums[2C] (+ dgamma, dbeta); all-reducible for sync-BN
  *   sept_conv1_bn_relu_pool_backward_apply : dpre (B, H, W, 32) bf16, the gradient sept_conv1_backward_* consume
  * wprep: sept_conv1_prep_floats() floats of scratch, as for sept_conv1_forward. */
+/* BatchNorm backward sums in the epilogue of the data-gradient conv that PRODUCES dy (baseline_models.py:172-188,
+ * backward): sept_conv5x5_dgrad_bnsums = sept_conv5x5_forward on data-gradient operands (wt from
+ * sept_conv5x5_prep_weights mode 1, cin > cout) that also leaves partials[2*cout][sept_conv5x5_stats_parts(B, H, W,
+ * cin, cout)] of (sum g, sum g * xhat) of the BatchNorm whose pooled output is `ypool` (B, H, W, cout) bf16, formed
+ * as in sept_bn_relu_pool_backward's pooled path; sept_bn_relu_pool_backward_presummed then finishes that
+ * BatchNorm's backward without a reduce pass (chunks with |gamma| < 1e-3 are re-summed from the windows of x). */
+int sept_conv5x5_bwsums_parts(int B, int H, int W, int cin, int cout);   /* 0: no such form for this shape */
+int sept_conv5x5_dgrad_bnsums(const void* dy_out, const void* wt, void* dx_out, const void* ypool, const float* bn_gamma,
+                              const float* bn_beta, const float* dropscale, float* partials, int B, int H, int W, int cin,
+                              int cout, void* stream);
+int sept_bn_relu_pool_backward_presummed(const void* dy, const void* x, const float* mean, const float* invstd,
+                                         const float* gamma, const float* beta, const float* dropscale,
+                                         const float* partials, int nparts, float* ws, void* dx, float* dgamma,
+                                         float* dbeta, int B, int H, int W, int C, int pool, void* stream);
+
 /* conv1's weights in operand form: every sept_conv1_* entry point builds it into `wprep` from (w, bias) unless called
  * with w == NULL ("wprep is current"); sept_conv1_prep builds it explicitly so a caller can keep it across calls. */
 int sept_conv1_prep(const float* w, const float* bias, float* wprep, void* stream);

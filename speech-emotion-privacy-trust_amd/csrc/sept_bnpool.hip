@@ -321,6 +321,56 @@ __global__ __launch_bounds__(256) void sept_bn_bwd_reduce_pooled_kernel(BnBwdArg
   block_reduce_2c<CPP>(s1, s2, a.ws, gridDim.x, lds);
 }
 
+// Window-path sums for the channel chunks with a tiny |gamma| ONLY (every other thread leaves at once, and a
+// workgroup without such a chunk writes nothing): the companion of sums that a producer kernel formed from the pooled
+// tensors (sept_conv5x5_dgrad_bnsums), which cannot serve those channels.
+template <int CPP, int P>
+__global__ __launch_bounds__(256) void sept_bn_bwd_reduce_small_kernel(BnBwdArgs a) {
+  __shared__ float lds[256 * 16];
+  const long n_items = long(a.B) * (a.H / P) * (a.W / P) * CPP;
+  const int chunk = threadIdx.x % CPP;
+  const f32x8 ga = loadf8(a.gamma + chunk * 8);
+  bool small = false;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) small |= !(fabsf(ga[e]) >= 1e-3f);
+  if (!__syncthreads_or(small)) return;
+  const f32x8 mu = loadf8(a.mean + chunk * 8), is = loadf8(a.invstd + chunk * 8), be = loadf8(a.beta + chunk * 8);
+  const f32x8 sc = ga * is, sh = be - mu * ga * is;
+  f32x8 s1 = {0, 0, 0, 0, 0, 0, 0, 0}, s2 = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (small) {
+    for (long i = long(blockIdx.x) * 256 + threadIdx.x; i < n_items; i += long(gridDim.x) * 256) {
+      f32x8 g, xh, xv[P * P];
+      int arg[8];
+      bn_bwd_window<CPP, P>(a, i / CPP, chunk, mu, is, sc, sh, g, xh, arg, xv);
+      s1 += g;
+      s2 += g * xh;
+    }
+  }
+  block_reduce_2c<CPP>(s1, s2, a.ws, gridDim.x, lds);
+}
+
+// totals of a channel from the producer's partials, or -- when any channel of its 8-channel chunk has a tiny |gamma| --
+// from the window-path partials of sept_bn_bwd_reduce_small_kernel
+__global__ __launch_bounds__(256) void sept_bn_bwd_finalize2_kernel(const float* parts, int nparts, float* ws, int nparts_ws,
+                                                                    const float* gamma, int C, float* dgamma,
+                                                                    float* dbeta, float* sums_out) {
+  const int c = blockIdx.x;  // one workgroup per channel
+  bool small = false;
+  for (int e = 0; e < 8; ++e) small |= !(fabsf(gamma[(c & ~7) + e]) >= 1e-3f);
+  double s1, s2;
+  channel_totals(small ? ws : parts, small ? nparts_ws : nparts, C, c, s1, s2);
+  if (threadIdx.x != 0) return;
+  float* sums = ws + size_t(kParts) * 2 * C;
+  sums[c] = float(s1);
+  sums[C + c] = float(s2);
+  if (dbeta) dbeta[c] = float(s1);
+  if (dgamma) dgamma[c] = float(s2);
+  if (sums_out) {
+    sums_out[c] = float(s1);
+    sums_out[C + c] = float(s2);
+  }
+}
+
 __global__ __launch_bounds__(256) void sept_bn_bwd_finalize_kernel(float* ws, int nparts, int C, float* dgamma,
                                                                    float* dbeta, float* sums_out, bool in_ws = true) {
   const int c = blockIdx.x;  // one workgroup per channel
@@ -502,6 +552,34 @@ extern "C" int sept_bn_relu_pool_backward(const void* dy, const void* x, const v
   if (int e = bn_bwd_launch_reduce(a, dgamma, dbeta, nullptr, st)) return e;
   if (int e = bn_bwd_launch_apply(a, st)) return e;
   return sept::launch_check("sept_bn_relu_pool_backward");
+}
+
+// Backward with the two channel sums already formed, as TRANSPOSED partials [2C][nparts], by the kernel that produced
+// dy (sept_conv5x5_dgrad_bnsums): no reduce pass over y / dy here -- only the chunks with a tiny |gamma| are re-summed
+// from the windows (a launch that exits at once when there is none), then the finalize and the apply pass.
+extern "C" int sept_bn_relu_pool_backward_presummed(const void* dy, const void* x, const float* mean, const float* invstd,
+                                                    const float* gamma, const float* beta, const float* dropscale,
+                                                    const float* partials, int nparts, float* ws, void* dx,
+                                                    float* dgamma, float* dbeta, int B, int H, int W, int C, int pool,
+                                                    void* stream) {
+  SEPT_REQUIRE(B > 0 && H > 0 && W > 0 && (pool == 1 || pool == 2) && nparts > 0, SEPT_ERR_INVALID,
+               "sept_bn_relu_pool_backward_presummed: B=%d H=%d W=%d pool=%d nparts=%d", B, H, W, pool, nparts);
+  SEPT_REQUIRE(dy && x && mean && invstd && gamma && beta && partials && ws && dx, SEPT_ERR_INVALID,
+               "sept_bn_relu_pool_backward_presummed: null argument");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  BnBwdArgs a{static_cast<const bf16*>(dy), static_cast<const bf16*>(x), nullptr, mean, invstd, gamma, beta, dropscale, ws,
+              static_cast<bf16*>(dx), B, H, W, C, pool, ws + size_t(kParts) * 2 * C, 1.0f / (float(B) * H * W)};
+  const long items = long(B) * (H / pool) * (W / pool) * (C / 8);
+  const int grid = grid_for(items);
+  if (pool == 2) {
+    SEPT_CPP_DISPATCH(C, hipLaunchKernelGGL((sept_bn_bwd_reduce_small_kernel<CPP, 2>), dim3(grid), dim3(256), 0, st, a));
+  } else {
+    SEPT_CPP_DISPATCH(C, hipLaunchKernelGGL((sept_bn_bwd_reduce_small_kernel<CPP, 1>), dim3(grid), dim3(256), 0, st, a));
+  }
+  hipLaunchKernelGGL(sept_bn_bwd_finalize2_kernel, dim3(C), dim3(256), 0, st, partials, nparts, ws, grid, gamma, C, dgamma,
+                     dbeta, static_cast<float*>(nullptr));
+  if (int e = bn_bwd_launch_apply(a, st)) return e;
+  return sept::launch_check("sept_bn_relu_pool_backward_presummed");
 }
 
 // ---- sync-BN (statistics over all ranks; SURVEY.md section 8e option 1): the fused entry points split

@@ -44,6 +44,13 @@ struct ConvArgs {
   bf16* y;            // [B][H][W][COUT]
   int B, H, W, nr_max;
   float* stats;       // STATS kernels: BatchNorm statistics partials [2*COUT][B * tiles] (sums, then sums of squares)
+  // BWSUMS kernels (data-gradient launches): the output IS the gradient of the previous block's pooled activation, so
+  // the epilogue also leaves that BatchNorm's backward sums (sum g, sum g * xhat) in `stats`, from the output tile and
+  //   ypool [B][H][W][COUT] : the pooled activation the forward pass stored at the same positions
+  //   bn_gamma, bn_beta [COUT], drop [B][COUT] (Dropout2d scale) or null
+  // exactly as sept_bn_bwd_reduce_pooled_kernel forms them (xhat = (y / drop - beta) / gamma where y > 0).
+  const bf16* ypool;
+  const float *bn_gamma, *bn_beta, *drop;
 };
 
 __host__ __device__ constexpr int conv_nr_max(int mt, int w) { return (mt + w - 2) / w + 5; }
@@ -70,10 +77,12 @@ __host__ __device__ constexpr size_t conv_stats_smem(int mt, int cout, int nthr)
 
 // (Second launch bound = waves per SIMD: the statistics form of an 8-wave shape that lives with two workgroups
 // per CU is held to the 128 VGPRs its plain form uses; shapes whose plain form needs more carry no cap.)
-template <int CINF, int COUT, int PB, int WP, int WN, int TGP, int CS, bool STATS = false>
+enum { kEpiPlain = 0, kEpiStats = 1, kEpiBwSums = 2 };
+template <int CINF, int COUT, int PB, int WP, int WN, int TGP, int CS, int EPI = kEpiPlain>
 __global__ __launch_bounds__(64 * WP * WN,
-                             (STATS && WP * WN == 8 && !(TGP == 0 && CINF >= 64 && (CS == 1 || CINF == 128))) ? 4 : 1)
+                             (EPI != kEpiPlain && WP * WN == 8 && !(TGP == 0 && CINF >= 64 && (CS == 1 || CINF == 128))) ? 4 : 1)
 void sept_conv5x5_mfma_kernel(ConvArgs a) {
+  constexpr bool STATS = EPI != kEpiPlain;   // the output tile goes through the LDS for per-channel column sums
   constexpr bool DBUF = TGP == 0;
   constexpr int TG = DBUF ? 1 : TGP;
   constexpr int CIN = CINF / CS;  // channels per slice
@@ -279,11 +288,26 @@ void sept_conv5x5_mfma_kernel(ConvArgs a) {
     {
       const int c = tid % COUT, grp = tid / COUT;
       float t1 = 0.f, t2 = 0.f;
+      if constexpr (EPI == kEpiStats) {
 #pragma unroll 8
-      for (int p = grp; p < MT; p += NGRP) {
-        const float v = float(*reinterpret_cast<const bf16*>(smem + size_t(p) * SP + c * 2));
-        t1 += v;
-        t2 += v * v;
+        for (int p = grp; p < MT; p += NGRP) {
+          const float v = float(*reinterpret_cast<const bf16*>(smem + size_t(p) * SP + c * 2));
+          t1 += v;
+          t2 += v * v;
+        }
+      } else {
+        const float d = a.drop ? a.drop[size_t(b) * COUT + c] : 1.0f;
+        const float rd = d > 0.f ? 1.0f / d : 0.f, be = a.bn_beta[c], rg = 1.0f / a.bn_gamma[c];
+        const bf16* yp = a.ypool + (size_t(b) * HW + q0) * COUT + c;
+        const int np = min(MT, HW - q0);
+#pragma unroll 8
+        for (int p = grp; p < np; p += NGRP) {
+          const float g = float(*reinterpret_cast<const bf16*>(smem + size_t(p) * SP + c * 2)) * d;
+          const float y = float(yp[size_t(p) * COUT]) * rd;
+          const float ge = y > 0.f ? g : 0.f;   // ReLU inactive (or channel dropped): no gradient
+          t1 += ge;
+          t2 += ge * (y - be) * rg;
+        }
       }
       red[(grp * 2 + 0) * COUT + c] = t1;
       red[(grp * 2 + 1) * COUT + c] = t2;
@@ -321,11 +345,12 @@ __global__ void sept_conv5x5_prep_kernel(const float* w, bf16* wt, int cout, int
 struct ConvVariant {
   int cin, cout, pb, wp, wn, tg, cs;
   const void* fn;
-  const void* fn_stats;   // the same kernel with the statistics epilogue (forward shapes only), or null
+  const void* fn_stats;   // the same kernel with the statistics epilogue (forward shapes) or the BatchNorm backward
+                          // sums epilogue (data-gradient shapes, cin > cout)
 };
 #define SEPT_CONV_VARIANT(ci, co, pb, wp, wn, tg, cs) \
   { ci, co, pb, wp, wn, tg, cs, reinterpret_cast<const void*>(&sept_conv5x5_mfma_kernel<ci, co, pb, wp, wn, tg, cs>), \
-    (ci <= co) ? reinterpret_cast<const void*>(&sept_conv5x5_mfma_kernel<ci, co, pb, wp, wn, tg, cs, (ci <= co)>) : nullptr }
+    reinterpret_cast<const void*>(&sept_conv5x5_mfma_kernel<ci, co, pb, wp, wn, tg, cs, (ci <= co) ? kEpiStats : kEpiBwSums>) }
 // Order = measured preference of tile shapes at the training shapes (tools/sweep_conv.py): the
 // 8-wave 256-pixel tiles first, smaller tiles for wide images.  Within the first tile shape that
 // fits, the dispatcher scores the buffering (TG 0 double / TG 1 single) and channel-slice (CS)
@@ -398,7 +423,8 @@ const ConvVariant* conv_pick(int W, int cin, int cout, bool want_stats, size_t* 
 }
 
 int conv_launch(const char* who, const void* x, const void* wt, const float* bias, void* y, float* stats, int B, int H,
-                int W, int cin, int cout, void* stream) {
+                int W, int cin, int cout, void* stream, const void* ypool = nullptr, const float* bn_gamma = nullptr,
+                const float* bn_beta = nullptr, const float* drop = nullptr) {
   SEPT_REQUIRE(B >= 0 && H > 0 && W > 0, SEPT_ERR_INVALID, "%s: B=%d H=%d W=%d", who, B, H, W);
   if (B == 0) return SEPT_OK;
   SEPT_REQUIRE(x && wt && y, SEPT_ERR_INVALID, "%s: null argument", who);
@@ -414,6 +440,10 @@ int conv_launch(const char* who, const void* x, const void* wt, const float* bia
   a.wt = static_cast<const bf16*>(wt);
   a.bias = bias;
   a.stats = stats;
+  a.ypool = static_cast<const bf16*>(ypool);
+  a.bn_gamma = bn_gamma;
+  a.bn_beta = bn_beta;
+  a.drop = drop;
   a.y = static_cast<bf16*>(y);
   a.B = B;
   a.H = H;
@@ -435,7 +465,23 @@ extern "C" int sept_conv5x5_forward(const void* x, const void* wt, const float* 
 
 // Forward + the BatchNorm statistics partials of the output: stats[2*cout][sept_conv5x5_stats_parts(...)] floats
 // (sums, then sums of squares; one column per workgroup), to be finished by sept_bn_stats_from_partials.
+namespace {
+int conv_epilogue_parts(int B, int H, int W, int cin, int cout) {
+  size_t smem = 0;
+  const ConvVariant* v = (B > 0 && H > 0 && W > 0) ? conv_pick(W, cin, cout, true, &smem) : nullptr;
+  if (!v) return 0;
+  const int mt = 32 * v->pb * v->wp;
+  return B * ((H * W + mt - 1) / mt);
+}
+}  // namespace
+
+// partial-sum columns of sept_conv5x5_dgrad_bnsums (0: the shape has no such form; cin > cout only)
+extern "C" int sept_conv5x5_bwsums_parts(int B, int H, int W, int cin, int cout) {
+  return cin > cout ? conv_epilogue_parts(B, H, W, cin, cout) : 0;
+}
+
 extern "C" int sept_conv5x5_stats_parts(int B, int H, int W, int cin, int cout) {
+  if (cin > cout) return 0;   // forward shapes only: the epilogue of a data-gradient shape forms BatchNorm BACKWARD sums
   size_t smem = 0;
   const ConvVariant* v = (B > 0 && H > 0 && W > 0) ? conv_pick(W, cin, cout, true, &smem) : nullptr;
   if (!v) return 0;   // no statistics form for this shape
@@ -446,5 +492,19 @@ extern "C" int sept_conv5x5_stats_parts(int B, int H, int W, int cin, int cout) 
 extern "C" int sept_conv5x5_forward_stats(const void* x, const void* wt, const float* bias, void* y, float* stats,
                                           int B, int H, int W, int cin, int cout, void* stream) {
   SEPT_REQUIRE(stats && B > 0, SEPT_ERR_INVALID, "sept_conv5x5_forward_stats: null statistics buffer / empty batch");
+  SEPT_REQUIRE(cin <= cout, SEPT_ERR_UNSUPPORTED, "sept_conv5x5_forward_stats: cin=%d > cout=%d is a data-gradient shape", cin, cout);
   return conv_launch("sept_conv5x5_forward_stats", x, wt, bias, y, stats, B, H, W, cin, cout, stream);
+}
+
+// Data-gradient launch (wt prepared with mode 1, cin > cout) whose epilogue also leaves the backward sums of the
+// BatchNorm in front of its output: partials[2*cout][sept_conv5x5_stats_parts(...)] of (sum g, sum g * xhat), to be
+// finished by sept_bn_relu_pool_backward_presummed.  Channels with |gamma| < 1e-3 carry garbage there (the pooled
+// form divides by gamma); the finishing entry point recomputes those from the windows.
+extern "C" int sept_conv5x5_dgrad_bnsums(const void* dy_out, const void* wt, void* dx_out, const void* ypool,
+                                         const float* bn_gamma, const float* bn_beta, const float* dropscale,
+                                         float* partials, int B, int H, int W, int cin, int cout, void* stream) {
+  SEPT_REQUIRE(partials && ypool && bn_gamma && bn_beta && B > 0 && cin > cout, SEPT_ERR_INVALID,
+               "sept_conv5x5_dgrad_bnsums: null argument / empty batch / not a data-gradient shape (cin=%d cout=%d)", cin, cout);
+  return conv_launch("sept_conv5x5_dgrad_bnsums", dy_out, wt, nullptr, dx_out, partials, B, H, W, cin, cout, stream, ypool,
+                     bn_gamma, bn_beta, dropscale);
 }

@@ -128,6 +128,10 @@ SIGNATURES = {
                               c_void_p]),
     "sept_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float, c_float,
                                c_float, c_int, c_float, c_void_p]),
+    "sept_conv5x5_bwsums_parts": (c_int, [c_int] * 5),
+    "sept_conv5x5_dgrad_bnsums": (c_int, [c_void_p] * 8 + [c_int] * 5 + [c_void_p]),
+    "sept_bn_relu_pool_backward_presummed": (c_int, [c_void_p] * 8 + [c_int, c_void_p, c_void_p, c_void_p, c_void_p] +
+                                             [c_int] * 5 + [c_void_p]),
     "sept_conv1_prep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "sept_conv1_fused_supported": (c_int, [c_int, c_int]),
     "sept_conv1_stats_only": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p]),

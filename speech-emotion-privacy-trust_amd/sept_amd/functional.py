@@ -444,6 +444,9 @@ BN_POOLED_SUMS = os.environ.get("SEPT_BN_POOLED", "1") != "0"
 # layer 1 (conv1 + BatchNorm + ReLU + pool) without its pre-activation tensor: "eval" (default) = only with running
 # statistics and no backward pass, "always" / "never" (SEPT_L1_FUSED=1 / 0) force it
 L1_FUSED = {"0": "never", "1": "always", "always": "always", "never": "never"}.get(os.environ.get("SEPT_L1_FUSED", "eval"), "eval")
+# BatchNorm backward sums of blocks 1 / 2 from the epilogue of the data-gradient conv that produces their dy
+# (SEPT_BN_DGRAD_SUMS=0: the separate reduce pass over the pooled tensors)
+BN_SUMS_IN_DGRAD = os.environ.get("SEPT_BN_DGRAD_SUMS", "1") != "0"
 # BatchNorm statistics of the 5x5 conv layers from the conv kernel's epilogue (SEPT_CONV_STATS=0: a separate pass)
 CONV_FUSED_STATS = os.environ.get("SEPT_CONV_STATS", "1") != "0"
 NO_WGRAD_FORK = set()
@@ -588,6 +591,7 @@ def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq, go
     # ---- conv stack ----
     dact = dseq.view(B, T, S.Wd, S.C)
     dx = None
+    presums = None   # (partials, count) of the current block's BatchNorm backward sums when the producer of dact formed them
     for li in range(len(S.blocks) - 1, -1, -1):
         blk, cv, bn = S.blocks[li], P.convs[li], P.bns[li]
         if not blk.bn_train:
@@ -599,6 +603,12 @@ def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq, go
                                                                   out_gamma=gout(bn.weight) if want_bn else None,
                                                                   out_beta=gout(bn.bias) if want_bn else None,
                                                                   prep=_conv1_operand(cv))
+        elif presums is not None:
+            dpre, dgamma, dbeta = ops.bn_relu_pool_backward_presummed(dact, blk.pre, blk.mean, blk.invstd, bn.weight,
+                                                                      bn.bias, blk.drop, presums, blk.pool,
+                                                                      need_param_grads=want_bn,
+                                                                      out_gamma=gout(bn.weight) if want_bn else None,
+                                                                      out_beta=gout(bn.bias) if want_bn else None)
         else:
             dpre, dgamma, dbeta = ops.bn_relu_pool_backward(dact, blk.pre, blk.mean, blk.invstd, bn.weight, bn.bias,
                                                             blk.drop, blk.pool, need_param_grads=want_bn,
@@ -627,7 +637,15 @@ def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq, go
                 ob = gout(cv.bias)
                 put(cv.bias, ops.fill(ob if ob is not None else torch.empty_like(cv.bias), 0.0))
             wtd = _cached("convdgrad", cv.weight, lambda: ops.conv5x5_prep_weights(cv.weight, 1))
-            dact = ops.conv5x5(dpre, wtd)
+            prev = S.blocks[li - 1]
+            if (BN_SUMS_IN_DGRAD and BN_POOLED_SUMS and prev.bn_train and not prev.sync and not prev.l1_fused
+                    and prev.pool == 2):
+                # the data-gradient conv's epilogue also forms the backward sums of the BatchNorm in front (from its
+                # output tile and that block's pooled activation): that block's reduce pass over y / dy disappears
+                pbn = P.bns[li - 1]
+                dact, presums = ops.conv5x5_dgrad_bnsums(dpre, wtd, prev.out, pbn.weight, pbn.bias, prev.drop)
+            else:
+                dact, presums = ops.conv5x5(dpre, wtd), None
     sq.finish()
     return dx, grads
 

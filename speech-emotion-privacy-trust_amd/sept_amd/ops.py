@@ -333,6 +333,46 @@ def bn_relu_pool_backward(dy, x, mean, invstd, gamma, beta, dropscale=None, pool
     return dx, dgamma, dbeta
 
 
+def conv5x5_dgrad_bnsums(dy_out, wtd, ypool, gamma, beta, dropscale=None):
+    """Data-gradient conv (dy_out (B,H,W,cin) bf16, wtd from conv5x5_prep_weights(w, 1)) -> (dx (B,H,W,cout) bf16,
+    (partials, nparts)) where the partials are the backward sums of the BatchNorm whose pooled output is `ypool`
+    (the block in front), or (dx, None) when the shape has no such kernel form."""
+    require_cuda(dy_out, wtd, ypool)
+    B, H, W, cin = dy_out.shape
+    cout = wtd.shape[1]
+    nparts = lib.sept_conv5x5_bwsums_parts(B, H, W, cin, cout)
+    if nparts <= 0 or tuple(ypool.shape) != (B, H, W, cout) or ypool.dtype != torch.bfloat16 or not ypool.is_contiguous():
+        return conv5x5(dy_out, wtd), None
+    dx = torch.empty((B, H, W, cout), dtype=torch.bfloat16, device=dy_out.device)
+    parts = workspace(f"conv5x5_bwsums{cout}", nparts * 2 * cout, dy_out.device)
+    h = TIMER.start(f"conv5x5_mfma<{cin},{cout}>") if TIMER is not None else None
+    check(lib.sept_conv5x5_dgrad_bnsums(dy_out.data_ptr(), wtd.data_ptr(), dx.data_ptr(), ypool.data_ptr(), gamma.data_ptr(),
+                                        beta.data_ptr(), _p(dropscale), parts.data_ptr(), B, H, W, cin, cout, _s(dx)),
+          "sept_conv5x5_dgrad_bnsums")
+    if h is not None:
+        TIMER.stop(h)
+    return dx, (parts, nparts)
+
+
+def bn_relu_pool_backward_presummed(dy, x, mean, invstd, gamma, beta, dropscale, presums, pool=2, need_param_grads=True,
+                                    out_gamma=None, out_beta=None):
+    """bn_relu_pool_backward with the two channel sums already formed by conv5x5_dgrad_bnsums."""
+    require_cuda(dy, x)
+    B, H, W, C = x.shape
+    parts, nparts = presums
+    ws = workspace("bn", lib.sept_bn_workspace_floats(C), x.device)
+    dx = torch.empty_like(x)
+    dgamma = dbeta = None
+    if need_param_grads:
+        dgamma = torch.empty(C, dtype=torch.float32, device=x.device) if out_gamma is None else out_gamma
+        dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if out_beta is None else out_beta
+    check(lib.sept_bn_relu_pool_backward_presummed(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                                   gamma.data_ptr(), beta.data_ptr(), _p(dropscale), parts.data_ptr(), nparts,
+                                                   ws.data_ptr(), dx.data_ptr(), _p(dgamma), _p(dbeta), B, H, W, C, pool,
+                                                   _s(x)), "sept_bn_relu_pool_backward_presummed")
+    return dx, dgamma, dbeta
+
+
 def conv5x5_backward_weight(x, dy, out=None):
     """x (B,H,W,cin) bf16, dy (B,H,W,cout) bf16 -> dW (cout,cin,5,5) fp32."""
     require_cuda(x, dy)

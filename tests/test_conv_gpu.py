@@ -101,3 +101,37 @@ def test_conv_weight_gradient(B, H, W, cin, cout):
     assert torch.allclose(dw, w.grad, rtol=1e-3, atol=1e-4 * scale), (dw - w.grad).abs().max() / scale
     # deterministic: same inputs, bit-identical result
     assert torch.equal(dw, ops.conv5x5_backward_weight(x.cuda(), dy.cuda()).cpu())
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout", [(9, 100, 40, 64, 32), (9, 50, 20, 128, 64), (3, 100, 64, 64, 32), (2, 51, 21, 128, 64)])
+@pytest.mark.parametrize("drop", [False, True])
+def test_dgrad_conv_with_batchnorm_backward_sums(B, H, W, cin, cout, drop):
+    """sept_conv5x5_dgrad_bnsums + sept_bn_relu_pool_backward_presummed against the separate data-gradient conv and
+    sept_bn_relu_pool_backward (pooled sums): identical dx of the conv, identical gradient of the pre-activations, the
+    same dgamma / dbeta up to summation order -- with one channel chunk that has to take the window path (tiny gamma)."""
+    from sept_amd import ops
+    g = torch.Generator().manual_seed(cin + H)
+    dy2 = (torch.randn(B, H, W, cin, generator=g) * 0.1).bfloat16().cuda()          # gradient of the NEXT conv's output
+    w = (torch.randn(cin, cout, 5, 5, generator=g) * 0.05).cuda()                   # that conv's weight (cin here = its cout)
+    wtd = ops.conv5x5_prep_weights(w, 1)
+    # the block in front: pre-activations x1 (B, 2H, 2W, cout), statistics, pooled output y1 (B, H, W, cout)
+    x1 = (torch.randn(B, 2 * H, 2 * W, cout, generator=g) * 1.3 + 0.2).bfloat16().cuda()
+    gamma = 1 + 0.3 * torch.randn(cout, generator=g)
+    gamma[5], gamma[cout - 3] = 2e-5, -0.6
+    gamma, beta = gamma.cuda(), (0.2 * torch.randn(cout, generator=g)).cuda()
+    dmask = ((torch.rand(B, cout, generator=g) > 0.2).float() * 1.25).cuda() if drop else None
+    mean, invstd = ops.bn_stats(x1)
+    y1 = ops.bn_relu_pool_forward(x1, mean, invstd, gamma, beta, dmask, 2)
+    want_dx = ops.conv5x5(dy2, wtd)
+    want = ops.bn_relu_pool_backward(want_dx, x1, mean, invstd, gamma, beta, dmask, 2, y=y1)
+    dx, presums = ops.conv5x5_dgrad_bnsums(dy2, wtd, y1, gamma, beta, dmask)
+    assert torch.equal(dx, want_dx)
+    if presums is None:      # no epilogue form for this shape: the caller falls back to the separate pass
+        assert ops.lib.sept_conv5x5_bwsums_parts(B, H, W, cin, cout) == 0
+        return
+    got = ops.bn_relu_pool_backward_presummed(dx, x1, mean, invstd, gamma, beta, dmask, presums, 2)
+    for a_, b_ in ((got[1], want[1]), (got[2], want[2])):
+        assert torch.allclose(a_, b_, rtol=2e-4, atol=2e-4 * float(b_.abs().max())), (a_ - b_).abs().max()
+    d, d2 = want[0].float(), got[0].float()
+    assert float((d - d2).norm() / d.norm()) < 1e-3           # the sums enter every element through the mean terms
+    assert ((d - d2).abs() <= d.abs() * 2 ** -6 + 2e-3 * float(d.abs().max())).all()
