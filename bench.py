@@ -235,6 +235,10 @@ def main():
     ap.add_argument("--graph", dest="graph", action="store_true", default=True,
                     help="replay the step from a captured HIP graph (default)")
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="enqueue every kernel from the host each step")
+    ap.add_argument("--replay-only", action="store_true",
+                    help="profiling aid: warm-up, capture, then ONLY graph replays (no probe / eager timing / serialised "
+                         "steps / mel-256 / cpu baseline), so a rocprofv3 kernel trace of the run is the replayed step; "
+                         "tools/replay_stats.py cuts the replay window out of it")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -302,6 +306,23 @@ def main():
     for _ in range(max(a.warmup, 1)):
         loss, _, _ = pipe.train_step(wav, le, lg, weights)
     torch.cuda.synchronize()
+    if a.replay_only:
+        step_fn = pipe.capture(wav, le, lg, weights)
+        for _ in range(2):
+            step_fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step_fn()
+        barrier()
+        dt = time.perf_counter() - t0
+        if rank == 0:
+            print(json.dumps({"mode": "replay-only", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                              "ms_per_step": round(dt / a.steps * 1e3, 3), "value": round(clips * world * a.steps / dt, 2),
+                              "unit": "utterances/s", "config": {"clips_per_gpu": clips, "windows_per_gpu": Bw, "n_mels": F}}))
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
     ops.TIMER = ops.KernelTimer()
     for _ in range(2):
         pipe.train_step(wav, le, lg, weights)

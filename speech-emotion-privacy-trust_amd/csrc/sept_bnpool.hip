@@ -570,7 +570,9 @@ extern "C" int sept_bn_relu_pool_backward_presummed(const void* dy, const void* 
   BnBwdArgs a{static_cast<const bf16*>(dy), static_cast<const bf16*>(x), nullptr, mean, invstd, gamma, beta, dropscale, ws,
               static_cast<bf16*>(dx), B, H, W, C, pool, ws + size_t(kParts) * 2 * C, 1.0f / (float(B) * H * W)};
   const long items = long(B) * (H / pool) * (W / pool) * (C / 8);
-  const int grid = grid_for(items);
+  // a SMALL grid: in the common case (no tiny |gamma|) every workgroup leaves after one load and one vote, and a
+  // full-size launch of them still cost 20-45 us beside the other branch's kernels (replay trace, round 2)
+  const int grid = grid_for(items, 64);
   if (pool == 2) {
     SEPT_CPP_DISPATCH(C, hipLaunchKernelGGL((sept_bn_bwd_reduce_small_kernel<CPP, 2>), dim3(grid), dim3(256), 0, st, a));
   } else {

@@ -63,6 +63,9 @@ __host__ __device__ constexpr int conv_nr_max(int mt, int w) { return (mt + w - 
 // of 25 and each interval carries TG times the MFMA work to hide the staging latency under.
 // TG = 0: one tap per interval with TWO weight buffers (one barrier per tap); costs one more
 // weight tile of LDS, which matters when it decides how many workgroups share a CU.
+// TG = -n: double-buffered GROUPS of n taps (one barrier per n taps).  With narrow channel slices a tap is only a
+// handful of MFMAs per wave (32 channels: PB * NB * 2 = 2-8, i.e. 64-256 matrix-pipe cycles) and every interval
+// opens with an exposed LDS round trip behind the barrier; n taps per interval amortise it n-fold.
 // CS > 1: the input channels are processed in CS slices, each with its own staged tile and weight
 // tiles (the accumulators run across slices): for wide inputs (128 channels) this halves the
 // LDS tile so that two workgroups fit on a CU.
@@ -80,11 +83,11 @@ __host__ __device__ constexpr size_t conv_stats_smem(int mt, int cout, int nthr)
 enum { kEpiPlain = 0, kEpiStats = 1, kEpiBwSums = 2 };
 template <int CINF, int COUT, int PB, int WP, int WN, int TGP, int CS, int EPI = kEpiPlain>
 __global__ __launch_bounds__(64 * WP * WN,
-                             (EPI != kEpiPlain && WP * WN == 8 && !(TGP == 0 && CINF >= 64 && (CS == 1 || CINF == 128))) ? 4 : 1)
+                             (EPI != kEpiPlain && WP * WN == 8 && !(TGP <= 0 && CINF >= 64 && (CS == 1 || CINF == 128))) ? 4 : 1)
 void sept_conv5x5_mfma_kernel(ConvArgs a) {
   constexpr bool STATS = EPI != kEpiPlain;   // the output tile goes through the LDS for per-channel column sums
-  constexpr bool DBUF = TGP == 0;
-  constexpr int TG = DBUF ? 1 : TGP;
+  constexpr bool DBUF = TGP <= 0;                               // TGP <= 0: double-buffered groups of max(1, -TGP) taps
+  constexpr int TG = TGP == 0 ? 1 : (TGP < 0 ? -TGP : TGP);
   constexpr int CIN = CINF / CS;  // channels per slice
   constexpr int MT = 32 * PB * WP;
   constexpr int NTHR = 64 * WP * WN;
@@ -129,7 +132,7 @@ void sept_conv5x5_mfma_kernel(ConvArgs a) {
   };
   auto wstore = [&](int g, const uint4 (&r)[WCH]) {
     const int n = min(TG, kTaps - g * TG) * COUT * CPP;
-    unsigned char* dst = wbuf + (DBUF ? size_t(g & 1) * COUT * PSW : 0);
+    unsigned char* dst = wbuf + (DBUF ? size_t(g & 1) * TG * COUT * PSW : 0);
 #pragma unroll
     for (int j = 0; j < WCH; ++j) {
       const int i = tid + NTHR * j;
@@ -183,7 +186,7 @@ void sept_conv5x5_mfma_kernel(ConvArgs a) {
       if (tap >= kTaps) break;
       const int kh = tap / 5, kw = tap - kh * 5;
       const int tapoff = kh * RP + kw * PS;
-      const unsigned char* wb = wbuf + size_t(DBUF ? buf : tl) * COUT * PSW;
+      const unsigned char* wb = wbuf + size_t(DBUF ? buf * TG + tl : tl) * COUT * PSW;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         bf16x8 bfrag[PB], afrag[NB];
@@ -362,6 +365,11 @@ const ConvVariant kConvVariants[] = {
     SEPT_CONV_VARIANT(64, 128, 1, 4, 1, 1, 1),  SEPT_CONV_VARIANT(64, 128, 2, 4, 2, 0, 2),  SEPT_CONV_VARIANT(64, 128, 2, 4, 2, 1, 2),
     SEPT_CONV_VARIANT(64, 32, 1, 8, 1, 0, 1),   SEPT_CONV_VARIANT(64, 32, 1, 8, 1, 1, 1),   SEPT_CONV_VARIANT(64, 32, 1, 4, 1, 1, 1),
     SEPT_CONV_VARIANT(64, 32, 1, 8, 1, 0, 2),   SEPT_CONV_VARIANT(64, 32, 1, 8, 1, 1, 2),
+    // 64 -> 32 in two channel slices is only 2 MFMAs per wave and tap: pairs of taps per barrier (-2) measured
+    // 115-120 us where one tap per barrier takes 123-130 (round 2 sweeps, gpurun_out/r2i, r2j); for the other shapes
+    // groups of 2 / 3 / 5 taps, 128-pixel tiles with 3-4 workgroups per CU and four channel slices were all equal
+    // or slower (more LDS or more registers cost the second workgroup per CU, which is worth 2x)
+    SEPT_CONV_VARIANT(64, 32, 1, 8, 1, -2, 2),  SEPT_CONV_VARIANT(64, 32, 1, 8, 1, -2, 1),
     SEPT_CONV_VARIANT(128, 64, 2, 4, 2, 0, 2),  SEPT_CONV_VARIANT(128, 64, 2, 4, 2, 1, 2),  SEPT_CONV_VARIANT(128, 64, 2, 4, 2, 0, 1),
     SEPT_CONV_VARIANT(128, 64, 1, 4, 2, 1, 1),  SEPT_CONV_VARIANT(128, 64, 1, 4, 1, 1, 1),
     SEPT_CONV_VARIANT(128, 128, 2, 4, 2, 0, 2), SEPT_CONV_VARIANT(128, 128, 2, 4, 2, 1, 2), SEPT_CONV_VARIANT(128, 128, 1, 4, 2, 1, 1),
@@ -395,16 +403,19 @@ const ConvVariant* conv_pick(int W, int cin, int cout, bool want_stats, size_t* 
     if (v.cin != cin || v.cout != cout) continue;
     if (force_pb && v.pb != force_pb) continue;
     if (force_ns && v.wp * v.wn != 4 * force_ns) continue;
-    if (force_tg && v.tg != (force_tg == 9 ? 0 : force_tg)) continue;  // SEPT_CONV_TG=9 selects the double-buffered form
+    // SEPT_CONV_TG=9 selects the double-buffered one-tap form, 92 / 93 / 95 the double-buffered groups of 2 / 3 / 5 taps
+    if (force_tg && v.tg != (force_tg == 9 ? 0 : (force_tg > 90 ? 90 - force_tg : force_tg))) continue;
     if (force_cs && v.cs != force_cs) continue;
     const int mt = 32 * v.pb * v.wp;
     const size_t ps = size_t(cin / v.cs) * 2 + 16;
-    const size_t smem = size_t(conv_nr_max(mt, W)) * conv_row_pitch(W, int(ps)) + size_t(v.tg == 0 ? 2 : v.tg) * cout * ps;
+    const size_t smem = size_t(conv_nr_max(mt, W)) * conv_row_pitch(W, int(ps)) +
+                        size_t(v.tg <= 0 ? 2 * std::max(1, -v.tg) : v.tg) * cout * ps;
     if (smem > 160 * 1024) continue;
     // measured on MI355X (tools/sweep_conv.py): what matters is whether TWO workgroups share a CU
     // (a third adds nothing); then the double-buffered form; then table order (tile shape)
-    const int occ = int(std::min<size_t>(2, (160 * 1024) / smem));
-    const int score = 10 * occ + (v.tg == 0 ? 1 : 0);
+    static const int occ_cap = getenv("SEPT_CONV_OCC") ? atoi(getenv("SEPT_CONV_OCC")) : 2;
+    const int occ = int(std::min<size_t>(occ_cap, (160 * 1024) / smem));
+    const int score = 10 * occ + (v.tg <= 0 ? 1 - v.tg : 0);
     if (!best || (v.pb == best->pb && v.wp == best->wp && v.wn == best->wn && score > best_score)) {
       best = &v;
       best_smem = smem;

@@ -345,6 +345,16 @@ def grad_out(param):
     return fp.grad[off:off + n].view(param.shape)
 
 
+def grad_out_pair(p_fwd, p_rev):
+    """One (2 x rows, ...) view over the slots of a forward / reverse GRU parameter pair when the trainer packed them
+    next to each other (FlatParams does): the product that yields both directions' gradients writes them in place."""
+    a, b = getattr(p_fwd, "_sept_flat", None), getattr(p_rev, "_sept_flat", None)
+    if a is None or b is None or a[0] is not b[0] or b[1] != a[1] + a[2] or not (p_fwd.requires_grad and p_rev.requires_grad):
+        return None
+    fp, off, n = a
+    return fp.grad[off:off + 2 * n].view((2 * p_fwd.shape[0],) + tuple(p_fwd.shape[1:]))
+
+
 def _into(out, src):
     """src copied into the flat slot `out` when there is one"""
     return src if out is None else ops.copy_into(out, src.contiguous())
@@ -562,9 +572,14 @@ def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq, go
         K = Gs.inp.shape[1]
         if need_wgrad:
             def rnn_wgrads(layer=layer, sfx=sfx, Gs=Gs, dgi2=dgi2, dgh2=dgh2, hp2=hp2):
-                dwcat = ops.linear_backward_weight(dgi2, Gs.inp)      # (2G, K): both directions in one product
-                dbih = ops.colsum(dgi2)
-                dbhh = dbih if S.lstm else ops.colsum(dgh2)
+                # both directions in one product / one column sum each; forward and reverse parameters sit next to
+                # each other in the trainer's flat gradient buffer, so the (2G, ...) results are written in place
+                pair = (lambda n: grad_out_pair(getattr(r, n + sfx), getattr(r, n + sfx + "_reverse"))) if need_wgrad \
+                    else (lambda n: None)
+                o_w, o_bi, o_bh = (pair("weight_ih") if layer == 1 else None), pair("bias_ih"), pair("bias_hh")
+                dwcat = ops.linear_backward_weight(dgi2, Gs.inp, out=o_w)      # (2G, K)
+                dbih = ops.colsum(dgi2, out=o_bi)
+                dbhh = (dbih if o_bh is None else ops.copy_into(o_bh, dbih)) if S.lstm else ops.colsum(dgh2, out=o_bh)
                 for d, tag in ((0, ""), (1, "_reverse")):
                     gh = dgh2[:, d * G:(d + 1) * G]
                     dwih = dwcat[d * G:(d + 1) * G]
@@ -572,12 +587,12 @@ def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq, go
                     bih, bhh = getattr(r, "bias_ih" + sfx + tag), getattr(r, "bias_hh" + sfx + tag)
                     if layer == 0:
                         dwih = ops.permute_cols(dwih, S.C, S.Wd, inverse=True, out=gout(wih))
-                    else:
+                    elif o_w is None:
                         dwih = _into(gout(wih), dwih)
                     put(wih, dwih)
                     put(whh, ops.linear_backward_weight(gh, hp2[:, d * Hh:(d + 1) * Hh], out=gout(whh)))
-                    put(bih, _into(gout(bih), dbih[d * G:(d + 1) * G]))
-                    put(bhh, _into(gout(bhh), dbhh[d * G:(d + 1) * G]))
+                    put(bih, dbih[d * G:(d + 1) * G] if o_bi is not None else _into(gout(bih), dbih[d * G:(d + 1) * G]))
+                    put(bhh, dbhh[d * G:(d + 1) * G] if o_bh is not None else _into(gout(bhh), dbhh[d * G:(d + 1) * G]))
             sq.small(rnn_wgrads, dgi2, dgh2, hp2, Gs.inp)
         # gradient wrt the layer input: dgi [W_if; W_ir]  (one product, reduction length 2G)
         odt = torch.float32 if layer == 1 else torch.bfloat16
@@ -870,7 +885,7 @@ class GrlStepLossFn(torch.autograd.Function):
     def forward(ctx, preds, preds_grl, labels_emo, labels_gen, weights, gender_lambda, scale_lamda, rhos,
                 min_scale, max_scale):
         B = preds.shape[0]
-        loss = torch.zeros((), dtype=torch.float32, device=preds.device)
+        loss = torch.empty((), dtype=torch.float32, device=preds.device)   # the first CE launch overwrites it
         d1 = ops.cross_entropy(preds.detach().contiguous(), labels_emo, weights, 1.0 / B, loss)
         d2 = None
         if preds_grl is not None:
@@ -895,7 +910,7 @@ class GrlStepLossFn(torch.autograd.Function):
         if ctx.scale_cfg is not None:
             lam, mn, mx, mean = ctx.scale_cfg
             rh = ctx.rhos
-            zero = torch.zeros((1, rh.numel()), dtype=torch.float32, device=rh.device)
+            zero = ops.fill(torch.empty((1, rh.numel()), dtype=torch.float32, device=rh.device), 0.0)
             _, drhos = ops.cloak_backward(zero, None, 0.0, rh, zero.view_as(rh), None, mn, mx, scale_lambda=lam,
                                           scale_mean=mean, need_locs=False)
             drhos = ops.scale_dev(drhos, g)

@@ -31,12 +31,37 @@ class FlatParams:
     are skipped by torch.optim -- no weight decay, no momentum.  The first gather_grads() finds
     them and moves them behind the `n_active` prefix that the optimiser and the all-reduce use."""
 
-    def __init__(self, params):
+    def __init__(self, params, named=None):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
         self._settled = False
+        self._pair_up(named)
         self._pack()
+
+    def _pair_up(self, named):
+        """Reorder so that every `<x>_reverse` recurrent parameter directly follows its forward twin `<x>`: the
+        backward pass computes both directions' weight / bias gradients as one (2G, ...) product and writes it
+        straight into the adjacent slots (functional.grad_out_pair)."""
+        if not named:
+            return
+        name_of = {id(p): n for n, p in named}
+        by_name = {n: p for n, p in named if p.requires_grad}
+        order, placed = [], set()
+        for p in self.params:
+            if id(p) in placed:
+                continue
+            n = name_of.get(id(p), "")
+            if n.endswith("_reverse") and n[:-len("_reverse")] in by_name and id(by_name[n[:-len("_reverse")]]) not in placed:
+                continue                      # placed right after its forward twin below
+            order.append(p)
+            placed.add(id(p))
+            twin = by_name.get(n + "_reverse")
+            if twin is not None and id(twin) not in placed:
+                order.append(twin)
+                placed.add(id(twin))
+        order += [p for p in self.params if id(p) not in placed]
+        self.params = order
 
     def _pack(self):
         dev = self.params[0].device
@@ -257,7 +282,7 @@ class GrlTrainer(_TrainerBase):
                  seed=None):
         self.model = cloak_model
         self.sync_bn = sync_bn   # BatchNorm statistics of the GLOBAL batch (extra tiny all-reduces); default: per rank
-        self.flat = FlatParams(cloak_model.parameters())  # filter(requires_grad), as :417/:420
+        self.flat = FlatParams(cloak_model.parameters(), list(cloak_model.named_parameters()))  # filter(requires_grad), :417/:420
         # :417  SGD(lr=0.001, momentum=0.9, weight_decay=1e-4);  :420  Adam(lr=0.0005, weight_decay=1e-4,
         # betas=(0.9, 0.98), eps=1e-9)
         self._init_optim(optimizer, lr, {"sgd": 1e-3, "adam": 5e-4}, momentum, weight_decay, betas, eps, process_group,
@@ -319,7 +344,7 @@ class BaselineTrainer(_TrainerBase):
     def __init__(self, model, optimizer="sgd", lr=None, momentum=0.9, weight_decay=1e-4, betas=(0.9, 0.98),
                  eps=1e-9, process_group=None, seed=None):
         self.model = model
-        self.flat = FlatParams(model.parameters())
+        self.flat = FlatParams(model.parameters(), list(model.named_parameters()))
         self._init_optim(optimizer, lr, {"sgd": 1e-4, "adam": 5e-5}, momentum, weight_decay, betas, eps, process_group,
                          seed)
 

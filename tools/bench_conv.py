@@ -13,7 +13,11 @@ for (H, W, ci, co, mode) in [(100, 40, 32, 64, 0), (50, 20, 64, 128, 0), (100, 4
     x = torch.randn(B, H, W, ci, device="cuda").bfloat16()
     w = torch.randn((co, ci, 5, 5) if mode == 0 else (ci, co, 5, 5), device="cuda") * 0.05
     wt = ops.conv5x5_prep_weights(w, mode)
-    y = ops.conv5x5(x, wt)
+    try:
+        y = ops.conv5x5(x, wt)
+    except Exception as e:   # a forced variant (SEPT_CONV_*) that does not exist for this shape
+        print(f"conv {ci}->{co} {H}x{W}: {type(e).__name__}")
+        continue
     for _ in range(3):
         ops.conv5x5(x, wt, out=y)
     torch.cuda.synchronize()
@@ -28,7 +32,7 @@ for (H, W, ci, co, mode) in [(100, 40, 32, 64, 0), (50, 20, 64, 128, 0), (100, 4
     fl = 2.0 * B * H * W * ci * co * 25
     print(f"conv {ci}->{co} {H}x{W} B={B} mode={mode}: {ms*1e3:.1f} us  {fl/ms/1e9:.1f} TFLOP/s")
 
-for (H, W, ci, co) in [(100, 40, 32, 64), (50, 20, 64, 128), (100, 64, 32, 64), (50, 32, 64, 128)]:
+for (H, W, ci, co) in ([] if os.environ.get("SEPT_BENCH_NO_WGRAD") else [(100, 40, 32, 64), (50, 20, 64, 128), (100, 64, 32, 64), (50, 32, 64, 128)]):
     x = torch.randn(B, H, W, ci, device="cuda").bfloat16()
     dy = torch.randn(B, H, W, co, device="cuda").bfloat16()
     for _ in range(3):
