@@ -235,6 +235,8 @@ def main():
     ap.add_argument("--graph", dest="graph", action="store_true", default=True,
                     help="replay the step from a captured HIP graph (default)")
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="enqueue every kernel from the host each step")
+    ap.add_argument("--no-ref-batch", action="store_true",
+                    help="skip the 32-windows-per-step line (counter passes: keeps per-kernel means at ONE shape)")
     ap.add_argument("--replay-only", action="store_true",
                     help="profiling aid: warm-up, capture, then ONLY graph replays (no probe / eager timing / serialised "
                          "steps / mel-256 / cpu baseline), so a rocprofv3 kernel trace of the run is the replayed step; "
@@ -430,7 +432,7 @@ def main():
     # the reference's own batch: 32 windows per step (training_cloak_with_grl.py:212) through the same captured
     # step -- BatchNorm statistics over 32 windows as in the reference, where the headline batches 7x more
     ref_batch = None
-    if rank == 0 and world == 1 and a.graph:
+    if rank == 0 and world == 1 and a.graph and not a.no_ref_batch:
         g = torch.Generator().manual_seed(8)
         x32 = torch.randn(32, 1, WIN, F, generator=g).to(dev)
         le32, lg32 = torch.randint(0, 4, (32,), generator=g).to(dev), torch.randint(0, 2, (32,), generator=g).to(dev)

@@ -8,6 +8,7 @@
 // gradient is a per-tile correlation reduced deterministically through a workspace.
 // Layouts: x / dx fp32 [B][H][W];  y / dy bf16 NHWC [B][H][W][32];  w fp32 OIHW [32][1][5][5].
 #include <algorithm>
+#include <cstdlib>
 
 #include "sept_common.h"
 
@@ -21,7 +22,8 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int kC = 32, kTaps = 25, kMT = 256;
-constexpr int kDyPS = 80;  // bytes per staged dy pixel (64 + 16 pad)
+constexpr int kDyPS = 80;  // bytes per staged dy pixel (64 + 16 pad): conflict-free for the 16-byte reads
+constexpr int kDyPSt = 64; // ... and for the transposing reads of the weight gradient (4 pixels x 16 words tile the banks)
 
 __host__ __device__ constexpr int nr_max(int w) { return (kMT + w - 2) / w + 5; }
 
@@ -39,10 +41,31 @@ struct C1Args {
 // stage rows [h_first-2, h_last+2] x cols [-2, W+2) of a single-channel fp32 image
 __device__ __forceinline__ void stage_x(const float* xb, float* tile, int h_first, int NR, int H, int W) {
   const int W4 = W + 4;
-  for (int i = threadIdx.x; i < NR * W4; i += 256) {
-    const int col = i % W4, row = i / W4;
-    const int h = h_first - 2 + row, w = col - 2;
-    tile[i] = (h >= 0 && h < H && w >= 0 && w < W) ? xb[size_t(h) * W + w] : 0.f;
+  for (int row = threadIdx.x / 64; row < NR; row += 4) {      // one wave per row: no per-element division
+    const int h = h_first - 2 + row;
+    const bool hin = h >= 0 && h < H;
+    for (int col = threadIdx.x & 63; col < W4; col += 64) {
+      const int w = col - 2;
+      tile[row * W4 + col] = (hin && w >= 0 && w < W) ? xb[size_t(h) * W + w] : 0.f;
+    }
+  }
+}
+
+// the same rows with every sample already split into its two bf16 halves, packed (hi << 16 | lo): the MFMA forward
+// builds its split im2col operands from these words with two byte-permutes per pair of taps, where splitting at every
+// USE (each staged sample is read by 25 taps) cost four conversions per tap and made the kernel VALU-bound
+__device__ __forceinline__ void stage_x_split(const float* xb, unsigned* tile, int h_first, int NR, int H, int W) {
+  const int W4 = W + 4;
+  for (int row = threadIdx.x / 64; row < NR; row += 4) {      // one wave per row: no per-element division
+    const int h = h_first - 2 + row;
+    const bool hin = h >= 0 && h < H;
+    for (int col = threadIdx.x & 63; col < W4; col += 64) {
+      const int w = col - 2;
+      const float v = (hin && w >= 0 && w < W) ? xb[size_t(h) * W + w] : 0.f;
+      const bf16 hi = (bf16)v;
+      const bf16 lo = (bf16)(v - float(hi));
+      tile[row * W4 + col] = (unsigned(__builtin_bit_cast(unsigned short, hi)) << 16) | __builtin_bit_cast(unsigned short, lo);
+    }
   }
 }
 
@@ -114,11 +137,11 @@ __global__ __launch_bounds__(256) void sept_conv1_fwd_mfma_kernel(const float* _
                                                                   bf16* __restrict__ y, float* __restrict__ stats,
                                                                   int B, int H, int W) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* tile = reinterpret_cast<float*>(smem);
+  unsigned* tile = reinterpret_cast<unsigned*>(smem);   // packed (hi << 16 | lo) bf16 halves of every staged sample
   const int W4 = W + 4;
   const int b = blockIdx.y, h0 = blockIdx.x * kFwdRows;
   const int nrows = min(kFwdRows, H - h0);
-  stage_x(x + size_t(b) * H * W, tile, h0, nrows + 4, H, W);
+  stage_x_split(x + size_t(b) * H * W, tile, h0, nrows + 4, H, W);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, c = lane & 31;
   // A operand (weights): lane (channel c, k half) holds taps 16*ks + 8*half + j, j = 0..7, of both K steps, split
   // into bf16 hi + lo (w = hi + lo up to 2^-17); tap 25 is the bias (against a constant 1), taps 26..31 are zero
@@ -146,24 +169,29 @@ __global__ __launch_bounds__(256) void sept_conv1_fwd_mfma_kernel(const float* _
     const int q = blk * 32 + c;
     const int qc = min(q, npx - 1);
     const int hh = qc / W, ww = qc - hh * W;
-    const float* tp = tile + hh * W4 + ww;
+    const unsigned* tp = tile + hh * W4 + ww;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      // B operand (im2col): the 8 taps of this lane for pixel q, split into hi + lo like the weights;
+      // B operand (im2col): the 8 taps of this lane for pixel q, each already split into hi + lo (stage_x_split);
       // three passes hi*hi + hi*lo + lo*hi keep the products at ~2^-17 relative (the output is bf16)
-      bf16x8 xhi, xlo;
+      unsigned wv[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int t = 16 * ks + 8 * half + j;   // half is a lane property: both candidates are compile-time taps
-        float xv = tp[tapoff[ks][j]];
-        if (ks == 1) xv = (half && j == 1) ? 1.0f : ((half && j > 1) ? 0.f : xv);
-        (void)t;
-        xhi[j] = (bf16)xv;
-        xlo[j] = (bf16)(xv - float(xhi[j]));
+        wv[j] = tp[tapoff[ks][j]];
+        // tap 25 is the bias against a constant 1 (hi = 0x3F80, lo = 0), taps 26..31 are zero (upper lanes, second step)
+        if (ks == 1) wv[j] = (half && j == 1) ? 0x3F800000u : ((half && j > 1) ? 0u : wv[j]);
       }
+      unsigned ph[4], pl[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        ph[j] = __builtin_amdgcn_perm(wv[2 * j + 1], wv[2 * j], 0x07060302u);   // [hi(2j+1) : hi(2j)]
+        pl[j] = __builtin_amdgcn_perm(wv[2 * j + 1], wv[2 * j], 0x05040100u);   // [lo(2j+1) : lo(2j)]
+      }
+      const bf16x8 xhi = __builtin_bit_cast(bf16x8, make_uint4(ph[0], ph[1], ph[2], ph[3]));
+      const bf16x8 xlo = __builtin_bit_cast(bf16x8, make_uint4(pl[0], pl[1], pl[2], pl[3]));
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo[ks], xhi, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[ks], xlo, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[ks], xhi, acc, 0, 0, 0);
@@ -457,6 +485,123 @@ __global__ __launch_bounds__(256) void sept_conv1_dgrad_stream_kernel(const bf16
   }
 }
 
+// ---- data gradient, streaming MFMA form with register accumulators -------------------------------
+// As sept_conv1_dgrad_stream_kernel, but the Z values are consumed the step after they are produced: each of the
+// 5 x 5 products of a dy row y belongs to exactly one output row r = y - dh + 2, so instead of keeping six Z rows in
+// LDS until an output row has all five of its sources (58 KB, two workgroups per CU), the thread that owns an
+// output pixel keeps FIVE running sums in registers -- rows y-2 .. y+2 -- adds the five tap-rows of every new Z row
+// to them and emits the oldest.  LDS then holds two dy rows and two Z rows (35 KB at W = 80): four workgroups per
+// CU hide the per-step dependency chain (load -> LDS -> MFMA -> LDS -> gather) that bounded the six-row form
+// (50 % of its wave cycles waiting, 27 % LDS busy, 11 % VALU: round-2 PMC).
+__global__ __launch_bounds__(256, 4) void sept_conv1_dgrad_stream2_kernel(const bf16* __restrict__ dy,
+                                                                          const float* __restrict__ wprep,
+                                                                          float* __restrict__ dx, int B, int H, int W,
+                                                                          int rows_per_chunk) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int W4 = W + 4;
+  const int NP = (W4 + 31) / 32 * 32;  // staged pixels per row, padded to whole MFMA blocks
+  unsigned char* dyrow = smem;                                              // [2][NP][kDyPS]
+  float* zbuf = reinterpret_cast<float*>(smem + size_t(2) * NP * kDyPS);    // [2][NP][kZS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y;
+  const int r0 = blockIdx.x * rows_per_chunk, r1 = min(H, r0 + rows_per_chunk);
+  const bf16* dyb = dy + size_t(b) * H * W * kC;
+
+  for (int i = tid; i < 2 * NP * (kDyPS / 16); i += 256) reinterpret_cast<uint4*>(dyrow)[i] = make_uint4(0, 0, 0, 0);
+  const int tap = lane & 31;
+  bf16x8 bw[2];
+  {
+    const uint4* wflip = reinterpret_cast<const uint4*>(wprep + kTaps * kC + kC);  // [25][4] x 8 bf16
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (tap < kTaps) v = wflip[tap * 4 + ks * 2 + (lane >> 5)];
+      bw[ks] = __builtin_bit_cast(bf16x8, v);
+    }
+  }
+  const int nchunks = W * 4;
+  auto gload = [&](int y, uint4 (&pre)[2]) {   // unconditional (clamped) loads: see sept_conv1_dgrad_stream_kernel
+    const bf16* row = dyb + size_t(min(max(y, 0), H - 1)) * W * kC;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) pre[j] = *reinterpret_cast<const uint4*>(row + size_t(min(tid + 256 * j, nchunks - 1)) * 8);
+  };
+  auto lstore = [&](int buf, int y, const uint4 (&pre)[2]) {
+    const bool inside = y >= 0 && y < H;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int i = tid + 256 * j;
+      if (i < nchunks)
+        *reinterpret_cast<uint4*>(dyrow + size_t(buf) * NP * kDyPS + size_t((i >> 2) + 2) * kDyPS + (i & 3) * 16) =
+            inside ? pre[j] : make_uint4(0, 0, 0, 0);
+    }
+  };
+  uint4 pre0[2], pre1[2], pre2[2], pre3[2];
+  __syncthreads();
+  gload(r0 - 2, pre0);
+  gload(r0 - 1, pre1);
+  gload(r0, pre2);
+  gload(r0 + 1, pre3);
+  lstore(0, r0 - 2, pre0);
+  __syncthreads();
+
+  // this thread's output pixel (if any) and its five running sums: oa[k] belongs to output row (yy - 2 + k), yy = the dy
+  // row whose Z values are being gathered
+  const int gp = (3 - wave) * 64 + lane;
+  const bool gather = gp < W;
+  float oa[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  const int nsteps = (r1 - r0) + 5;  // dy rows r0-2 .. r1+1 are transformed; the gather lags one step
+  auto step = [&](int s, uint4 (&pre_req)[2], const uint4 (&pre_next1)[2]) {
+    const int y = r0 - 2 + s;        // dy row transformed in this step (zeros outside the image)
+    gload(y + 4, pre_req);
+    if (s < nsteps - 1) {            // ---- Z row of dy row y -> zbuf[s & 1] ----
+      const unsigned char* cur = dyrow + size_t(s & 1) * NP * kDyPS;
+      float* zrow = zbuf + size_t(s & 1) * NP * kZS;
+      for (int blk = wave; blk < NP / 32; blk += 4) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(cur + size_t(blk * 32 + (lane & 31)) * kDyPS + ks * 32 + (lane >> 5) * 16);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bw[ks], acc, 0, 0, 0);
+        }
+        if (tap < kTaps) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int px = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            zrow[px * kZS + tap] = acc[r];
+          }
+        }
+      }
+    }
+    if (s >= 1 && gather) {          // ---- gather the Z row of the PREVIOUS step: dy row yy = y - 1 ----
+      const float* zr = zbuf + size_t((s - 1) & 1) * NP * kZS + gp * kZS;
+#pragma unroll
+      for (int dh = 0; dh < 5; ++dh) {
+        float sum = 0.f;
+#pragma unroll
+        for (int dw = 0; dw < 5; ++dw) sum += zr[dw * kZS + dh * 5 + dw];
+        oa[4 - dh] += sum;           // output row yy - dh + 2
+      }
+      const int r = y - 3;           // = yy - 2: its five source rows are all in
+      if (r >= r0 && r < r1) dx[(size_t(b) * H + r) * W + gp] = oa[0];
+      oa[0] = oa[1];
+      oa[1] = oa[2];
+      oa[2] = oa[3];
+      oa[3] = oa[4];
+      oa[4] = 0.f;
+    }
+    lstore((s + 1) & 1, y + 1, pre_next1);
+    sept::lds_barrier();
+  };
+  for (int s = 0; s < nsteps; s += 4) {
+    step(s, pre0, pre1);
+    if (s + 1 < nsteps) step(s + 1, pre1, pre2);
+    if (s + 2 < nsteps) step(s + 2, pre2, pre3);
+    if (s + 3 < nsteps) step(s + 3, pre3, pre0);
+  }
+}
+
 // ---- weight gradient on MFMA (image width a multiple of 8) -------------------------------
 // D[c][tap] += sum_pixels dy[pixel][c] * x[pixel + tap]:  A[c][pixel] comes from the NHWC dy tile by
 // the transposing LDS read (as in sept_conv_wgrad.hip); B[pixel][tap] is built on the fly -- lane
@@ -491,23 +636,36 @@ __global__ __launch_bounds__(256) void sept_conv1_wgrad_mfma_kernel(const float*
       const int t = i >> 2, c = i & 3;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (q0 + t < HW) v = *reinterpret_cast<const uint4*>(dyb + size_t(t) * kC + c * 8);
-      *reinterpret_cast<uint4*>(yt + size_t(t) * kDyPS + c * 16) = v;
+      *reinterpret_cast<uint4*>(yt + size_t(t) * kDyPSt + c * 16) = v;
     }
     __syncthreads();
+    // this lane's 8-pixel group of each 16-pixel step: (row, column) advanced by 16 pixels per step, one division per tile
+    int gh, gw;
+    {
+      const int q = q0 + wave * (kMT / 4) + 8 * k_hi;
+      gh = q / W;
+      gw = q - gh * W;
+    }
+    const int last_q = HW - 8, last_h = last_q / W, last_w = last_q - last_h * W;   // groups past the image read the last one (dy = 0)
 #pragma unroll
     for (int ks = 0; ks < kMT / 64; ++ks) {
       const int kb = wave * (kMT / 4) + ks * 16;  // first pixel of this 16-pixel step
       // A: dy^T fragment (two transposing reads of 4 pixels x 16 channels)
       const int ta = kb + 8 * k_hi + tr_q;
       const bf16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-          (__attribute__((address_space(3))) bf16x4*)(reinterpret_cast<uintptr_t>(yt + size_t(ta) * kDyPS + tr_ch * 2)));
+          (__attribute__((address_space(3))) bf16x4*)(reinterpret_cast<uintptr_t>(yt + size_t(ta) * kDyPSt + tr_ch * 2)));
       const bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-          (__attribute__((address_space(3))) bf16x4*)(reinterpret_cast<uintptr_t>(yt + size_t(ta + 4) * kDyPS + tr_ch * 2)));
+          (__attribute__((address_space(3))) bf16x4*)(reinterpret_cast<uintptr_t>(yt + size_t(ta + 4) * kDyPSt + tr_ch * 2)));
       const bf16x8 afrag = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
       // B: 8 consecutive pixels (same image row: W % 8 == 0 and the group start is 8-aligned)
-      const int q = min(q0 + kb + 8 * k_hi, HW - 8);
-      const int h = q / W, w = q - h * W;
+      const bool inside = gh * W + gw <= last_q;
+      const int h = inside ? gh : last_h, w = inside ? gw : last_w;
       const float* xp = xt + (h - h_first) * W4 + w + tapoff;
+      gw += 16;
+      while (gw >= W) {
+        gw -= W;
+        ++gh;
+      }
       f32x8 xv;
 #pragma unroll
       for (int e = 0; e < 8; ++e) xv[e] = tap < kTaps ? xp[e] : (tap == kTaps ? 1.0f : 0.0f);
@@ -821,6 +979,20 @@ extern "C" int sept_conv1_backward_data(const void* dy, const float* w, float* w
                        static_cast<const float*>(nullptr), wprep);
   if (W * 4 <= 512 && H >= 1) {  // streaming MFMA form: a dy row fits two 16-byte chunks per lane
     const int NP = (W + 4 + 31) / 32 * 32;
+    static const bool ring_form = getenv("SEPT_CONV1_DGRAD_RING") != nullptr;   // tuning aid: the six-row LDS ring form
+    if (!ring_form) {
+      // register accumulators: two dy rows + two Z rows of LDS, four workgroups per CU (1024 at a time): as many row
+      // chunks as keep the whole grid resident in ONE round, at least 16 rows per chunk
+      const size_t smem_r = size_t(2) * NP * kDyPS + size_t(2) * NP * kZS * sizeof(float);
+      const int per_cu = int(std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / smem_r)));
+      int chunks = std::max(1, std::min((H + 15) / 16, 256 * per_cu / std::max(B, 1)));
+      const int rows = (H + chunks - 1) / chunks;
+      chunks = (H + rows - 1) / rows;
+      SEPT_HIP(sept::allow_max_lds(reinterpret_cast<const void*>(&sept_conv1_dgrad_stream2_kernel)));
+      hipLaunchKernelGGL(sept_conv1_dgrad_stream2_kernel, dim3(chunks, B), dim3(256), smem_r, st,
+                         static_cast<const bf16*>(dy), static_cast<const float*>(wprep), dx, B, H, W, rows);
+      return sept::launch_check("sept_conv1_dgrad_stream2_kernel");
+    }
     const size_t smem_s = size_t(2) * NP * kDyPS + size_t(kRing) * NP * kZS * sizeof(float);
     // Two workgroups fit on a CU (LDS), i.e. 512 at a time: as many row chunks as keep the whole
     // grid resident in ONE round (a second, partly filled round costs a full pass), at least 16

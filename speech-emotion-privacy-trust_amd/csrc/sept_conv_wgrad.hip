@@ -33,6 +33,12 @@ constexpr int kMT = 128;
 constexpr int kXCH = 13;  // max 16-byte input chunks a lane prefetches per tile
 
 __host__ __device__ constexpr int wg_nr_max(int w) { return (kMT + w - 2) / w + 5; }
+// Bytes per staged pixel for the TRANSPOSING reads: a 32-lane group of ds_read_b64_tr_b16 touches 4 consecutive pixels
+// x 16 words, so the pixel stride must be 16 words mod 64 for the four pixels to tile the 64 banks: 64 B for 32
+// channels (no padding at all), 192 B for 64 channels.  (The 16-byte padding that suits ds_read_b128 -- 80 / 144 B --
+// put pixels 0 / 2 and 1 / 3 on shared banks here: 46-48 % of this kernel's LDS cycles were conflicts, round-2 PMC.)
+// Row wraps add 4 pixel slots = a multiple of 64 words, so they change nothing.
+__host__ __device__ constexpr int wg_ps(int channels) { return channels * 2 + (channels % 64 == 0 ? 64 : 0); }
 
 struct WgArgs {
   const bf16* x;   // [B][H][W][CIN]
@@ -54,7 +60,7 @@ __global__ __launch_bounds__(64 * NW) void sept_conv5x5_wgrad_kernel(WgArgs a) {
   constexpr int NTHR = 64 * NW;
   constexpr int MSL = COUT / 32 / MBZ;  // output-channel slices
   constexpr int CX = NBZ * 32, CY = MBZ * 32;
-  constexpr int PSX = CX * 2 + 16, PSY = CY * 2 + 16;
+  constexpr int PSX = wg_ps(CX), PSY = wg_ps(CY);
   constexpr int CPP = CX / 8, CPY = CY / 8;
   constexpr int YCH = (kMT * CPY + NTHR - 1) / NTHR;
   constexpr int XCH = (kXCH * 256 + NTHR - 1) / NTHR;  // 16-byte input chunks a lane prefetches per tile
@@ -92,74 +98,105 @@ __global__ __launch_bounds__(64 * NW) void sept_conv5x5_wgrad_kernel(WgArgs a) {
   const long n_tiles = long(a.B) * tiles_per_img;
 
   uint4 xr[XCH], yr[YCH];
-  auto tile_geom = [&](long tile_id, int& b, int& q0, int& h_first, int& NR) {
-    b = tile_id / tiles_per_img;
-    q0 = int(tile_id % tiles_per_img) * kMT;
-    h_first = q0 / W;
-    NR = min(q0 + kMT - 1, HW - 1) / W - h_first + 5;
-  };
-  auto gload = [&](long tile_id) {
+  // Staging geometry.  Everything about a 16-byte chunk that does not depend on the tile -- its channel group, its
+  // (row, column) inside the staged rows, its LDS offset -- is computed ONCE: with 128-pixel tiles the per-tile
+  // integer divisions of the first version (per chunk in the loader and again in the store, plus 64-bit tile
+  // arithmetic three times per tile) cost more issue cycles than the tile's 48-64 MFMAs (round-2 PMC: 42 % of this
+  // kernel's cycles issued non-matrix instructions at 28 % matrix-pipe occupancy).
+  int xc_off[XCH], xc_rc[XCH];   // global element offset of the chunk's channel group / packed (row << 16 | column)
+  int xl_off[XCH];               // LDS byte offset
+#pragma unroll
+  for (int j = 0; j < XCH; ++j) {
+    const int i = tid + NTHR * j;
+    const int c = i % CPP, px = i / CPP;
+    const int col = px % W4, row = px / W4;
+    xc_off[j] = c * 8;
+    xc_rc[j] = (row << 16) | col;
+    xl_off[j] = px * PSX + c * 16;
+  }
+  int yc_off[YCH], yl_off[YCH], yc_t[YCH];
+#pragma unroll
+  for (int j = 0; j < YCH; ++j) {
+    const int i = tid + NTHR * j;
+    const int c = i % CPY, t = i / CPY;
+    yc_t[j] = t;
+    yc_off[j] = t * COUT + c * 8;
+    yl_off[j] = t * PSY + c * 16;
+  }
+  struct Geom {
     int b, q0, h_first, NR;
-    tile_geom(tile_id, b, q0, h_first, NR);
-    const bf16* xb = a.x + size_t(b) * HW * CIN + cin0;
-    const int total = NR * W4 * CPP;
+  };
+  auto tile_geom = [&](int b, int t) {
+    Geom g;
+    g.b = b;
+    g.q0 = t * kMT;
+    g.h_first = g.q0 / W;
+    g.NR = min(g.q0 + kMT - 1, HW - 1) / W - g.h_first + 5;
+    return g;
+  };
+  auto gload = [&](const Geom& g) {
+    const bf16* xb = a.x + size_t(g.b) * HW * CIN + cin0;
+    const int nrows = g.NR;
 #pragma unroll
     for (int j = 0; j < XCH; ++j) {
-      const int i = tid + NTHR * j;
+      const int row = xc_rc[j] >> 16, col = xc_rc[j] & 0xFFFF;
+      const int h = g.h_first - 2 + row, w = col - 2;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (i < total) {
-        const int c = i % CPP, px = i / CPP;
-        const int col = px % W4, row = px / W4;
-        const int h = h_first - 2 + row, w = col - 2;
-        if (h >= 0 && h < H && w >= 0 && w < W)
-          v = *reinterpret_cast<const uint4*>(xb + (size_t(h) * W + w) * CIN + c * 8);
-      }
+      if (row < nrows && h >= 0 && h < H && w >= 0 && w < W)
+        v = *reinterpret_cast<const uint4*>(xb + (size_t(h) * W + w) * CIN + xc_off[j]);
       xr[j] = v;
     }
-    const bf16* yb = a.dy + size_t(b) * HW * COUT + cout0;
+    const bf16* yb = a.dy + (size_t(g.b) * HW + g.q0) * COUT + cout0;
 #pragma unroll
     for (int j = 0; j < YCH; ++j) {
-      const int i = tid + NTHR * j;
-      const int c = i % CPY, t = i / CPY;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (t < kMT && q0 + t < HW) v = *reinterpret_cast<const uint4*>(yb + size_t(q0 + t) * COUT + c * 8);
+      if (yc_t[j] < kMT && g.q0 + yc_t[j] < HW) v = *reinterpret_cast<const uint4*>(yb + yc_off[j]);
       yr[j] = v;
     }
   };
-  auto lstore = [&](long tile_id, unsigned char* buf) {
-    int b, q0, h_first, NR;
-    tile_geom(tile_id, b, q0, h_first, NR);
-    const int total = NR * W4 * CPP;
+  auto lstore = [&](const Geom& g, unsigned char* buf) {
+    const int nrows = g.NR;
 #pragma unroll
-    for (int j = 0; j < XCH; ++j) {
-      const int i = tid + NTHR * j;
-      if (i < total) *reinterpret_cast<uint4*>(buf + size_t(i / CPP) * PSX + (i % CPP) * 16) = xr[j];
-    }
+    for (int j = 0; j < XCH; ++j)
+      if ((xc_rc[j] >> 16) < nrows) *reinterpret_cast<uint4*>(buf + xl_off[j]) = xr[j];
     unsigned char* yt = buf + xbytes;
 #pragma unroll
-    for (int j = 0; j < YCH; ++j) {
-      const int i = tid + NTHR * j;
-      if (i < kMT * CPY) *reinterpret_cast<uint4*>(yt + size_t(i / CPY) * PSY + (i % CPY) * 16) = yr[j];
-    }
+    for (int j = 0; j < YCH; ++j)
+      if (yc_t[j] < kMT) *reinterpret_cast<uint4*>(yt + yl_off[j]) = yr[j];
   };
 
   // each workgroup walks a CONTIGUOUS range of tiles: consecutive tiles share their halo rows, which
-  // then come from this XCD's L2 instead of HBM
-  long tile_id = n_tiles * blockIdx.x / gridDim.x;
-  const long tile_end = n_tiles * (blockIdx.x + 1) / gridDim.x;
-  if (tile_id < tile_end) {
-    gload(tile_id);
-    lstore(tile_id, smem);
+  // then come from this XCD's L2 instead of HBM.  (image, tile in image) advance by increment.
+  const long tile_begin = n_tiles * blockIdx.x / gridDim.x;
+  int n_left = int(n_tiles * (blockIdx.x + 1) / gridDim.x - tile_begin);
+  int tb = int(tile_begin / tiles_per_img), tt = int(tile_begin % tiles_per_img);
+  Geom g_cur = tile_geom(tb, tt);
+  if (n_left > 0) {
+    gload(g_cur);
+    lstore(g_cur, smem);
   }
   __syncthreads();
   int cur = 0;
-  for (; tile_id < tile_end; ++tile_id, cur ^= 1) {
-    const long next = tile_id + 1;
-    if (next < tile_end) gload(next);  // in flight under the MFMAs below
-    int b, q0, h_first, NR;
-    tile_geom(tile_id, b, q0, h_first, NR);
+  for (; n_left > 0; --n_left, cur ^= 1) {
+    if (++tt == tiles_per_img) {
+      tt = 0;
+      ++tb;
+    }
+    const Geom g_next = tile_geom(tb, tt);
+    if (n_left > 1) gload(g_next);  // in flight under the MFMAs below
+    const int q0 = g_cur.q0, h_first = g_cur.h_first;
     const unsigned char* xt = smem + size_t(cur) * bufbytes;
     const unsigned char* yt = xt + xbytes;
+    // (row, column) of this lane's two pixels per 16-pixel step, advanced by 16 pixels per step with a compare instead
+    // of a division per step
+    int ph[2], pw[2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int q = q0 + 8 * k_hi + tr_q + 4 * half;
+      ph[half] = q / W;
+      pw[half] = q - ph[half] * W;
+    }
+    const int last_h = (HW - 1) / W - h_first, last_w = (HW - 1) % W;   // pixels past the image read the last one (dy = 0 there)
 #pragma unroll 2
     for (int ks = 0; ks < kMT / 16; ++ks) {
       const int kb = ks * 16 + 8 * k_hi + tr_q;
@@ -169,9 +206,14 @@ __global__ __launch_bounds__(64 * NW) void sept_conv5x5_wgrad_kernel(WgArgs a) {
       for (int half = 0; half < 2; ++half) {
         const int t = kb + 4 * half;
         ya[half] = yt + size_t(t) * PSY + tr_ch * 2;
-        const int q = min(q0 + t, HW - 1);
-        const int h = q / W, w = q - h * W;
-        xa[half] = xt + size_t((h - h_first) * W4 + w) * PSX + tr_ch * 2;
+        const bool inside = ph[half] < H;
+        const int hr = inside ? ph[half] - h_first : last_h, wc = inside ? pw[half] : last_w;
+        xa[half] = xt + size_t(hr * W4 + wc) * PSX + tr_ch * 2;
+        pw[half] += 16;
+        while (pw[half] >= W) {
+          pw[half] -= W;
+          ++ph[half];
+        }
       }
       bf16x8 afrag[MBZ];
 #pragma unroll
@@ -192,7 +234,8 @@ __global__ __launch_bounds__(64 * NW) void sept_conv5x5_wgrad_kernel(WgArgs a) {
         }
       }
     }
-    if (next < tile_end) lstore(next, smem + size_t(cur ^ 1) * bufbytes);
+    if (n_left > 1) lstore(g_next, smem + size_t(cur ^ 1) * bufbytes);
+    g_cur = g_next;
     __syncthreads();
   }
 
@@ -255,7 +298,7 @@ int launch_wgrad(const WgArgs& a0, float* dw, hipStream_t st) {
   WgArgs a = a0;
   constexpr int Z = (COUT / 32 / MBZ) * (CIN / 32 / NBZ);
   constexpr int NBLK = 25 * MBZ * NBZ;
-  constexpr int PSX = NBZ * 64 + 16, PSY = MBZ * 64 + 16;
+  constexpr int PSX = wg_ps(NBZ * 32), PSY = wg_ps(MBZ * 32);
   a.nr_max = wg_nr_max(a.W);
   const size_t smem = 2 * (size_t(a.nr_max) * (a.W + 4) * PSX + size_t(kMT) * PSY);
   SEPT_REQUIRE(smem <= 160 * 1024 && a.nr_max * (a.W + 4) * (NBZ * 4) <= ((kXCH * 256 + 64 * NW - 1) / (64 * NW)) * 64 * NW, SEPT_ERR_UNSUPPORTED,

@@ -168,8 +168,9 @@ def _grad_report(grl, ref):
 
 def _is_conv_stack(name):
     """parameters whose gradient is formed inside / behind the bf16 conv stack -- including the first recurrent
-    layer's input weights, whose operand IS the stack's bf16 output (measured 3-5 %, cosine 0.9986-0.9995)"""
-    return name.startswith("intermed.") or ".conv." in name or name.startswith("conv.") or "rnn.weight_ih_l0" in name
+    layer, whose input IS the stack's bf16 output (measured 3-6 %, cosine 0.9984-0.9995)"""
+    return name.startswith("intermed.") or ".conv." in name or name.startswith("conv.") or \
+        ("rnn." in name and "_l0" in name)
 
 
 CONV_COS, CONV_REL = 0.995, 0.10   # gradients inside / behind the bf16 conv stack against the simulated-bf16 oracle

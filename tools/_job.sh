@@ -1,14 +1,12 @@
 set -e
 export TMPDIR=/tmp
-mkdir -p gpurun_out/r2l
-python -m pytest tests -m gpu -q --tb=line > gpurun_out/r2l/gpu_tests.log 2>&1 || true
-grep -E "^/root|^E |Error|passed|failed" gpurun_out/r2l/gpu_tests.log | cut -c1-300 | head -30
-for i in 1 2; do
-python bench.py --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/r2l/bench_$i.json 2> gpurun_out/r2l/bench_$i.err || { tail -30 gpurun_out/r2l/bench_$i.err; exit 1; }
-python - <<PY
+O=gpurun_out/r2r
+mkdir -p $O
+python3 tools/bench_parts2.py 2>&1 | grep -v amdgpu
+python -m pytest tests -m gpu -q --tb=line > $O/gpu_tests.log 2>&1 || true
+grep -E "^/root|^E |Error|passed|failed" $O/gpu_tests.log | cut -c1-300 | head -20
+python bench.py --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err
+python - <<'PY'
 import json
-d=json.load(open("gpurun_out/r2l/bench_$i.json")); print(d["value"], d["ms_per_step"], d["roofline"]["kernel"], d["roofline"]["frac"], d["roofline"]["alone"]["frac"], d["reference_batch"]["ms_per_step"])
+d=json.load(open("gpurun_out/r2r/bench.json")); print(d["value"], d["ms_per_step"], d["vs_cpu_baseline"], d["roofline"]["kernel"], d["roofline"]["frac"], d["roofline"]["alone"]["frac"], d["reference_batch"]["ms_per_step"], d["cpu_baseline"]["value"], d["cpu_baseline"]["one_thread"]["value"])
 PY
-done
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/r2l/replay -- python3 bench.py --replay-only --steps 30 --warmup 3 > gpurun_out/r2l/replay.log 2>&1
-python3 tools/replay_stats.py gpurun_out/r2l/replay 30 gpurun_out/r2l/replay_kernel_stats.csv
