@@ -277,6 +277,21 @@ int sept_bn_relu_pool_backward_presummed(const void* dy, const void* x, const fl
                                          const float* partials, int nparts, float* ws, void* dx, float* dgamma,
                                          float* dbeta, int B, int H, int W, int C, int pool, void* stream);
 
+/* conv1's data gradient straight from the BatchNorm-backward inputs -- the gradient of conv1's output (dpre, 64 bytes
+ * per pixel) is formed in the kernel's row loader from conv1's stored output `pre`, the gradient of the pooled
+ * activation and the two channel sums, and is never written for a network without weight gradients (dpre_out NULL:
+ * the frozen emotion model, cloak_models.py:142-144) or written once for conv1's weight gradient.  sums[2*32] as
+ * left by sept_bn_relu_pool_backward_reduce or sept_bn_backward_sums_presummed (= finalize of a producer's partials,
+ * tiny-|gamma| chunks re-summed from the windows; also yields dgamma / dbeta); n_total = elements per channel. */
+int sept_bn_backward_sums_presummed(const void* dy, const void* x, const float* mean, const float* invstd,
+                                    const float* gamma, const float* beta, const float* dropscale, const float* partials,
+                                    int nparts, float* ws, float* sums_out, float* dgamma, float* dbeta, int B, int H,
+                                    int W, int C, int pool, void* stream);
+int sept_conv1_backward_data_bn(const void* pre, const void* dy_pooled, const float* mean, const float* invstd,
+                                const float* gamma, const float* beta, const float* dropscale, const float* sums,
+                                double n_total, const float* w, float* wprep, float* dx, void* dpre_out, int B, int H,
+                                int W, void* stream);
+
 /* conv1's weights in operand form: every sept_conv1_* entry point builds it into `wprep` from (w, bias) unless called
  * with w == NULL ("wprep is current"); sept_conv1_prep builds it explicitly so a caller can keep it across calls. */
 int sept_conv1_prep(const float* w, const float* bias, float* wprep, void* stream);

@@ -584,6 +584,32 @@ extern "C" int sept_bn_relu_pool_backward_presummed(const void* dy, const void* 
   return sept::launch_check("sept_bn_relu_pool_backward_presummed");
 }
 
+// The sums alone (no apply pass) from a producer's partials, with the same tiny-|gamma| re-summation: sums_out[2C]
+// (sum g, sum g * xhat) for a consumer that applies them itself (sept_conv1_backward_data_bn).
+extern "C" int sept_bn_backward_sums_presummed(const void* dy, const void* x, const float* mean, const float* invstd,
+                                               const float* gamma, const float* beta, const float* dropscale,
+                                               const float* partials, int nparts, float* ws, float* sums_out,
+                                               float* dgamma, float* dbeta, int B, int H, int W, int C, int pool,
+                                               void* stream) {
+  SEPT_REQUIRE(B > 0 && H > 0 && W > 0 && (pool == 1 || pool == 2) && nparts > 0, SEPT_ERR_INVALID,
+               "sept_bn_backward_sums_presummed: B=%d H=%d W=%d pool=%d nparts=%d", B, H, W, pool, nparts);
+  SEPT_REQUIRE(dy && x && mean && invstd && gamma && beta && partials && ws && sums_out, SEPT_ERR_INVALID,
+               "sept_bn_backward_sums_presummed: null argument");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  BnBwdArgs a{static_cast<const bf16*>(dy), static_cast<const bf16*>(x), nullptr, mean, invstd, gamma, beta, dropscale, ws,
+              nullptr, B, H, W, C, pool, nullptr, 0.f};
+  const long items = long(B) * (H / pool) * (W / pool) * (C / 8);
+  const int grid = grid_for(items, 64);
+  if (pool == 2) {
+    SEPT_CPP_DISPATCH(C, hipLaunchKernelGGL((sept_bn_bwd_reduce_small_kernel<CPP, 2>), dim3(grid), dim3(256), 0, st, a));
+  } else {
+    SEPT_CPP_DISPATCH(C, hipLaunchKernelGGL((sept_bn_bwd_reduce_small_kernel<CPP, 1>), dim3(grid), dim3(256), 0, st, a));
+  }
+  hipLaunchKernelGGL(sept_bn_bwd_finalize2_kernel, dim3(C), dim3(256), 0, st, partials, nparts, ws, grid, gamma, C, dgamma,
+                     dbeta, sums_out);
+  return sept::launch_check("sept_bn_backward_sums_presummed");
+}
+
 // ---- sync-BN (statistics over all ranks; SURVEY.md section 8e option 1): the fused entry points split
 // at the point where the per-channel sums exist, so the caller can all-reduce them in between ----
 extern "C" int sept_bn_partial_sums(const void* x, long n_rows, int C, float* ws, double* sums, void* stream) {

@@ -602,6 +602,207 @@ __global__ __launch_bounds__(256, 4) void sept_conv1_dgrad_stream2_kernel(const 
   }
 }
 
+// ---- data gradient with the BatchNorm backward "apply" pass folded into its row loader -----------------------------
+// sept_conv1_dgrad_stream2_kernel consumes the gradient of conv1's output (dpre, 64 B per pixel) row by row.  That
+// tensor is itself a pointwise function of conv1's stored output (pre), the gradient of the POOLED activation (dyp,
+// a quarter of the pixels) and two per-channel sums: dpre = sc * (ge - m1 - xhat * m2), ge = the pooled gradient
+// at the window's first maximum (sept_bn_bwd_apply_kernel).  Here the loader fetches pre rows in PAIRS (a 2x2 pooling
+// window is two rows x two neighbouring pixels: one thread fetches all four 16-byte chunks of its 8 channels)
+// plus the pooled gradient row, forms both dpre rows in registers and feeds them to the
+// same MFMA / gather pipeline -- so the 229 MB dpre tensor is neither written nor read for a network that needs no
+// weight gradient (the frozen emotion model), and written once (`dpre_out`) for one that does.
+struct C1BnArgs {
+  const bf16* pre;    // [B][H][W][32] conv1 output (pre-BatchNorm)
+  const bf16* dyp;    // [B][H/2][W/2][32] gradient of the pooled activation
+  const float *mean, *invstd, *gamma, *beta, *drop, *sums;   // drop [B][32] or null; sums [64] = sum g, sum g * xhat
+  float inv_n;
+  const float* wprep;
+  float* dx;          // [B][H][W]
+  bf16* dpre_out;     // [B][H][W][32] or null
+  int B, H, W, rows_per_chunk;
+};
+
+__device__ __forceinline__ unsigned lane_xor4(unsigned v) {   // value of lane ^ 4 (ds_swizzle bit mode: and 0x1F, xor 4)
+  return unsigned(__builtin_amdgcn_ds_swizzle(int(v), 0x101F));
+}
+
+__global__ __launch_bounds__(256, 3) void sept_conv1_dgrad_bnapply_kernel(C1BnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int H = a.H, W = a.W, W4 = W + 4;
+  const int NP = (W4 + 31) / 32 * 32;
+  unsigned char* dyrow = smem;                                              // [2][NP][kDyPS]
+  float* zbuf = reinterpret_cast<float*>(smem + size_t(2) * NP * kDyPS);    // [2][NP][kZS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y;
+  const int r0 = blockIdx.x * a.rows_per_chunk, r1 = min(H, r0 + a.rows_per_chunk);   // both even
+  const bf16* preb = a.pre + size_t(b) * H * W * kC;
+  const bf16* dypb = a.dyp + size_t(b) * (H / 2) * (W / 2) * kC;
+  bf16* outb = a.dpre_out ? a.dpre_out + size_t(b) * H * W * kC : nullptr;
+
+  for (int i = tid; i < 2 * NP * (kDyPS / 16); i += 256) reinterpret_cast<uint4*>(dyrow)[i] = make_uint4(0, 0, 0, 0);
+  const int tap = lane & 31;
+  bf16x8 bw[2];
+  {
+    const uint4* wflip = reinterpret_cast<const uint4*>(a.wprep + kTaps * kC + kC);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (tap < kTaps) v = wflip[tap * 4 + ks * 2 + (lane >> 5)];
+      bw[ks] = __builtin_bit_cast(bf16x8, v);
+    }
+  }
+  // A thread owns one pooling-window COLUMN and one group of 8 channels: thread t -> window column t >> 2 (pixels
+  // 2 * (t >> 2) and + 1 of both rows of a pair), channels 8 * (t & 3) .. + 7.  Each window is evaluated once, by
+  // one thread, from four 16-byte chunks of pre and one of the pooled gradient -- no lane exchange, no duplicated
+  // arithmetic.  BatchNorm constants in the form the apply pass needs:
+  //   relu test / arg-max : r = max(v * sc + sh, 0);   dpre = scd * g_pooled [winner] + (c0 + c1 * v)
+  //   with c1 = -sc * m2 * invstd, c0 = -sc * m1 - c1 * mean, scd = sc * dropscale  (= sc * (ge - m1 - xhat * m2))
+  const int cg = tid & 3, wc = tid >> 2;
+  const bool owner = wc < W / 2;
+  float sc[8], sh[8], scd[8], c0[8], c1[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int ch = 8 * cg + e;
+    const float is = a.invstd[ch], mu = a.mean[ch];
+    sc[e] = a.gamma[ch] * is;
+    sh[e] = __builtin_fmaf(-mu, sc[e], a.beta[ch]);
+    scd[e] = sc[e] * (a.drop ? a.drop[size_t(b) * kC + ch] : 1.0f);
+    c1[e] = -sc[e] * (a.sums[kC + ch] * a.inv_n) * is;
+    c0[e] = -sc[e] * (a.sums[ch] * a.inv_n) - c1[e] * mu;
+  }
+  // raw data of one window column of a row pair: pre rows y (even) and y + 1, two pixels each; the pooled gradient
+  struct Raw {
+    uint4 a0, a1, b0, b1, g;
+  };
+  const int wcc = min(wc, W / 2 - 1);      // idle threads re-read the last window (never stored)
+  auto gload = [&](int y, Raw& r) {        // y even; clamped addresses (rows outside the image are zeroed at use)
+    const int yc = min(max(y, 0), H - 2);
+    const bf16* ra = preb + (size_t(yc) * W + 2 * wcc) * kC + cg * 8;
+    r.a0 = *reinterpret_cast<const uint4*>(ra);
+    r.a1 = *reinterpret_cast<const uint4*>(ra + kC);
+    r.b0 = *reinterpret_cast<const uint4*>(ra + size_t(W) * kC);
+    r.b1 = *reinterpret_cast<const uint4*>(ra + size_t(W) * kC + kC);
+    r.g = *reinterpret_cast<const uint4*>(dypb + (size_t(yc >> 1) * (W / 2) + wcc) * kC + cg * 8);
+  };
+  // dpre chunks of the window's four pixels: row y (da[0], da[1]) and row y + 1 (db[0], db[1])
+  auto apply = [&](int y, const Raw& r, uint4 (&da)[2], uint4 (&db)[2]) {
+    const bool inside = y >= 0 && y < H;
+    const bf16x8 v0 = __builtin_bit_cast(bf16x8, r.a0), v1 = __builtin_bit_cast(bf16x8, r.a1);
+    const bf16x8 v2 = __builtin_bit_cast(bf16x8, r.b0), v3 = __builtin_bit_cast(bf16x8, r.b1);
+    const bf16x8 gq = __builtin_bit_cast(bf16x8, r.g);
+    bf16x8 o0, o1, o2, o3;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x0 = float(v0[e]), x1 = float(v1[e]), x2 = float(v2[e]), x3 = float(v3[e]);
+      // scan order of the window: (y, even col), (y, odd col), (y + 1, even col), (y + 1, odd col); first maximum wins
+      const float q0 = fmaxf(__builtin_fmaf(x0, sc[e], sh[e]), 0.f), q1 = fmaxf(__builtin_fmaf(x1, sc[e], sh[e]), 0.f);
+      const float q2 = fmaxf(__builtin_fmaf(x2, sc[e], sh[e]), 0.f), q3 = fmaxf(__builtin_fmaf(x3, sc[e], sh[e]), 0.f);
+      const float best = fmaxf(fmaxf(q0, q1), fmaxf(q2, q3));
+      const float g = best > 0.f ? float(gq[e]) * scd[e] : 0.f;
+      const bool w0 = q0 == best, w1 = !w0 && q1 == best, w2 = !w0 && !w1 && q2 == best, w3 = !w0 && !w1 && !w2;
+      o0[e] = (bf16)((w0 ? g : 0.f) + __builtin_fmaf(c1[e], x0, c0[e]));
+      o1[e] = (bf16)((w1 ? g : 0.f) + __builtin_fmaf(c1[e], x1, c0[e]));
+      o2[e] = (bf16)((w2 ? g : 0.f) + __builtin_fmaf(c1[e], x2, c0[e]));
+      o3[e] = (bf16)((w3 ? g : 0.f) + __builtin_fmaf(c1[e], x3, c0[e]));
+    }
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    da[0] = inside ? __builtin_bit_cast(uint4, o0) : z;
+    da[1] = inside ? __builtin_bit_cast(uint4, o1) : z;
+    db[0] = inside ? __builtin_bit_cast(uint4, o2) : z;
+    db[1] = inside ? __builtin_bit_cast(uint4, o3) : z;
+  };
+  auto lstore = [&](int buf, int y, const uint4 (&d)[2]) {
+    if (!owner) return;
+    const bool inside = y >= 0 && y < H;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int px = 2 * wc + j;
+      *reinterpret_cast<uint4*>(dyrow + size_t(buf) * NP * kDyPS + size_t(px + 2) * kDyPS + cg * 16) = d[j];
+      if (outb && inside && y >= r0 && y < r1) *reinterpret_cast<uint4*>(outb + (size_t(y) * W + px) * kC + cg * 8) = d[j];
+    }
+  };
+  Raw raw0, raw1;
+  uint4 da[2], db[2];
+  __syncthreads();
+  gload(r0 - 2, raw0);
+  gload(r0, raw1);
+  apply(r0 - 2, raw0, da, db);
+  lstore(0, r0 - 2, da);
+  __syncthreads();
+
+  const int gp = (3 - wave) * 64 + lane;
+  const bool gather = gp < W;
+  float oacc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  const int nsteps = (r1 - r0) + 5;
+  // step s handles dpre row y = r0 - 2 + s from LDS buffer s & 1.  Even s (y even): the held odd row y + 1 (db) is
+  // stored at the end and the raw pair y + 4 is requested; odd s: the next pair (raw rows y + 1, y + 2) is applied
+  // and its even row stored.
+  // the MFMA + gather part of a step (dpre row y = r0 - 2 + s from LDS buffer s & 1), shared by both step kinds
+  auto mid = [&](int s) {
+    const int y = r0 - 2 + s;
+    if (s < nsteps - 1) {
+      const unsigned char* cur = dyrow + size_t(s & 1) * NP * kDyPS;
+      float* zrow = zbuf + size_t(s & 1) * NP * kZS;
+      for (int blk = wave; blk < NP / 32; blk += 4) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const bf16x8 av = *reinterpret_cast<const bf16x8*>(cur + size_t(blk * 32 + (lane & 31)) * kDyPS + ks * 32 + (lane >> 5) * 16);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bw[ks], acc, 0, 0, 0);
+        }
+        if (tap < kTaps) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int px = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            zrow[px * kZS + tap] = acc[r];
+          }
+        }
+      }
+    }
+    if (s >= 1 && gather) {
+      const float* zr = zbuf + size_t((s - 1) & 1) * NP * kZS + gp * kZS;
+#pragma unroll
+      for (int dh = 0; dh < 5; ++dh) {
+        float sum = 0.f;
+#pragma unroll
+        for (int dw = 0; dw < 5; ++dw) sum += zr[dw * kZS + dh * 5 + dw];
+        oacc[4 - dh] += sum;
+      }
+      const int r = y - 3;
+      if (r >= r0 && r < r1) a.dx[(size_t(b) * H + r) * W + gp] = oacc[0];
+      oacc[0] = oacc[1];
+      oacc[1] = oacc[2];
+      oacc[2] = oacc[3];
+      oacc[3] = oacc[4];
+      oacc[4] = 0.f;
+    }
+  };
+  // even step (y even): request the raw pair y + 4, run the row, store the held odd row y + 1 of the current pair
+  auto even_step = [&](int s, Raw& req) {
+    const int y = r0 - 2 + s;
+    gload(y + 4, req);
+    mid(s);
+    lstore((s + 1) & 1, y + 1, db);
+    sept::lds_barrier();
+  };
+  // odd step: run the row, form the next pair (rows y + 1 even, y + 2) from its raw rows and store its even row
+  auto odd_step = [&](int s, const Raw& nxt) {
+    const int y = r0 - 2 + s;
+    mid(s);
+    apply(y + 1, nxt, da, db);
+    lstore((s + 1) & 1, y + 1, da);
+    sept::lds_barrier();
+  };
+  for (int s = 0; s < nsteps; s += 4) {
+    even_step(s, raw0);                               // pair y already applied (da stored, db held); pair y + 2 is in raw1
+    if (s + 1 < nsteps) odd_step(s + 1, raw1);
+    if (s + 2 < nsteps) even_step(s + 2, raw1);       // pair y + 4 (requested two steps ago) is in raw0
+    if (s + 3 < nsteps) odd_step(s + 3, raw0);
+  }
+}
+
 // ---- weight gradient on MFMA (image width a multiple of 8) -------------------------------
 // D[c][tap] += sum_pixels dy[pixel][c] * x[pixel + tap]:  A[c][pixel] comes from the NHWC dy tile by
 // the transposing LDS read (as in sept_conv_wgrad.hip); B[pixel][tap] is built on the fly -- lane
@@ -1129,4 +1330,36 @@ extern "C" int sept_conv1_prep(const float* w, const float* bias, float* wprep, 
   hipLaunchKernelGGL(sept_conv1_prep_kernel, dim3((kTaps * kC + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), w,
                      bias, wprep);
   return sept::launch_check("sept_conv1_prep_kernel");
+}
+
+// Data gradient of conv1 straight from the BatchNorm backward inputs (no dpre tensor): see
+// sept_conv1_dgrad_bnapply_kernel.  sums[64] = (sum g, sum g * xhat) as sept_bn_relu_pool_backward_reduce /
+// sept_bn_bwd_sums_from_partials leave them; n_total = elements per channel they cover.  dpre_out (nullable)
+// receives the gradient of conv1's output for a weight-gradient launch.  H, W even, W <= 128.
+extern "C" int sept_conv1_backward_data_bn(const void* pre, const void* dy_pooled, const float* mean,
+                                           const float* invstd, const float* gamma, const float* beta,
+                                           const float* dropscale, const float* sums, double n_total, const float* w,
+                                           float* wprep, float* dx, void* dpre_out, int B, int H, int W, void* stream) {
+  if (int e = conv1_check("sept_conv1_backward_data_bn", B, H, W)) return e;
+  if (B == 0) return SEPT_OK;
+  SEPT_REQUIRE(pre && dy_pooled && mean && invstd && gamma && beta && sums && wprep && dx && n_total > 0, SEPT_ERR_INVALID,
+               "sept_conv1_backward_data_bn: null argument");
+  SEPT_REQUIRE(H % 2 == 0 && W % 2 == 0 && W * 4 <= 512 && H >= 2, SEPT_ERR_UNSUPPORTED,
+               "sept_conv1_backward_data_bn: H=%d W=%d (needs even H, even W <= 128)", H, W);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (w)
+    hipLaunchKernelGGL(sept_conv1_prep_kernel, dim3((kTaps * kC + 255) / 256), dim3(256), 0, st, w,
+                       static_cast<const float*>(nullptr), wprep);
+  const int NP = (W + 4 + 31) / 32 * 32;
+  const size_t smem_r = size_t(2) * NP * kDyPS + size_t(2) * NP * kZS * sizeof(float);
+  const int per_cu = int(std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / smem_r)));
+  int chunks = std::max(1, std::min((H + 15) / 16, 256 * per_cu / std::max(B, 1)));
+  int rows = (H + chunks - 1) / chunks;
+  rows += rows & 1;                                   // pooling windows must not straddle chunks
+  chunks = (H + rows - 1) / rows;
+  C1BnArgs a{static_cast<const bf16*>(pre), static_cast<const bf16*>(dy_pooled), mean, invstd, gamma, beta, dropscale, sums,
+             float(1.0 / n_total), wprep, dx, static_cast<bf16*>(dpre_out), B, H, W, rows};
+  SEPT_HIP(sept::allow_max_lds(reinterpret_cast<const void*>(&sept_conv1_dgrad_bnapply_kernel)));
+  hipLaunchKernelGGL(sept_conv1_dgrad_bnapply_kernel, dim3(chunks, B), dim3(256), smem_r, st, a);
+  return sept::launch_check("sept_conv1_dgrad_bnapply_kernel");
 }

@@ -132,6 +132,9 @@ SIGNATURES = {
     "sept_conv5x5_dgrad_bnsums": (c_int, [c_void_p] * 8 + [c_int] * 5 + [c_void_p]),
     "sept_bn_relu_pool_backward_presummed": (c_int, [c_void_p] * 8 + [c_int, c_void_p, c_void_p, c_void_p, c_void_p] +
                                              [c_int] * 5 + [c_void_p]),
+    "sept_bn_backward_sums_presummed": (c_int, [c_void_p] * 8 + [c_int, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 5 +
+                                        [c_void_p]),
+    "sept_conv1_backward_data_bn": (c_int, [c_void_p] * 8 + [c_double] + [c_void_p] * 4 + [c_int] * 3 + [c_void_p]),
     "sept_conv1_prep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "sept_conv1_fused_supported": (c_int, [c_int, c_int]),
     "sept_conv1_stats_only": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p]),

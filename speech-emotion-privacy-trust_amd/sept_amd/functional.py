@@ -457,6 +457,12 @@ L1_FUSED = {"0": "never", "1": "always", "always": "always", "never": "never"}.g
 # BatchNorm backward sums of blocks 1 / 2 from the epilogue of the data-gradient conv that produces their dy
 # (SEPT_BN_DGRAD_SUMS=0: the separate reduce pass over the pooled tensors)
 BN_SUMS_IN_DGRAD = os.environ.get("SEPT_BN_DGRAD_SUMS", "1") != "0"
+# block 1's BatchNorm backward apply pass inside conv1's data gradient (sept_conv1_backward_data_bn: no gradient-of-
+# conv1-output tensor for the frozen network).  OFF by default: measured (round 2, gpurun_out/r2t) 211 us against
+# 174 us for the separate apply + data-gradient launches at 224 windows -- the apply arithmetic sits in the row
+# loader's serial chain (load -> apply -> LDS -> MFMA -> LDS -> gather) and lengthens every step more than the
+# 229 MB it saves; SEPT_BN_APPLY_DGRAD=1 selects it (tests keep it correct).
+BN_APPLY_IN_DGRAD = os.environ.get("SEPT_BN_APPLY_DGRAD", "0") == "1"
 # BatchNorm statistics of the 5x5 conv layers from the conv kernel's epilogue (SEPT_CONV_STATS=0: a separate pass)
 CONV_FUSED_STATS = os.environ.get("SEPT_CONV_STATS", "1") != "0"
 NO_WGRAD_FORK = set()
@@ -612,6 +618,25 @@ def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq, go
         if not blk.bn_train:
             raise SeptError("backward through an eval-mode BatchNorm is not implemented on the HIP path")
         want_bn = need_wgrad and bn.weight.requires_grad
+        if (li == 0 and BN_APPLY_IN_DGRAD and need_dx and not blk.l1_fused and not blk.sync and blk.pool == 2
+                and blk.pre.shape[1] % 2 == 0 and blk.pre.shape[2] % 2 == 0 and blk.pre.shape[2] <= 128):
+            # block 1: the BatchNorm backward apply pass lives in conv1's data-gradient row loader -- the 64-byte-per-
+            # pixel gradient of conv1's output is only materialised when conv1's weight gradient needs it
+            want_w = need_wgrad and cv.weight.requires_grad
+            dx, dpre, dgamma, dbeta = ops.conv1_backward_data_bn(
+                blk.pre, dact, blk.mean, blk.invstd, bn.weight, bn.bias, blk.drop, cv.weight, presums=presums,
+                want_dpre=want_w, need_param_grads=want_bn, out_gamma=gout(bn.weight) if want_bn else None,
+                out_beta=gout(bn.bias) if want_bn else None, prep=_conv1_operand(cv),
+                y=blk.out if BN_POOLED_SUMS else None)
+            if want_bn:
+                put(bn.weight, dgamma)
+                put(bn.bias, dbeta)
+            if want_w:
+                dw, db = sq.big(lambda dpre=dpre: ops.conv1_backward_weight(S.x, dpre, out_w=gout(cv.weight),
+                                                                            out_b=gout(cv.bias)), dpre, S.x)
+                put(cv.weight, dw)
+                put(cv.bias, db)
+            continue
         if blk.l1_fused:
             dpre, dgamma, dbeta = ops.conv1_bn_relu_pool_backward(S.x, cv.weight, cv.bias, dact, blk.mean, blk.invstd,
                                                                   bn.weight, bn.bias, blk.drop, need_param_grads=want_bn,

@@ -373,6 +373,42 @@ def bn_relu_pool_backward_presummed(dy, x, mean, invstd, gamma, beta, dropscale,
     return dx, dgamma, dbeta
 
 
+def conv1_backward_data_bn(pre, dy, mean, invstd, gamma, beta, dropscale, w, presums=None, want_dpre=False,
+                           need_param_grads=True, out_gamma=None, out_beta=None, prep=None, y=None):
+    """Backward of block 1 (BatchNorm + ReLU + MaxPool 2x2 + Dropout2d behind conv1) fused into conv1's data gradient:
+    pre (B,H,W,32) bf16 = conv1's stored output, dy (B,H/2,W/2,32) bf16 = gradient of the pooled activation.
+    Returns (dx (B,H,W) fp32, dpre or None, dgamma, dbeta); dpre (B,H,W,32) bf16 only when `want_dpre` (conv1's
+    weight gradient needs it).  `presums` = the (partials, count) a data-gradient conv left; else the sums are taken
+    here, from the pooled tensors when the pooled output `y` is given, from every window of `pre` otherwise."""
+    require_cuda(pre, dy, w)
+    B, H, W, C = pre.shape
+    dev = pre.device
+    ws = workspace("bn", lib.sept_bn_workspace_floats(C), dev)
+    sums = torch.empty(2 * C, dtype=torch.float32, device=dev)
+    dgamma = dbeta = None
+    if need_param_grads:
+        dgamma = torch.empty(C, dtype=torch.float32, device=dev) if out_gamma is None else out_gamma
+        dbeta = torch.empty(C, dtype=torch.float32, device=dev) if out_beta is None else out_beta
+    if presums is not None:
+        parts, nparts = presums
+        check(lib.sept_bn_backward_sums_presummed(dy.data_ptr(), pre.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                                  gamma.data_ptr(), beta.data_ptr(), _p(dropscale), parts.data_ptr(), nparts,
+                                                  ws.data_ptr(), sums.data_ptr(), _p(dgamma), _p(dbeta), B, H, W, C, 2,
+                                                  _s(pre)), "sept_bn_backward_sums_presummed")
+    else:
+        check(lib.sept_bn_relu_pool_backward_reduce(dy.data_ptr(), pre.data_ptr(), _p(y), mean.data_ptr(), invstd.data_ptr(),
+                                                    gamma.data_ptr(), beta.data_ptr(), _p(dropscale), ws.data_ptr(),
+                                                    sums.data_ptr(), _p(dgamma), _p(dbeta), B, H, W, C, 2, _s(pre)),
+              "sept_bn_relu_pool_backward_reduce")
+    dx = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    dpre = torch.empty_like(pre) if want_dpre else None
+    wptr, wp = _c1w(pre, w, prep, "conv1_prep_bwd")
+    check(lib.sept_conv1_backward_data_bn(pre.data_ptr(), dy.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+                                          beta.data_ptr(), _p(dropscale), sums.data_ptr(), float(B) * H * W, wptr, wp.data_ptr(),
+                                          dx.data_ptr(), _p(dpre), B, H, W, _s(pre)), "sept_conv1_backward_data_bn")
+    return dx, dpre, dgamma, dbeta
+
+
 def conv5x5_backward_weight(x, dy, out=None):
     """x (B,H,W,cin) bf16, dy (B,H,W,cout) bf16 -> dW (cout,cin,5,5) fp32."""
     require_cuda(x, dy)

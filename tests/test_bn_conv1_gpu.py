@@ -244,3 +244,35 @@ def test_layer1_without_preactivation_tensor_equals_the_separate_kernels(B, H, W
     moved = ((d - d2).abs() > d.abs() * 2 ** -6 + 1e-3 * float(d.abs().max())).float().mean()
     assert moved < 1e-3, float(moved)
     assert float((d - d2).norm() / d.norm()) < 2e-2
+
+
+@pytest.mark.parametrize("B,H,W", [(3, 200, 80), (2, 200, 128), (2, 34, 16), (1, 6, 6), (3, 50, 22)])
+@pytest.mark.parametrize("drop", [False, True])
+@pytest.mark.parametrize("want_dpre", [False, True])
+def test_conv1_data_gradient_with_batchnorm_apply_folded_in(B, H, W, drop, want_dpre):
+    """sept_conv1_backward_data_bn (BatchNorm backward apply inside conv1's data-gradient row loader) against the
+    separate passes sept_bn_relu_pool_backward -> sept_conv1_backward_data, which the tests above hold to torch:
+    the same dgamma / dbeta, the same gradient of conv1's output (when asked for) up to a bf16 rounding of the
+    re-associated affine, the same dx."""
+    from sept_amd import ops
+    g = torch.Generator().manual_seed(H * W + B)
+    pre = (torch.randn(B, H, W, 32, generator=g) * 1.4 + 0.2).bfloat16().cuda()
+    w = (torch.randn(32, 1, 5, 5, generator=g) * 0.2).cuda()
+    gamma = 1 + 0.3 * torch.randn(32, generator=g)
+    gamma[7], gamma[20] = 3e-5, -0.6
+    gamma, beta = gamma.cuda(), (0.2 * torch.randn(32, generator=g)).cuda()
+    dmask = ((torch.rand(B, 32, generator=g) > 0.2).float() * 1.25).cuda() if drop else None
+    mean, invstd = ops.bn_stats(pre)
+    y = ops.bn_relu_pool_forward(pre, mean, invstd, gamma, beta, dmask, 2)
+    dy = torch.randn(B, H // 2, W // 2, 32, generator=g).bfloat16().cuda()
+    want_dpre_t, want_dg, want_db = ops.bn_relu_pool_backward(dy, pre, mean, invstd, gamma, beta, dmask, 2, y=y)
+    want_dx = ops.conv1_backward_data(want_dpre_t, w)
+    dx, dpre, dg, db = ops.conv1_backward_data_bn(pre, dy, mean, invstd, gamma, beta, dmask, w, want_dpre=want_dpre, y=y)
+    assert (dpre is not None) == want_dpre
+    assert torch.allclose(dg, want_dg, rtol=1e-5, atol=1e-6) and torch.allclose(db, want_db, rtol=1e-5, atol=1e-6)
+    if want_dpre:
+        d, d2 = want_dpre_t.float(), dpre.float()
+        assert ((d - d2).abs() <= d.abs() * 2 ** -7 + 1e-6 * float(d.abs().max())).all(), (d - d2).abs().max()
+    scale = float(want_dx.abs().max())
+    assert torch.allclose(dx, want_dx, rtol=2e-2, atol=2e-3 * scale), float((dx - want_dx).abs().max()) / scale
+    assert float((dx - want_dx).norm() / want_dx.norm()) < 3e-3

@@ -45,7 +45,7 @@ def main(fetch_dir, write_dir, out):
         kernels[name[:90]] = {"tag": tag_of(name), "FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1),
                               "hbm_bytes_per_launch": int((2 * f + w) * 1024), "launches": len(fe.get(name, []))}
     note = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, no trace domains) of `python3 bench.py "
-            "--steps 3 --warmup 1 --no-cpu-baseline` (32 clips = 224 windows, F=80).  Counter unit KiB.  "
+            "--steps 3 --warmup 1 --no-cpu-baseline --no-ref-batch` (32 clips = 224 windows, F=80).  Counter unit KiB.  "
             "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 FETCH_SIZE reports half the bytes of 16-B/lane "
             "streaming reads (MI355X_MICROARCH.md, HBM section); check: sept_bn_stats_partial_kernel<4> reads "
             "exactly 224*200*80*32*2 = 229.4 MB.  Means over all launches of a kernel name (the mel kernel mixes "
