@@ -74,8 +74,9 @@ __host__ __device__ constexpr int conv_nr_max(int mt, int w) { return (mt + w - 
 // tile goes through the LDS (free by then) and is summed by columns, which costs no registers: the 8-wave shapes
 // sit at the 128-VGPR limit that lets two workgroups share a CU.
 __host__ __device__ constexpr size_t conv_row_pitch(int w, int ps) { return size_t(w + 4) * ps + kRowPad; }
+__host__ __device__ constexpr size_t conv_epilogue_smem(int mt, int cout) { return size_t(mt) * (cout * 2 + 16); }
 __host__ __device__ constexpr size_t conv_stats_smem(int mt, int cout, int nthr) {
-  return size_t(mt) * (cout * 2 + 8) + size_t(nthr / cout) * 2 * cout * sizeof(float);
+  return conv_epilogue_smem(mt, cout) + size_t(nthr / cout) * 2 * cout * sizeof(float);
 }
 
 // (Second launch bound = waves per SIMD: the statistics form of an 8-wave shape that lives with two workgroups
@@ -161,16 +162,29 @@ void sept_conv5x5_mfma_kernel(ConvArgs a) {
   if (cs > 0) __syncthreads();  // previous slice's tile and weights are no longer read
   // ---- stage input rows [h_first-2, h_last+2] x cols [-2, W+2) ----
   {
+    // four loads in flight per lane (unconditional: coordinates clamped into the image, the halo zeroed afterwards);
+    // one load at a time, as the plain loop compiled, made this a chain of 4-7 serial HBM round trips per workgroup --
+    // with the tile staged the whole prologue took as long as a third of the 25 taps (round-2 ablation)
     const bf16* xb = a.x + size_t(b) * HW * CINF + c0;
     const int total = NR * W4 * CPP;
-    for (int i = tid; i < total; i += NTHR) {
-      const int c = i % CPP, px = i / CPP;
-      const int col = px % W4, row = px / W4;
-      const int h = h_first - 2 + row, w = col - 2;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (h >= 0 && h < H && w >= 0 && w < W)
-        v = *reinterpret_cast<const uint4*>(xb + (size_t(h) * W + w) * CINF + c * 8);
-      *reinterpret_cast<uint4*>(tile + size_t(row) * RP + col * PS + c * 16) = v;
+    constexpr int SB = (PB * NB >= 4 && CS > 1) ? 2 : 4;   // 64 accumulator registers are live while slice 2 is staged: stay under 128
+    for (int i0 = tid; i0 < total; i0 += NTHR * SB) {
+      uint4 v[SB];
+      int dst[SB];
+#pragma unroll
+      for (int j = 0; j < SB; ++j) {
+        const int i = min(i0 + j * NTHR, total - 1);
+        const int c = i % CPP, px = i / CPP;
+        const int row = px / W4, col = px - row * W4;
+        const int h = h_first - 2 + row, w = col - 2;
+        const bool in = h >= 0 && h < H && w >= 0 && w < W;
+        v[j] = *reinterpret_cast<const uint4*>(xb + (size_t(min(max(h, 0), H - 1)) * W + min(max(w, 0), W - 1)) * CINF + c * 8);
+        if (!in) v[j] = make_uint4(0, 0, 0, 0);
+        dst[j] = row * RP + col * PS + c * 16;
+      }
+#pragma unroll
+      for (int j = 0; j < SB; ++j)
+        if (i0 + j * NTHR < total) *reinterpret_cast<uint4*>(tile + dst[j]) = v[j];
     }
   }
   {
@@ -235,53 +249,41 @@ void sept_conv5x5_mfma_kernel(ConvArgs a) {
   }
   }  // channel slices
 
-  // ---- epilogue: + bias, round to bf16, 8-byte NHWC stores ----
+  // ---- epilogue: + bias, round to bf16, through the LDS (free once the taps are done) so that the tile leaves as
+  // ONE contiguous run of 16-byte stores: in NHWC the MT pixels x COUT channels of a tile are MT * COUT * 2 consecutive
+  // bytes, while the accumulator layout (lane = pixel, 4 channels per register quad) gave 16 scattered 8-byte stores
+  // per lane, each to its own 128-byte line -- 13-17 % of the kernel (round-2 ablation) ----
   bf16* yb = a.y + size_t(b) * HW * COUT;
-  constexpr int SP = COUT * 2 + 8;   // STATS: bytes per pixel row of the LDS copy (padded: conflict-free 8-byte writes)
-  if constexpr (!STATS) {
+  constexpr int SP = COUT * 2 + 16;   // bytes per pixel row of the LDS copy (16-byte aligned rows, conflict-free 8-byte writes)
+  __syncthreads();   // every wave is done with the staged tiles
 #pragma unroll
-    for (int pb = 0; pb < PB; ++pb) {
-      const int q = q0 + (wave * PB + pb) * 32 + (lane & 31);
-      if (q >= HW) continue;
+  for (int pb = 0; pb < PB; ++pb) {
+    const int pl = (wave * PB + pb) * 32 + (lane & 31);
+    const int q = q0 + pl;
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
+    for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int co = (nhalf * NB + nb) * 32 + 8 * g + 4 * (lane >> 5);
-          f32x4 v = {acc[pb][nb][4 * g + 0], acc[pb][nb][4 * g + 1], acc[pb][nb][4 * g + 2],
-                     acc[pb][nb][4 * g + 3]};
-          if (a.bias) {
-            const f32x4 bv = {a.bias[co], a.bias[co + 1], a.bias[co + 2], a.bias[co + 3]};
-            v += bv;
-          }
-          *reinterpret_cast<bf16x4*>(yb + size_t(q) * COUT + co) = __builtin_convertvector(v, bf16x4);
+      for (int g = 0; g < 4; ++g) {
+        const int co = (nhalf * NB + nb) * 32 + 8 * g + 4 * (lane >> 5);
+        f32x4 v = {acc[pb][nb][4 * g + 0], acc[pb][nb][4 * g + 1], acc[pb][nb][4 * g + 2],
+                   acc[pb][nb][4 * g + 3]};
+        if (a.bias) {
+          const f32x4 bv = {a.bias[co], a.bias[co + 1], a.bias[co + 2], a.bias[co + 3]};
+          v += bv;
         }
+        bf16x4 r = __builtin_convertvector(v, bf16x4);
+        if (STATS && q >= HW) r = bf16x4{0, 0, 0, 0};   // pixels past the image add nothing to the column sums
+        *reinterpret_cast<bf16x4*>(smem + size_t(pl) * SP + co * 2) = r;
       }
     }
-  } else {
-    __syncthreads();   // every wave is done with the staged tiles: the LDS is free for a copy of the output tile
-#pragma unroll
-    for (int pb = 0; pb < PB; ++pb) {
-      const int pl = (wave * PB + pb) * 32 + (lane & 31);
-      const int q = q0 + pl;
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int co = (nhalf * NB + nb) * 32 + 8 * g + 4 * (lane >> 5);
-          f32x4 v = {acc[pb][nb][4 * g + 0], acc[pb][nb][4 * g + 1], acc[pb][nb][4 * g + 2],
-                     acc[pb][nb][4 * g + 3]};
-          if (a.bias) {
-            const f32x4 bv = {a.bias[co], a.bias[co + 1], a.bias[co + 2], a.bias[co + 3]};
-            v += bv;
-          }
-          bf16x4 r = __builtin_convertvector(v, bf16x4);
-          if (q < HW) *reinterpret_cast<bf16x4*>(yb + size_t(q) * COUT + co) = r;
-          if (q >= HW) r = bf16x4{0, 0, 0, 0};   // pixels past the image add nothing
-          *reinterpret_cast<bf16x4*>(smem + size_t(pl) * SP + co * 2) = r;
-        }
-      }
-    }
+  }
+  __syncthreads();
+  {
+    constexpr int CPR = COUT / 8;                       // 16-byte chunks per pixel
+    const int nch = min(MT, HW - q0) * CPR;             // the tile's pixels inside the image
+    uint4* dst = reinterpret_cast<uint4*>(yb + size_t(q0) * COUT);
+    for (int i = tid; i < nch; i += NTHR)
+      dst[i] = *reinterpret_cast<const uint4*>(smem + size_t(i / CPR) * SP + (i % CPR) * 16);
   }
   if constexpr (STATS) {
     constexpr int NGRP = NTHR / COUT;   // pixel groups summed side by side
@@ -408,8 +410,9 @@ const ConvVariant* conv_pick(int W, int cin, int cout, bool want_stats, size_t* 
     if (force_cs && v.cs != force_cs) continue;
     const int mt = 32 * v.pb * v.wp;
     const size_t ps = size_t(cin / v.cs) * 2 + 16;
-    const size_t smem = size_t(conv_nr_max(mt, W)) * conv_row_pitch(W, int(ps)) +
-                        size_t(v.tg <= 0 ? 2 * std::max(1, -v.tg) : v.tg) * cout * ps;
+    const size_t smem = std::max(size_t(conv_nr_max(mt, W)) * conv_row_pitch(W, int(ps)) +
+                                     size_t(v.tg <= 0 ? 2 * std::max(1, -v.tg) : v.tg) * cout * ps,
+                                 conv_epilogue_smem(mt, cout));   // the output tile is copied out through the LDS
     if (smem > 160 * 1024) continue;
     // measured on MI355X (tools/sweep_conv.py): what matters is whether TWO workgroups share a CU
     // (a third adds nothing); then the double-buffered form; then table order (tile shape)
