@@ -365,6 +365,10 @@ const ConvVariant kConvVariants[] = {
     SEPT_CONV_VARIANT(32, 64, 2, 4, 2, 0, 1),   SEPT_CONV_VARIANT(32, 64, 2, 4, 2, 1, 1),   SEPT_CONV_VARIANT(32, 64, 1, 4, 1, 1, 1),
     SEPT_CONV_VARIANT(64, 128, 2, 4, 2, 0, 1),  SEPT_CONV_VARIANT(64, 128, 2, 4, 2, 1, 1),  SEPT_CONV_VARIANT(64, 128, 1, 4, 2, 1, 1),
     SEPT_CONV_VARIANT(64, 128, 1, 4, 1, 1, 1),  SEPT_CONV_VARIANT(64, 128, 2, 4, 2, 0, 2),  SEPT_CONV_VARIANT(64, 128, 2, 4, 2, 1, 2),
+    // 64 -> 32 (data gradient of conv2): one 32-channel output block per wave, so a 256-pixel tile is only 2 MFMAs per
+    // wave, tap and channel slice; 512-pixel tiles (two pixel blocks per wave) with pairs of taps per barrier measured
+    // 109 us where the 256-pixel form takes 131 (same call, round 2)
+    SEPT_CONV_VARIANT(64, 32, 2, 8, 1, -2, 2),  SEPT_CONV_VARIANT(64, 32, 2, 8, 1, 0, 2),
     SEPT_CONV_VARIANT(64, 32, 1, 8, 1, 0, 1),   SEPT_CONV_VARIANT(64, 32, 1, 8, 1, 1, 1),   SEPT_CONV_VARIANT(64, 32, 1, 4, 1, 1, 1),
     SEPT_CONV_VARIANT(64, 32, 1, 8, 1, 0, 2),   SEPT_CONV_VARIANT(64, 32, 1, 8, 1, 1, 2),
     // 64 -> 32 in two channel slices is only 2 MFMAs per wave and tap: pairs of taps per barrier (-2) measured
@@ -394,35 +398,57 @@ extern "C" int sept_conv5x5_prep_weights(const float* w_oihw, int cout, int cin,
 namespace {
 // The kernel for a shape; with want_stats only if its statistics form keeps the same number of workgroups per CU.
 const ConvVariant* conv_pick(int W, int cin, int cout, bool want_stats, size_t* smem_out) {
-  const ConvVariant* best = nullptr;
-  size_t best_smem = 0;
-  int best_score = -1;
   const int force_pb = getenv("SEPT_CONV_PB") ? atoi(getenv("SEPT_CONV_PB")) : 0;  // tuning aids
   const int force_ns = getenv("SEPT_CONV_NS") ? atoi(getenv("SEPT_CONV_NS")) : 0;
   const int force_tg = getenv("SEPT_CONV_TG") ? atoi(getenv("SEPT_CONV_TG")) : 0;
   const int force_cs = getenv("SEPT_CONV_CS") ? atoi(getenv("SEPT_CONV_CS")) : 0;
-  for (const ConvVariant& v : kConvVariants) {
-    if (v.cin != cin || v.cout != cout) continue;
-    if (force_pb && v.pb != force_pb) continue;
-    if (force_ns && v.wp * v.wn != 4 * force_ns) continue;
-    // SEPT_CONV_TG=9 selects the double-buffered one-tap form, 92 / 93 / 95 the double-buffered groups of 2 / 3 / 5 taps
-    if (force_tg && v.tg != (force_tg == 9 ? 0 : (force_tg > 90 ? 90 - force_tg : force_tg))) continue;
-    if (force_cs && v.cs != force_cs) continue;
-    const int mt = 32 * v.pb * v.wp;
-    const size_t ps = size_t(cin / v.cs) * 2 + 16;
-    const size_t smem = std::max(size_t(conv_nr_max(mt, W)) * conv_row_pitch(W, int(ps)) +
-                                     size_t(v.tg <= 0 ? 2 * std::max(1, -v.tg) : v.tg) * cout * ps,
-                                 conv_epilogue_smem(mt, cout));   // the output tile is copied out through the LDS
-    if (smem > 160 * 1024) continue;
-    // measured on MI355X (tools/sweep_conv.py): what matters is whether TWO workgroups share a CU
-    // (a third adds nothing); then the double-buffered form; then table order (tile shape)
-    static const int occ_cap = getenv("SEPT_CONV_OCC") ? atoi(getenv("SEPT_CONV_OCC")) : 2;
-    const int occ = int(std::min<size_t>(occ_cap, (160 * 1024) / smem));
-    const int score = 10 * occ + (v.tg <= 0 ? 1 - v.tg : 0);
-    if (!best || (v.pb == best->pb && v.wp == best->wp && v.wn == best->wn && score > best_score)) {
-      best = &v;
-      best_smem = smem;
-      best_score = score;
+  static const int occ_cap = getenv("SEPT_CONV_OCC") ? atoi(getenv("SEPT_CONV_OCC")) : 2;
+  // Per tile shape (pb, wp, wn) the best-scoring buffering / channel-slice form; then the FIRST shape in table order
+  // whose best form puts two workgroups on a CU (worth up to 2x: round-2 sweeps), else the first shape that fits.
+  // score: measured on MI355X (tools/sweep_conv.py) -- what matters is whether TWO workgroups share a CU (a third adds
+  // nothing); then the double-buffered forms (more taps per barrier first); then table order
+  const ConvVariant* best = nullptr;        // choice so far
+  size_t best_smem = 0;
+  int best_score = -1;
+  const ConvVariant* shape_best = nullptr;  // best form of the shape currently scanned (table entries of a shape need not be adjacent)
+  for (const ConvVariant& lead : kConvVariants) {
+    if (lead.cin != cin || lead.cout != cout) continue;
+    if (best && best_score >= 20) break;
+    // scan every form of lead's shape once (at the shape's first table entry)
+    bool first_of_shape = true;
+    for (const ConvVariant& u : kConvVariants) {
+      if (&u == &lead) break;
+      if (u.cin == cin && u.cout == cout && u.pb == lead.pb && u.wp == lead.wp && u.wn == lead.wn) first_of_shape = false;
+    }
+    if (!first_of_shape) continue;
+    shape_best = nullptr;
+    size_t shape_smem = 0;
+    int shape_score = -1;
+    for (const ConvVariant& v : kConvVariants) {
+      if (v.cin != cin || v.cout != cout || v.pb != lead.pb || v.wp != lead.wp || v.wn != lead.wn) continue;
+      if (force_pb && v.pb != force_pb) continue;
+      if (force_ns && v.wp * v.wn != 4 * force_ns) continue;
+      // SEPT_CONV_TG=9 selects the double-buffered one-tap form, 92 / 93 / 95 the double-buffered groups of 2 / 3 / 5 taps
+      if (force_tg && v.tg != (force_tg == 9 ? 0 : (force_tg > 90 ? 90 - force_tg : force_tg))) continue;
+      if (force_cs && v.cs != force_cs) continue;
+      const int mt = 32 * v.pb * v.wp;
+      const size_t ps = size_t(cin / v.cs) * 2 + 16;
+      const size_t smem = std::max(size_t(conv_nr_max(mt, W)) * conv_row_pitch(W, int(ps)) +
+                                       size_t(v.tg <= 0 ? 2 * std::max(1, -v.tg) : v.tg) * cout * ps,
+                                   conv_epilogue_smem(mt, cout));   // the output tile is copied out through the LDS
+      if (smem > 160 * 1024) continue;
+      const int occ = int(std::min<size_t>(occ_cap, (160 * 1024) / smem));
+      const int score = 10 * occ + (v.tg <= 0 ? 1 - v.tg : 0);
+      if (score > shape_score) {
+        shape_best = &v;
+        shape_smem = smem;
+        shape_score = score;
+      }
+    }
+    if (shape_best && (!best || (best_score < 20 && shape_score >= 20))) {
+      best = shape_best;
+      best_smem = shape_smem;
+      best_score = shape_score;
     }
   }
   if (best && want_stats) {
