@@ -362,6 +362,10 @@ struct ConvVariant {
 // forms by whether two workgroups fit on a CU -- e.g. 64->128 at 50x20: one workgroup (163 us),
 // single buffer -> two (136 us), two channel slices + double buffer -> two (105 us, 875 TFLOP/s).
 const ConvVariant kConvVariants[] = {
+    // 512-pixel tiles, every wave all output channels (WN = 1: two 32-channel blocks per wave, one LDS read per MFMA):
+    // 32 -> 64 91 us where the 256-pixel / two-channel-halves form takes 104-108, 128 -> 64 (four channel slices) 94.5
+    // against 103-105 (same call, round 2); pairs of taps per barrier were slower here (111 us)
+    SEPT_CONV_VARIANT(32, 64, 2, 8, 1, 0, 1),
     SEPT_CONV_VARIANT(32, 64, 2, 4, 2, 0, 1),   SEPT_CONV_VARIANT(32, 64, 2, 4, 2, 1, 1),   SEPT_CONV_VARIANT(32, 64, 1, 4, 1, 1, 1),
     SEPT_CONV_VARIANT(64, 128, 2, 4, 2, 0, 1),  SEPT_CONV_VARIANT(64, 128, 2, 4, 2, 1, 1),  SEPT_CONV_VARIANT(64, 128, 1, 4, 2, 1, 1),
     SEPT_CONV_VARIANT(64, 128, 1, 4, 1, 1, 1),  SEPT_CONV_VARIANT(64, 128, 2, 4, 2, 0, 2),  SEPT_CONV_VARIANT(64, 128, 2, 4, 2, 1, 2),
@@ -376,8 +380,10 @@ const ConvVariant kConvVariants[] = {
     // groups of 2 / 3 / 5 taps, 128-pixel tiles with 3-4 workgroups per CU and four channel slices were all equal
     // or slower (more LDS or more registers cost the second workgroup per CU, which is worth 2x)
     SEPT_CONV_VARIANT(64, 32, 1, 8, 1, -2, 2),  SEPT_CONV_VARIANT(64, 32, 1, 8, 1, -2, 1),
+    SEPT_CONV_VARIANT(128, 64, 2, 8, 1, 0, 4),
     SEPT_CONV_VARIANT(128, 64, 2, 4, 2, 0, 2),  SEPT_CONV_VARIANT(128, 64, 2, 4, 2, 1, 2),  SEPT_CONV_VARIANT(128, 64, 2, 4, 2, 0, 1),
     SEPT_CONV_VARIANT(128, 64, 1, 4, 2, 1, 1),  SEPT_CONV_VARIANT(128, 64, 1, 4, 1, 1, 1),
+
     SEPT_CONV_VARIANT(128, 128, 2, 4, 2, 0, 2), SEPT_CONV_VARIANT(128, 128, 2, 4, 2, 1, 2), SEPT_CONV_VARIANT(128, 128, 1, 4, 2, 1, 1),
     SEPT_CONV_VARIANT(128, 128, 1, 4, 1, 1, 1),
 };
@@ -402,6 +408,7 @@ const ConvVariant* conv_pick(int W, int cin, int cout, bool want_stats, size_t* 
   const int force_ns = getenv("SEPT_CONV_NS") ? atoi(getenv("SEPT_CONV_NS")) : 0;
   const int force_tg = getenv("SEPT_CONV_TG") ? atoi(getenv("SEPT_CONV_TG")) : 0;
   const int force_cs = getenv("SEPT_CONV_CS") ? atoi(getenv("SEPT_CONV_CS")) : 0;
+  const int force_wn = getenv("SEPT_CONV_WN") ? atoi(getenv("SEPT_CONV_WN")) : 0;
   static const int occ_cap = getenv("SEPT_CONV_OCC") ? atoi(getenv("SEPT_CONV_OCC")) : 2;
   // Per tile shape (pb, wp, wn) the best-scoring buffering / channel-slice form; then the FIRST shape in table order
   // whose best form puts two workgroups on a CU (worth up to 2x: round-2 sweeps), else the first shape that fits.
@@ -428,6 +435,7 @@ const ConvVariant* conv_pick(int W, int cin, int cout, bool want_stats, size_t* 
       if (v.cin != cin || v.cout != cout || v.pb != lead.pb || v.wp != lead.wp || v.wn != lead.wn) continue;
       if (force_pb && v.pb != force_pb) continue;
       if (force_ns && v.wp * v.wn != 4 * force_ns) continue;
+      if (force_wn && v.wn != force_wn) continue;
       // SEPT_CONV_TG=9 selects the double-buffered one-tap form, 92 / 93 / 95 the double-buffered groups of 2 / 3 / 5 taps
       if (force_tg && v.tg != (force_tg == 9 ? 0 : (force_tg > 90 ? 90 - force_tg : force_tg))) continue;
       if (force_cs && v.cs != force_cs) continue;
