@@ -16,11 +16,16 @@
 //     transpose through a wave-private LDS scratch between the passes; 64/TPF frames ride
 //     in each wavefront (n_fft 800: 400 = 20 x 20, 20 lanes per frame, 3 frames per wave).
 //     Window and inter-pass twiddles live in VGPRs for the whole tile.
-//   * |X|^2 goes back to the scratch; the filterbank is applied in its sparse form (each
-//     bin feeds <= 2 triangular filters): every lane walks a pre-balanced flat list of
-//     (bin, weight, filter) entries.  Filter sums land in an LDS tile that the whole
-//     workgroup finally converts to dB and stores with coalesced rows in either layout.
-//   * no MFMA: this is butterfly + sparse work, HBM/LDS/VALU bound (DESIGN.md roofline).
+//   * |X|^2 goes back to the scratch (each frame's row on its own banks); the filterbank -- a
+//     matrix product in the reference, matmul(spec, fb) -- runs on the matrix pipe in exact
+//     fp32 (v_mfma_f32_16x16x4_f32: bit-for-bit a k-ordered fmaf chain): the frames of one
+//     workgroup iteration are the 16 rows of the A operand, 16 filters the columns of B, and
+//     only the k range where those 16 filters are non-zero is walked (the band of the
+//     triangular filterbank; any filterbank is accepted, a dense one just walks more steps).
+//     The (filter tile, k range) segments are dealt to the four waves on the host; a filter
+//     tile split between two waves lands in two LDS tiles that the final pass adds in a fixed
+//     order, so results do not depend on scheduling.  The whole workgroup finally converts
+//     to dB and stores with coalesced rows in either layout.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -33,8 +38,9 @@
 namespace {
 
 constexpr int kWaves = 4;      // waves per workgroup
-constexpr int kMelChunk = 4;   // filterbank entries fetched per LDS round trip
-constexpr int kMaxSlots = 16;  // filters per lane (n_mels / TPF, rounded up)
+constexpr int kBatch = 8;      // filterbank steps whose operands are fetched together
+constexpr int kMaxSteps = 64;  // filterbank steps per wave (one header word per lane)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct MelArgs {
   const float* wav;      // [B][L]
@@ -42,10 +48,9 @@ struct MelArgs {
   const float2* window;  // [N] (pairs of window samples)
   const float2* tw;      // [N1][N2]  W_N^(k1*n2)
   const float2* ptw;     // [N/2+1]   e^{-i pi p / N}
-  const int2* melent;    // [n_ent][TPF]  (byte offset of the bin in P, weight)
-  const int* melfilt;    // [n_slots][TPF] filter written by (slot, lane), -1 = none
-  int slot_len[kMaxSlots];  // entries per slot (multiple of kMelChunk)
-  int n_slots, n_ent;
+  const float2* btab;    // [n_steps][64]: B operands of one 8-bin step (two MFMAs) per lane
+  const int* steps;      // [kWaves][kMaxSteps + 2]: per step of the wave (first bin / 8) | flush << 10 | slot << 11 | filter tile << 12;
+                         // then the wave's first step in btab and its number of steps
   int B, L, T, F, layout, tiles_per_clip;
 };
 
@@ -70,12 +75,42 @@ struct MelCfg {
   static constexpr int HOPP = HOP + PAD;
   static constexpr int SPAN = HOP * (TILE - 1) + NFFT;                    // samples
   static constexpr int SPANP = SPAN + PAD * ((SPAN + HOP - 1) / HOP);     // padded floats
+  static constexpr int MT = (FPI + 15) / 16;     // 16-frame row tiles of the filterbank product
   static_assert(N2 % TPF == 0 && N1 % TPF == 0, "TPF must divide both factors");
-  static_assert(SCR >= N && 2 * SCR >= N + 1 + (N + 1) / 32 + 1, "scratch must hold Z and the skewed P");
+  // P of frame g starts 0..63 floats into the frame's scratch (bank 20 g: see p_offset) and is read 8 bins at a time
+  static_assert(SCR >= N && 2 * SCR >= N + 1 + 63 + 8, "scratch must hold Z and the staggered P");
   static_assert(HOP % 4 == 0 && PAD % 2 == 0, "float4 staging / float2 reads");
 };
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~size_t(15); }
+
+// Float offset of frame g's power spectrum inside the scratch: the frame's own slot plus a stagger that puts
+// P[g][0] on bank 20 g mod 64 = 4 (5 g mod 16): the 16 rows x 4 consecutive floats that one half-wave reads for the
+// A operand fall on 64 distinct banks, and the three (TPF 20) frames a wave writes side by side do not collide.
+// -DSEPT_MEL_PROF (tools/mel_prof.hip): cycles per phase, summed over the waves of the launch
+#ifdef SEPT_MEL_PROF
+__device__ unsigned long long g_mel_prof[8];
+#define MEL_T(i)                                              \
+  {                                                           \
+    const long long tn_ = __builtin_amdgcn_s_memtime();       \
+    tp_[i] += tn_ - tl_;                                      \
+    tl_ = tn_;                                                \
+  }
+#else
+#define MEL_T(i)
+#endif
+// -DSEPT_MEL_ABLATE=mask (tools/mel_prof.hip): leave a phase out to time the rest (results are then garbage):
+// 1 span staging, 2 pass 1, 4 pass 2, 8 post-pass, 16 filterbank, 32 dB + store, 64 B-operand loads, 128 filter-tile stores,
+// 256 the two workgroup barriers around the filterbank, 512 A-operand reads
+#ifndef SEPT_MEL_ABLATE
+#define SEPT_MEL_ABLATE 0
+#endif
+
+template <class C>
+__device__ __forceinline__ int p_offset(int g) {
+  const int base = g * 2 * C::SCR;
+  return base + (((20 * g - base) % 64) + 64) % 64;
+}
 
 // AmplitudeToDB: 10 log10(clamp(x, 1e-10)).  The clamp floor is emitted as exactly -100 dB,
 // which is what a correctly rounded log10f(1e-10f) gives (and what torch returns).
@@ -86,19 +121,17 @@ __device__ __forceinline__ float power_to_db(float x) {
 template <int N1, int N2, int TPF, int HOP, int ITERS>
 struct MelSmem {
   using C = MelCfg<N1, N2, TPF, HOP, ITERS>;
-  size_t span, tile, scratch, melent, melfilt, ptw, total;
-  __host__ __device__ MelSmem(int F, int n_ent, int n_slots) {
+  size_t span, tile, tile1, scratch, ptw, total;
+  __host__ __device__ explicit MelSmem(int F) {
     size_t off = 0;
     span = off;
     off = align16(off + sizeof(float) * C::SPANP);
     tile = off;
     off = align16(off + sizeof(float) * size_t(C::TILE) * (F + 1));
+    tile1 = off;
+    off = align16(off + sizeof(float) * size_t(C::TILE) * (F + 1));
     scratch = off;
     off = align16(off + sizeof(float2) * size_t(kWaves) * C::FPW * C::SCR);
-    melent = off;
-    off = align16(off + sizeof(int2) * size_t(n_ent) * TPF);
-    melfilt = off;
-    off = align16(off + sizeof(int) * size_t(n_slots) * TPF);
     ptw = off;
     off = align16(off + sizeof(float2) * C::NP);
     total = off;
@@ -110,22 +143,22 @@ template <int N1, int N2, int TPF, int HOP, int ITERS, bool REG_TABLES>
 __global__ __launch_bounds__(kWaves * 64, REG_TABLES ? 2 : 1) void sept_mel_stft_kernel(MelArgs a) {
   using C = MelCfg<N1, N2, TPF, HOP, ITERS>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const MelSmem<N1, N2, TPF, HOP, ITERS> lay(a.F, a.n_ent, a.n_slots);
+  const MelSmem<N1, N2, TPF, HOP, ITERS> lay(a.F);
   float* sp = reinterpret_cast<float*>(smem + lay.span);
   float* tile = reinterpret_cast<float*>(smem + lay.tile);
+  float* tile1 = reinterpret_cast<float*>(smem + lay.tile1);
   float2* scratch_all = reinterpret_cast<float2*>(smem + lay.scratch);
-  int2* melent = reinterpret_cast<int2*>(smem + lay.melent);
-  int* melfilt = reinterpret_cast<int*>(smem + lay.melfilt);
   float2* ptw = reinterpret_cast<float2*>(smem + lay.ptw);
 
   const int tid = threadIdx.x;
   constexpr int nthr = kWaves * 64;
   const int L = a.L, F = a.F, T = a.T;
 
-  // ---- once per workgroup: small tables to LDS, per-lane tables to registers ----
-  for (int i = tid; i < a.n_ent * TPF; i += nthr) melent[i] = a.melent[i];
-  for (int i = tid; i < a.n_slots * TPF; i += nthr) melfilt[i] = a.melfilt[i];
+  // ---- once per workgroup: small tables to LDS, per-lane tables to registers.  Both filter tiles start at
+  // zero: an element is either rewritten for every frame group or belongs to a filter tile with no segment
+  // in that slot (not split / all-zero filters) and stays zero for good.
   for (int i = tid; i < C::NP; i += nthr) ptw[i] = a.ptw[i];
+  for (int i = tid; i < 2 * C::TILE * (a.F + 1); i += nthr) tile[i] = 0.f;   // tile and tile1 are adjacent
 
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -134,7 +167,19 @@ __global__ __launch_bounds__(kWaves * 64, REG_TABLES ? 2 : 1) void sept_mel_stft
   const bool lane_ok = fiw < C::FPW;
   if (!lane_ok) fiw = C::FPW - 1;  // spare lanes shadow the last frame, never write
   float2* scr = scratch_all + size_t(wave * C::FPW + fiw) * C::SCR;
-  float* P = reinterpret_cast<float*>(scr);
+  float* P = reinterpret_cast<float*>(scratch_all) + p_offset<C>(wave * C::FPW + fiw);
+  // A operand of the filterbank product: lane l reads row (l & 15) of row tile mt, bins k + 2 (l >> 4) + {0, 1}
+  const float* prow[C::MT];
+#pragma unroll
+  for (int mt = 0; mt < C::MT; ++mt)
+    prow[mt] = reinterpret_cast<const float*>(scratch_all) + p_offset<C>(min(mt * 16 + (lane & 15), C::FPI - 1)) +
+               2 * (lane >> 4);
+  // this wave's share of the filterbank: a contiguous run of steps (one header word per lane)
+  const int* stp = a.steps + __builtin_amdgcn_readfirstlane(wave) * (kMaxSteps + 2);
+  const int hdr = stp[lane];
+  const int wn = __builtin_amdgcn_readfirstlane(stp[kMaxSteps + 1]);
+  const float2* bt = a.btab + size_t(__builtin_amdgcn_readfirstlane(stp[kMaxSteps])) * 64 + lane;
+  const int wlast = max(wn, 1) - 1;
 
   float2 win[REG_TABLES ? C::CPT : 1][REG_TABLES ? N1 : 1];
   float2 tw[REG_TABLES ? C::CPT : 1][REG_TABLES ? N1 : 1];
@@ -149,27 +194,26 @@ __global__ __launch_bounds__(kWaves * 64, REG_TABLES ? 2 : 1) void sept_mel_stft
       }
     }
   }
-  // split post-pass: this lane's (p, N-p) pairs (scratch indices are frame independent).
-  // The power spectrum is stored SKEWED, P[k + k/32]: the filterbank gathers below walk bins
-  // at regular strides (neighbouring filters start ~width/2 apart) and a power-of-two stride
-  // would otherwise put most lanes of a frame on two or four LDS banks.
-  int pa[C::PPT], pb[C::PPT], pwa[C::PPT], pwb[C::PPT];
+  // split post-pass: this lane's (p, N-p) pairs (scratch indices are frame independent)
+  int pa[C::PPT], pb[C::PPT], pwb[C::PPT];
 #pragma unroll
   for (int q = 0; q < C::PPT; ++q) {
     const int p = min(j + TPF * q, C::N / 2);
     pa[q] = p;
     pb[q] = p == 0 ? 0 : C::N - p;
-    pwa[q] = p + (p >> 5);
-    pwb[q] = (C::N - p) + ((C::N - p) >> 5);
+    pwb[q] = C::N - p;
   }
 
+#ifdef SEPT_MEL_PROF
+  long long tp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_ = __builtin_amdgcn_s_memtime();
+#endif
   const long n_tiles = long(a.B) * a.tiles_per_clip;
   for (long tile_id = blockIdx.x; tile_id < n_tiles; tile_id += gridDim.x) {
     const int b = tile_id / a.tiles_per_clip;
     const int t0 = int(tile_id % a.tiles_per_clip) * C::TILE;
     __syncthreads();  // previous tile fully stored before its LDS is reused
     // ---- stage the waveform span (reflect-mirrored at the clip edges) ----
-    {
+    if constexpr (!(SEPT_MEL_ABLATE & 1)) {
       const float* w = a.wav + size_t(b) * L;
       const int s0 = t0 * HOP - C::N;  // original-sample index of span[0]
       const bool interior = (s0 >= 0) && (s0 + C::SPAN <= L) && ((s0 & 3) == 0) &&
@@ -192,14 +236,15 @@ __global__ __launch_bounds__(kWaves * 64, REG_TABLES ? 2 : 1) void sept_mel_stft
       }
     }
     __syncthreads();
+    MEL_T(0)
 
 #pragma unroll 1
     for (int it = 0; it < ITERS; ++it) {
       const int fl = it * C::FPI + wave * C::FPW + fiw;  // frame index inside the tile
-      const bool active = lane_ok && (t0 + fl) < T;
       const float2* fr = reinterpret_cast<const float2*>(sp + fl * C::HOPP);
 
       // ---- pass 1: N2 column FFTs of length N1 (lane owns columns j + TPF*u) ----
+      if constexpr (!(SEPT_MEL_ABLATE & 2))
 #pragma unroll
       for (int u = 0; u < C::CPT; ++u) {
         const int c = j + TPF * u;
@@ -229,9 +274,10 @@ __global__ __launch_bounds__(kWaves * 64, REG_TABLES ? 2 : 1) void sept_mel_stft
         }
       }
       sept::wave_lds_sync();
+      MEL_T(1)
 
       // ---- pass 2: N1 row FFTs of length N2 (lane owns rows j + TPF*u); Z in natural order
-      {
+      if constexpr (!(SEPT_MEL_ABLATE & 4)) {
         float xr[C::RPT][N2], xi[C::RPT][N2];
 #pragma unroll
         for (int u = 0; u < C::RPT; ++u) {
@@ -256,9 +302,15 @@ __global__ __launch_bounds__(kWaves * 64, REG_TABLES ? 2 : 1) void sept_mel_stft
         }
       }
       sept::wave_lds_sync();
+      MEL_T(2)
+
+      // B operands of this wave's first filterbank batch: in flight under the post-pass
+      float2 bq0[kBatch], bq1[kBatch];
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) bq0[u] = (SEPT_MEL_ABLATE & 64) ? make_float2(1.f, 1.f) : bt[size_t(min(u, wlast)) * 64];
 
       // ---- split post-pass: pairs (p, N-p) -> |X[p]|^2, |X[N-p]|^2 of the real 2N-FFT ----
-      {
+      if constexpr (!(SEPT_MEL_ABLATE & 8)) {
         float2 za[C::PPT], zb[C::PPT], tq[C::PPT];
 #pragma unroll
         for (int q = 0; q < C::PPT; ++q) {
@@ -282,58 +334,94 @@ __global__ __launch_bounds__(kWaves * 64, REG_TABLES ? 2 : 1) void sept_mel_stft
 #pragma unroll
           for (int q = 0; q < C::PPT; ++q) {
             if (j + TPF * q <= C::N / 2) {  // only the last q can fail (uniform per q for most lanes)
-              P[pwa[q]] = p0[q];
+              P[pa[q]] = p0[q];
               P[pwb[q]] = p1[q];
             }
           }
         }
       }
-      sept::wave_lds_sync();
+      MEL_T(3)
+      if constexpr (!(SEPT_MEL_ABLATE & 256)) __syncthreads();  // the power spectra of every frame of this group are in place
+      MEL_T(4)
 
-      // ---- sparse mel filterbank: slot s of lane j is one filter; slot lengths are uniform
-      // across lanes (filters sorted by length and dealt round-robin, zero-weight padded), so
-      // there is no per-entry control flow: kMelChunk table reads, kMelChunk power reads, FMAs.
-      {
-        float* trow = tile + size_t(fl) * (F + 1);
-        const unsigned char* Pb = reinterpret_cast<const unsigned char*>(P);
-        int e = 0;
-        for (int s = 0; s < a.n_slots; ++s) {
-          float acc = 0.f;
-          const int len = a.slot_len[s];
-          for (int i = 0; i < len; i += kMelChunk, e += kMelChunk) {
-            int2 ent[kMelChunk];
-            float pv[kMelChunk];
+      // ---- filterbank on the fp32 matrix pipe: this wave's steps (8 bins x 16 filters each) in batches; the A
+      // operands of a batch are read before its MFMAs, the next batch's B operands are fetched while they run.
+      if constexpr (!(SEPT_MEL_ABLATE & 16)) {
+        f32x4 acc[C::MT][2];
 #pragma unroll
-            for (int u = 0; u < kMelChunk; ++u) ent[u] = melent[(e + u) * TPF + j];
+        for (int mt = 0; mt < C::MT; ++mt) acc[mt][0] = acc[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto batch = [&](const float2 (&bc)[kBatch], float2 (&bn)[kBatch], int i0) {
+          int h[kBatch];
+          float2 av[C::MT][kBatch];
 #pragma unroll
-            for (int u = 0; u < kMelChunk; ++u) pv[u] = *reinterpret_cast<const float*>(Pb + ent[u].x);
+          for (int u = 0; u < kBatch; ++u) {
+            h[u] = __builtin_amdgcn_readlane(hdr, min(i0 + u, wlast));
 #pragma unroll
-            for (int u = 0; u < kMelChunk; ++u) acc = fmaf(__int_as_float(ent[u].y), pv[u], acc);
+            for (int mt = 0; mt < C::MT; ++mt)
+              av[mt][u] = (SEPT_MEL_ABLATE & 512) ? make_float2(float(h[u]), 1.f)
+                                                  : *reinterpret_cast<const float2*>(prow[mt] + 8 * (h[u] & 0x3ff));
           }
-          const int filt = melfilt[s * TPF + j];
-          if (active && filt >= 0) trow[filt] = acc;
+#pragma unroll
+          for (int u = 0; u < kBatch; ++u)
+            bn[u] = (SEPT_MEL_ABLATE & 64) ? make_float2(1.f, 1.f) : bt[size_t(min(i0 + kBatch + u, wlast)) * 64];
+#pragma unroll
+          for (int u = 0; u < kBatch; ++u) {
+            if (i0 + u < wn) {
+#pragma unroll
+              for (int mt = 0; mt < C::MT; ++mt) {
+                acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][u].x, bc[u].x, acc[mt][0], 0, 0, 0);
+                acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][u].y, bc[u].y, acc[mt][1], 0, 0, 0);
+              }
+              if ((h[u] & 0x400) && !(SEPT_MEL_ABLATE & 128)) {   // last step of this wave's part of the filter tile
+                // D[row 4 (l >> 4) + i][col l & 15]: frame row of the group, filter 16 tile + (l & 15)
+                float* tl = (h[u] & 0x800) ? tile1 : tile;
+                const int n = (h[u] >> 12) * 16 + (lane & 15);
+#pragma unroll
+                for (int mt = 0; mt < C::MT; ++mt) {
+#pragma unroll
+                  for (int i = 0; i < 4; ++i) {
+                    const int r = mt * 16 + 4 * (lane >> 4) + i;
+                    if (r < C::FPI && n < F) tl[size_t(it * C::FPI + r) * (F + 1) + n] = acc[mt][0][i] + acc[mt][1][i];
+                  }
+                  acc[mt][0] = acc[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+              }
+            }
+          }
+        };
+#pragma unroll 1
+        for (int i0 = 0; i0 < wn; i0 += 2 * kBatch) {
+          batch(bq0, bq1, i0);
+          if (i0 + kBatch < wn) batch(bq1, bq0, i0 + kBatch);
         }
       }
-      sept::wave_lds_sync();
+      MEL_T(5)
+      if constexpr (!(SEPT_MEL_ABLATE & 256)) __syncthreads();  // the spectra are consumed before the next group's pass 1 reuses the scratch
+      MEL_T(6)
     }
     __syncthreads();
 
     // ---- dB + coalesced store of the tile ----
-    const int nfr = min(C::TILE, T - t0);
+    const int nfr = (SEPT_MEL_ABLATE & 32) ? 0 : min(C::TILE, T - t0);
     if (a.layout == SEPT_MEL_LAYOUT_BFT) {
       float* o = a.out + size_t(b) * F * T;
       for (int idx = tid; idx < F * C::TILE; idx += nthr) {
         const int m = idx / C::TILE, fl = idx - m * C::TILE;
-        if (fl < nfr) o[size_t(m) * T + t0 + fl] = power_to_db(tile[fl * (F + 1) + m]);
+        if (fl < nfr) o[size_t(m) * T + t0 + fl] = power_to_db(tile[fl * (F + 1) + m] + tile1[fl * (F + 1) + m]);
       }
     } else {
       float* o = a.out + (size_t(b) * T + t0) * F;
       for (int idx = tid; idx < F * nfr; idx += nthr) {
         const int fl = idx / F, m = idx - fl * F;
-        o[idx] = power_to_db(tile[fl * (F + 1) + m]);
+        o[idx] = power_to_db(tile[fl * (F + 1) + m] + tile1[fl * (F + 1) + m]);
       }
     }
+    MEL_T(7)
   }
+#ifdef SEPT_MEL_PROF
+  if (lane == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_mel_prof[i], (unsigned long long)tp_[i]);
+#endif
 }
 
 }  // namespace
@@ -343,14 +431,13 @@ __global__ __launch_bounds__(kWaves * 64, REG_TABLES ? 2 : 1) void sept_mel_stft
 // ---------------------------------------------------------------------------------------
 struct sept_mel_plan {
   int n_fft, hop, n_mels, n_freq, N, N1, N2, TPF, FPW;
-  int tile, n_ent, n_slots;
-  int slot_len[kMaxSlots];
+  int tile, n_steps;
   size_t smem;
   float2* d_window = nullptr;
   float2* d_tw = nullptr;
   float2* d_ptw = nullptr;
-  int2* d_melent = nullptr;
-  int* d_melfilt = nullptr;
+  float2* d_btab = nullptr;
+  int* d_steps = nullptr;
   const void* kernel = nullptr;
   const char* kernel_name = nullptr;
 };
@@ -362,12 +449,12 @@ struct Variant {
   const void* fn;
   const char* name;
   int tile;
-  size_t (*smem)(int F, int n_ent, int n_slots);
+  size_t (*smem)(int F);
 };
 
 template <int N1, int N2, int TPF, int HOP, int ITERS>
-size_t smem_of(int F, int n_ent, int n_slots) {
-  return MelSmem<N1, N2, TPF, HOP, ITERS>(F, n_ent, n_slots).total;
+size_t smem_of(int F) {
+  return MelSmem<N1, N2, TPF, HOP, ITERS>(F).total;
 }
 
 #define SEPT_MEL_VARIANT(nfft, hop, n1, n2, tpf, it, reg)                                              \
@@ -418,57 +505,76 @@ extern "C" int sept_mel_plan_create(int n_fft, int hop, int n_mels, const float*
   p.kernel_name = var->name;
   p.tile = var->tile;
 
-  // ---- sparse filterbank: one contiguous run of bins per filter ----
-  struct Run { int m, lo, len; };
-  std::vector<Run> runs;
-  for (int m = 0; m < n_mels; ++m) {
+  // ---- filterbank as MFMA work: per tile of 16 filters the 8-bin steps that cover its non-zero rows ----
+  struct Tile { int k0, steps; };
+  const int n_tiles = (n_mels + 15) / 16;
+  std::vector<Tile> tiles(n_tiles);
+  int total = 0;
+  for (int t = 0; t < n_tiles; ++t) {
     int lo = -1, hi = -1;
-    for (int k = 0; k < p.n_freq; ++k) {
-      if (fb_host[size_t(k) * n_mels + m] != 0.0f) {
-        if (lo < 0) lo = k;
-        hi = k;
+    for (int k = 0; k < p.n_freq; ++k)
+      for (int m = t * 16; m < std::min(n_mels, t * 16 + 16); ++m)
+        if (fb_host[size_t(k) * n_mels + m] != 0.0f) {
+          if (lo < 0) lo = k;
+          hi = k;
+        }
+    tiles[t].k0 = lo < 0 ? 0 : lo & ~7;
+    tiles[t].steps = lo < 0 ? 0 : (hi - tiles[t].k0) / 8 + 1;   // all-zero filters: no work, the LDS tile stays 0
+    total += tiles[t].steps;
+  }
+  p.n_steps = std::max(total, 1);
+  // B operands: step s of tile t covers bins k0 + 8 s .. + 7; lane l feeds filter 16 t + (l & 15) with the bins
+  // k + 2 (l >> 4) (first MFMA) and k + 2 (l >> 4) + 1 (second) -- the pair one ds_read_b64 of P delivers
+  std::vector<float2> btab(size_t(p.n_steps) * 64, make_float2(0.f, 0.f));
+  std::vector<int> first_step(n_tiles);
+  for (int t = 0, s0 = 0; t < n_tiles; s0 += tiles[t].steps, ++t) {
+    first_step[t] = s0;
+    for (int s = 0; s < tiles[t].steps; ++s)
+      for (int l = 0; l < 64; ++l) {
+        const int m = t * 16 + (l & 15), k = tiles[t].k0 + 8 * s + 2 * (l >> 4);
+        auto w = [&](int kk) { return (m < n_mels && kk < p.n_freq) ? fb_host[size_t(kk) * n_mels + m] : 0.0f; };
+        btab[size_t(s0 + s) * 64 + l] = make_float2(w(k), w(k + 1));
       }
-    }
-    if (lo >= 0)
-      for (int k = lo; k <= hi; ++k)
-        SEPT_REQUIRE(fb_host[size_t(k) * n_mels + m] != 0.0f, SEPT_ERR_UNSUPPORTED,
-                     "sept_mel_plan_create: filter %d is not one contiguous run of bins", m);
-    runs.push_back({m, lo < 0 ? 0 : lo, lo < 0 ? 0 : hi - lo + 1});
   }
-  // filters sorted by length and dealt round-robin: slot s holds ranks [s*TPF, (s+1)*TPF), whose
-  // lengths are nearly equal; every slot is padded to its longest filter (multiple of kMelChunk)
-  std::stable_sort(runs.begin(), runs.end(), [](const Run& x, const Run& y) { return x.len > y.len; });
-  p.n_slots = (n_mels + p.TPF - 1) / p.TPF;
-  SEPT_REQUIRE(p.n_slots <= kMaxSlots, SEPT_ERR_UNSUPPORTED, "sept_mel_plan_create: n_mels=%d needs %d slots (max %d)",
-               n_mels, p.n_slots, kMaxSlots);
-  p.n_ent = 0;
-  for (int s = 0; s < kMaxSlots; ++s) p.slot_len[s] = 0;
-  for (int s = 0; s < p.n_slots; ++s) {
-    int longest = 1;
-    for (int l = 0; l < p.TPF && s * p.TPF + l < n_mels; ++l) longest = std::max(longest, runs[s * p.TPF + l].len);
-    p.slot_len[s] = (longest + kMelChunk - 1) / kMelChunk * kMelChunk;
-    p.n_ent += p.slot_len[s];
-  }
-  std::vector<int2> ent(size_t(p.n_ent) * p.TPF, make_int2(0, 0));
-  std::vector<int> filt(size_t(p.n_slots) * p.TPF, -1);
-  for (int s = 0, e0 = 0; s < p.n_slots; e0 += p.slot_len[s], ++s) {
-    for (int l = 0; l < p.TPF && s * p.TPF + l < n_mels; ++l) {
-      const Run& r = runs[s * p.TPF + l];
-      filt[size_t(s) * p.TPF + l] = r.m;  // empty filters are still written (as 0 -> -100 dB)
-      for (int i = 0; i < r.len; ++i) {
-        const int k = r.lo + i;
-        const float w = fb_host[size_t(k) * n_mels + r.m];
-        int wi;
-        std::memcpy(&wi, &w, 4);
-        ent[size_t(e0 + i) * p.TPF + l] = make_int2(4 * (k + (k >> 5)), wi);  // skewed P index, bytes
+  // deal the steps to the waves in order (each wave gets one contiguous run): a tile is cut between waves at most
+  // once, and its second part then goes to LDS tile 1
+  std::vector<int> steps(size_t(kWaves) * (kMaxSteps + 2), 0);
+  SEPT_REQUIRE(n_tiles <= 256 && p.n_freq / 8 < 1024, SEPT_ERR_UNSUPPORTED, "sept_mel_plan_create: n_mels=%d / n_fft=%d too large",
+               n_mels, n_fft);
+  {
+    const int target = (total + kWaves - 1) / kWaves;
+    int wave = 0, load = 0, flat = 0;
+    steps[kMaxSteps] = 0;
+    for (int t = 0; t < n_tiles; ++t) {
+      int done = 0, parts = 0;
+      while (done < tiles[t].steps) {
+        int take = tiles[t].steps - done;
+        const bool may_cut = parts == 0 && wave < kWaves - 1;
+        if (may_cut && load + take > target && target - load > 0) take = target - load;
+        if (wave < kWaves - 1 && load >= target) {   // this wave is full
+          ++wave;
+          load = 0;
+          steps[size_t(wave) * (kMaxSteps + 2) + kMaxSteps] = flat;
+          continue;
+        }
+        SEPT_REQUIRE(load + take <= kMaxSteps, SEPT_ERR_UNSUPPORTED,
+                     "sept_mel_plan_create: n_mels=%d, n_fft=%d need more than %d filterbank steps per wave", n_mels, n_fft, kMaxSteps);
+        for (int c = 0; c < take; ++c)
+          steps[size_t(wave) * (kMaxSteps + 2) + load + c] =
+              ((tiles[t].k0 / 8) + done + c) | (c + 1 == take ? 0x400 : 0) | (parts << 11) | (t << 12);
+        done += take;
+        load += take;
+        flat += take;
+        steps[size_t(wave) * (kMaxSteps + 2) + kMaxSteps + 1] = load;
+        ++parts;
       }
     }
   }
 
-  p.smem = var->smem(n_mels, p.n_ent, p.n_slots);
+  p.smem = var->smem(n_mels);
   if (p.smem > 80 * 1024) {  // shallower tile: two workgroups per CU beat the smaller halo
     const Variant* alt = var + 1;
-    const size_t s1 = alt->smem(n_mels, p.n_ent, p.n_slots);
+    const size_t s1 = alt->smem(n_mels);
     if (s1 <= 80 * 1024 || p.smem > 160 * 1024) {
       var = alt;
       p.smem = s1;
@@ -502,8 +608,8 @@ extern "C" int sept_mel_plan_create(int n_fft, int hop, int n_mels, const float*
   hipError_t e = up(reinterpret_cast<void**>(&h->d_window), win.data(), sizeof(float2) * win.size());
   if (e == hipSuccess) e = up(reinterpret_cast<void**>(&h->d_tw), tw.data(), sizeof(float2) * tw.size());
   if (e == hipSuccess) e = up(reinterpret_cast<void**>(&h->d_ptw), ptw.data(), sizeof(float2) * ptw.size());
-  if (e == hipSuccess) e = up(reinterpret_cast<void**>(&h->d_melent), ent.data(), sizeof(int2) * ent.size());
-  if (e == hipSuccess) e = up(reinterpret_cast<void**>(&h->d_melfilt), filt.data(), sizeof(int) * filt.size());
+  if (e == hipSuccess) e = up(reinterpret_cast<void**>(&h->d_btab), btab.data(), sizeof(float2) * btab.size());
+  if (e == hipSuccess) e = up(reinterpret_cast<void**>(&h->d_steps), steps.data(), sizeof(int) * steps.size());
   if (e == hipSuccess) e = sept::allow_max_lds(h->kernel);
   if (e != hipSuccess) {
     sept_mel_plan_destroy(h);
@@ -518,8 +624,8 @@ extern "C" int sept_mel_plan_destroy(sept_mel_plan* plan) {
   (void)hipFree(plan->d_window);
   (void)hipFree(plan->d_tw);
   (void)hipFree(plan->d_ptw);
-  (void)hipFree(plan->d_melent);
-  (void)hipFree(plan->d_melfilt);
+  (void)hipFree(plan->d_btab);
+  (void)hipFree(plan->d_steps);
   delete plan;
   return SEPT_OK;
 }
@@ -550,11 +656,8 @@ extern "C" int sept_mel_forward(const sept_mel_plan* plan, const float* wav, int
   a.window = plan->d_window;
   a.tw = plan->d_tw;
   a.ptw = plan->d_ptw;
-  a.melent = plan->d_melent;
-  a.melfilt = plan->d_melfilt;
-  for (int s = 0; s < kMaxSlots; ++s) a.slot_len[s] = plan->slot_len[s];
-  a.n_slots = plan->n_slots;
-  a.n_ent = plan->n_ent;
+  a.btab = plan->d_btab;
+  a.steps = plan->d_steps;
   a.B = B;
   a.L = L;
   a.T = 1 + L / plan->hop;

@@ -468,6 +468,7 @@ CONV_FUSED_STATS = os.environ.get("SEPT_CONV_STATS", "1") != "0"
 NO_WGRAD_FORK = set()
 _WG_STREAMS = {}
 _DEFERRED = {"on": False, "pending": []}
+_BWD_ORDER = int(os.environ.get("SEPT_BWD_ORDER", "0"))
 
 # HIP-graph capture and side streams.  On ROCm 7.2 hipStreamEndCapture aborts the PROCESS (core dump, no error
 # code) when a forked stream is joined into another FORKED stream inside a capture:
@@ -850,10 +851,16 @@ class GrlPairFn(torch.autograd.Function):
             s2.wait_stream(cur)
             _DEFERRED["on"] = WGRAD_STREAM     # the branches' small weight gradients fork; joined HERE, on `cur`
             try:
-                with torch.cuda.stream(s2):    # the gender branch first: its recurrent chain is the critical path
-                    dx2, g2 = trunk_backward(S2, P2, d2, need_wgrad=ctx.need_w[1], need_dx=need_dx)
-                with torch.cuda.stream(s1):
-                    dx1, g1 = trunk_backward(S1, P1, d1, need_wgrad=ctx.need_w[0], need_dx=need_dx)
+                if _BWD_ORDER == 1:
+                    with torch.cuda.stream(s1):
+                        dx1, g1 = trunk_backward(S1, P1, d1, need_wgrad=ctx.need_w[0], need_dx=need_dx)
+                    with torch.cuda.stream(s2):
+                        dx2, g2 = trunk_backward(S2, P2, d2, need_wgrad=ctx.need_w[1], need_dx=need_dx)
+                else:
+                    with torch.cuda.stream(s2):    # the gender branch first: its recurrent chain is the critical path
+                        dx2, g2 = trunk_backward(S2, P2, d2, need_wgrad=ctx.need_w[1], need_dx=need_dx)
+                    with torch.cuda.stream(s1):
+                        dx1, g1 = trunk_backward(S1, P1, d1, need_wgrad=ctx.need_w[0], need_dx=need_dx)
             finally:
                 _DEFERRED["on"] = prev
             cur.wait_stream(s1)
