@@ -319,6 +319,10 @@ int sept_scale(const float* x, float a, float* y, long n, void* stream);
 int sept_fill(float* y, float value, long n, void* stream);
 /* y = x * m  (GRU inter-layer dropout with a pre-scaled mask) */
 int sept_mul(const float* x, const float* m, float* y, long n, void* stream);
+/* diagnostics: *slot = the device's 100 MHz wall clock when `stream` reaches this launch (also inside a graph replay) */
+int sept_debug_stamp(long long* slot, void* stream);
+/* out = x + y (the two branch losses of the hand-scheduled GRL step: training_cloak_with_grl.py:160) */
+int sept_add(const float* x, const float* y, float* out, long n, void* stream);
 /* y = x * (*scalar_dev): scale by a value that lives on the device (no host read of a loss gradient). */
 int sept_scale_dev(const float* x, const float* scalar_dev, float* y, long n, void* stream);
 /* y = relu(x) * dropscale (nullable)  -- dense_relu1 + dropout, baseline_models.py:248-249 */

@@ -14,10 +14,14 @@
 // grid = (G workgroups, 1, Z): z selects a slice of MBZ*32 output channels and NBZ*32 input
 // channels.  A workgroup walks many 128-pixel tiles; per tile the input rows (+halo) and the dY
 // rows are staged ONCE in LDS (double-buffered, next tile prefetched into registers under the
-// MFMAs) and reused by all 25 taps: wave w owns taps {w, w+4, ...} for every pixel of the tile,
-// so its 7*MBZ*NBZ accumulator blocks persist in registers across ALL tiles and no cross-wave
-// reduction is needed.  The only cross-workgroup traffic is one partial slab per workgroup,
-// summed in fixed order by a finalize kernel (deterministic, no float atomics).
+// MFMAs) and reused by all 25 taps: wave w of the eight owns taps {w, w+8, w+16} for every pixel of
+// the tile, and the 25th tap is shared -- wave w takes it for the w-th 16-pixel step of every tile --
+// so all waves do the same work between two barriers; the 4*MBZ*NBZ accumulator blocks persist in
+// registers across ALL tiles and no cross-wave reduction is needed inside the kernel.  The fragment
+// reads run two MFMAs ahead of their use (register double buffer over the fully unrolled 16-pixel
+// steps).  The eight partial sums of tap 24 meet in LDS at the very end.  The only cross-workgroup
+// traffic is one partial slab per workgroup, summed in fixed order by a finalize kernel
+// (deterministic, no float atomics).
 #include <algorithm>
 
 #include "sept_common.h"
@@ -47,16 +51,16 @@ struct WgArgs {
   int B, H, W, nr_max;
 };
 
-__device__ __forceinline__ bf16x4 lds_tr(const unsigned char* p) {
-  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-      (__attribute__((address_space(3))) bf16x4*)(reinterpret_cast<uintptr_t>(p)));
+__device__ __forceinline__ bf16x4 lds_tr(unsigned addr) {   // addr: byte address inside the LDS
+  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(uintptr_t(addr)));
 }
 
-// NW waves per workgroup share a tile; the 25 taps are dealt round-robin to the waves.  NW = 8 puts
-// two waves on every SIMD (128 accumulator registers each instead of 224), so one wave's LDS / barrier
-// waits hide under the other's MFMAs.
-template <int CIN, int COUT, int MBZ, int NBZ, int NW>
-__global__ __launch_bounds__(64 * NW) void sept_conv5x5_wgrad_kernel(WgArgs a) {
+constexpr int kNW = 8;                  // waves per workgroup (two per SIMD)
+constexpr int kOwn = 3;                 // taps a wave owns outright: w, w + 8, w + 16
+
+template <int CIN, int COUT, int MBZ, int NBZ>
+__global__ __launch_bounds__(64 * kNW) void sept_conv5x5_wgrad_kernel(WgArgs a) {
+  constexpr int NW = kNW;
   constexpr int NTHR = 64 * NW;
   constexpr int MSL = COUT / 32 / MBZ;  // output-channel slices
   constexpr int CX = NBZ * 32, CY = MBZ * 32;
@@ -64,34 +68,37 @@ __global__ __launch_bounds__(64 * NW) void sept_conv5x5_wgrad_kernel(WgArgs a) {
   constexpr int CPP = CX / 8, CPY = CY / 8;
   constexpr int YCH = (kMT * CPY + NTHR - 1) / NTHR;
   constexpr int XCH = (kXCH * 256 + NTHR - 1) / NTHR;  // 16-byte input chunks a lane prefetches per tile
-  constexpr int NT = (25 + NW - 1) / NW;  // taps per wave (wave 0 owns the odd one)
+  constexpr int KS = kMT / 16;                          // 16-pixel steps per tile
+  static_assert(KS == NW, "wave w takes tap 24 for step w");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int W = a.W, H = a.H, HW = H * W, W4 = W + 4;
-  const size_t xbytes = size_t(a.nr_max) * W4 * PSX;
-  const size_t bufbytes = xbytes + size_t(kMT) * PSY;
+  const unsigned xbytes = unsigned(a.nr_max) * W4 * PSX;
+  const unsigned bufbytes = xbytes + unsigned(kMT) * PSY;
+  const unsigned smem_lds = unsigned(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)smem));
 
   const int z = blockIdx.z;
   const int msl = z % MSL, nsl = z / MSL;
   const int cout0 = msl * CY, cin0 = nsl * CX;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tr_q = (lane & 15) >> 2;
   const int tr_ch = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
   const int k_hi = lane >> 5;
 
-  f32x16 acc[NT][MBZ][NBZ];
+  f32x16 acc[kOwn + 1][MBZ][NBZ];
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+  for (int t = 0; t <= kOwn; ++t)
 #pragma unroll
     for (int mb = 0; mb < MBZ; ++mb)
 #pragma unroll
       for (int nb = 0; nb < NBZ; ++nb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][mb][nb][r] = 0.f;
-  int tapoff[NT];
+  unsigned tapoff[kOwn + 1];   // wave-uniform
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int tap = min(wave + NW * j, 24);
-    tapoff[j] = ((tap / 5) * W4 + (tap % 5)) * PSX;
+  for (int j = 0; j <= kOwn; ++j) {
+    const int tap = j < kOwn ? wave + NW * j : 24;
+    tapoff[j] = unsigned((tap / 5) * W4 + (tap % 5)) * PSX;
   }
 
   const int tiles_per_img = (HW + kMT - 1) / kMT;
@@ -176,6 +183,9 @@ __global__ __launch_bounds__(64 * NW) void sept_conv5x5_wgrad_kernel(WgArgs a) {
     lstore(g_cur, smem);
   }
   __syncthreads();
+  const float inv_w = 1.0f / float(W);
+  const unsigned y_lane = unsigned(8 * k_hi + tr_q) * PSY + tr_ch * 2;   // + (16 ks + 4 half) * PSY
+  const unsigned x_lane = tr_ch * 2;
   int cur = 0;
   for (; n_left > 0; --n_left, cur ^= 1) {
     if (++tt == tiles_per_img) {
@@ -185,53 +195,71 @@ __global__ __launch_bounds__(64 * NW) void sept_conv5x5_wgrad_kernel(WgArgs a) {
     const Geom g_next = tile_geom(tb, tt);
     if (n_left > 1) gload(g_next);  // in flight under the MFMAs below
     const int q0 = g_cur.q0, h_first = g_cur.h_first;
-    const unsigned char* xt = smem + size_t(cur) * bufbytes;
-    const unsigned char* yt = xt + xbytes;
-    // (row, column) of this lane's two pixels per 16-pixel step, advanced by 16 pixels per step with a compare instead
-    // of a division per step
-    int ph[2], pw[2];
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const int q = q0 + 8 * k_hi + tr_q + 4 * half;
-      ph[half] = q / W;
-      pw[half] = q - ph[half] * W;
-    }
+    const unsigned xt = smem_lds + unsigned(cur) * bufbytes;
+    const unsigned yt = xt + xbytes + y_lane;
     const int last_h = (HW - 1) / W - h_first, last_w = (HW - 1) % W;   // pixels past the image read the last one (dy = 0 there)
-#pragma unroll 2
-    for (int ks = 0; ks < kMT / 16; ++ks) {
-      const int kb = ks * 16 + 8 * k_hi + tr_q;
-      const unsigned char* ya[2];
-      const unsigned char* xa[2];
+    // LDS address of this lane's two pixels (tap 0,0) in step ks.  Straight-line code: the row of a pixel comes from
+    // one float multiply (exact: q < 2^24 and the quotient's distance to an integer is >= 0.5 / W), so the step loop
+    // below is ONE basic block per step and the fragment reads can be scheduled across the whole of it.
+    const int q_lane = q0 + 8 * k_hi + tr_q;
+    auto x_step = [&](unsigned (&xo)[2], int ks) {
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
-        const int t = kb + 4 * half;
-        ya[half] = yt + size_t(t) * PSY + tr_ch * 2;
-        const bool inside = ph[half] < H;
-        const int hr = inside ? ph[half] - h_first : last_h, wc = inside ? pw[half] : last_w;
-        xa[half] = xt + size_t(hr * W4 + wc) * PSX + tr_ch * 2;
-        pw[half] += 16;
-        while (pw[half] >= W) {
-          pw[half] -= W;
-          ++ph[half];
-        }
+        const int q = q_lane + 16 * ks + 4 * half;
+        const int qh = int((float(q) + 0.5f) * inv_w);
+        const int qw = q - __mul24(qh, W);
+        const bool inside = qh < H;
+        const int hr = inside ? qh - h_first : last_h, wc = inside ? qw : last_w;
+        xo[half] = xt + x_lane + unsigned(__mul24(hr, W4) + wc) * PSX;
       }
-      bf16x8 afrag[MBZ];
+    };
+    auto read_a = [&](bf16x8 (&fr)[MBZ], int ks) {
 #pragma unroll
       for (int mb = 0; mb < MBZ; ++mb) {
-        const bf16x4 lo = lds_tr(ya[0] + mb * 64), hi = lds_tr(ya[1] + mb * 64);
-        afrag[mb] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        const bf16x4 lo = lds_tr(yt + unsigned(16 * ks) * PSY + mb * 64), hi = lds_tr(yt + unsigned(16 * ks + 4) * PSY + mb * 64);
+        fr[mb] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
       }
+    };
+    auto read_b = [&](bf16x8 (&fr)[NBZ], const unsigned (&xo)[2], unsigned toff) {
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        if (wave + NW * j >= 25) break;  // the odd tap only exists for wave 0 (wave-uniform)
+      for (int nb = 0; nb < NBZ; ++nb) {
+        const bf16x4 lo = lds_tr(xo[0] + toff + nb * 64), hi = lds_tr(xo[1] + toff + nb * 64);
+        fr[nb] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+    };
+    auto mma = [&](f32x16 (&c)[MBZ][NBZ], const bf16x8 (&af)[MBZ], const bf16x8 (&bf)[NBZ]) {
 #pragma unroll
-        for (int nb = 0; nb < NBZ; ++nb) {
-          const bf16x4 lo = lds_tr(xa[0] + tapoff[j] + nb * 64), hi = lds_tr(xa[1] + tapoff[j] + nb * 64);
-          const bf16x8 bfrag = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      for (int nb = 0; nb < NBZ; ++nb)
 #pragma unroll
-          for (int mb = 0; mb < MBZ; ++mb)
-            acc[j][mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[mb], bfrag, acc[j][mb][nb], 0, 0, 0);
+        for (int mb = 0; mb < MBZ; ++mb) c[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb], bf[nb], c[mb][nb], 0, 0, 0);
+    };
+    bf16x8 afr[2][MBZ], bfr[2][NBZ];
+    unsigned xo[2][2];
+    x_step(xo[0], 0);
+    read_a(afr[0], 0);
+    read_b(bfr[0], xo[0], tapoff[0]);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks + 1 < KS) x_step(xo[(ks + 1) & 1], ks + 1);
+#pragma unroll
+      for (int j = 0; j < kOwn; ++j) {
+        const int cb = (kOwn * ks + j) & 1;
+        // the fragments of the NEXT product are requested before this one is issued; the scheduling barriers keep
+        // the compiler from sinking the reads back down to their use (it would, to save registers)
+        if (j + 1 < kOwn) {
+          read_b(bfr[cb ^ 1], xo[ks & 1], tapoff[j + 1]);
+        } else if (ks + 1 < KS) {
+          read_a(afr[(ks + 1) & 1], ks + 1);
+          read_b(bfr[cb ^ 1], xo[(ks + 1) & 1], tapoff[0]);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        mma(acc[j], afr[ks & 1], bfr[cb]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (ks == wave) {   // this wave's share of tap 24 (wave-uniform)
+        bf16x8 b24[NBZ];
+        read_b(b24, xo[ks & 1], tapoff[kOwn]);
+        mma(acc[kOwn], afr[ks & 1], b24);
       }
     }
     if (n_left > 1) lstore(g_next, smem + size_t(cur ^ 1) * bufbytes);
@@ -239,19 +267,33 @@ __global__ __launch_bounds__(64 * NW) void sept_conv5x5_wgrad_kernel(WgArgs a) {
     __syncthreads();
   }
 
-  // ---- one slab per workgroup: [tap 25][MBZ][NBZ][16][64] ----
+  // ---- one slab per workgroup: [tap 25][MBZ][NBZ][16][64].  The eight partial sums of tap 24 are combined in wave
+  // order through LDS (free by now): lane-for-lane, so the block layout is the accumulators' own.
   float* slab = a.ws + (size_t(z) * gridDim.x + blockIdx.x) * (25 * MBZ * NBZ * 1024);
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int tap = wave + NW * j;
-    if (tap >= 25) break;
+  for (int j = 0; j < kOwn; ++j) {
+    const int blk = wave + NW * j;
 #pragma unroll
     for (int mb = 0; mb < MBZ; ++mb)
 #pragma unroll
       for (int nb = 0; nb < NBZ; ++nb)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          slab[(((size_t(tap) * MBZ + mb) * NBZ + nb) * 16 + r) * 64 + lane] = acc[j][mb][nb][r];
+          slab[(((size_t(blk) * MBZ + mb) * NBZ + nb) * 16 + r) * 64 + lane] = acc[j][mb][nb][r];
+  }
+  float* red = reinterpret_cast<float*>(smem);   // [NW][MBZ * NBZ * 16][64]
+#pragma unroll
+  for (int mb = 0; mb < MBZ; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NBZ; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[((wave * MBZ * NBZ + mb * NBZ + nb) * 16 + r) * 64 + lane] = acc[kOwn][mb][nb][r];
+  __syncthreads();
+  for (int i = tid; i < MBZ * NBZ * 1024; i += NTHR) {
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) sum += red[w * MBZ * NBZ * 1024 + i];
+    slab[size_t(24) * MBZ * NBZ * 1024 + i] = sum;
   }
 }
 
@@ -292,22 +334,25 @@ __global__ __launch_bounds__(256) void sept_conv5x5_wgrad_finalize_kernel(const 
 constexpr int kSlabFloats = 25 * 2 * 1024;  // every supported shape has MBZ * NBZ = 2
 constexpr int kTotalWG = 256;               // one 4-wave workgroup per CU (accumulators fill the VGPR file)
 
-template <int CIN, int COUT, int MBZ, int NBZ, int NW>
+template <int CIN, int COUT, int MBZ, int NBZ>
 int launch_wgrad(const WgArgs& a0, float* dw, hipStream_t st) {
   static_assert(MBZ * NBZ == 2, "slab size");
   WgArgs a = a0;
   constexpr int Z = (COUT / 32 / MBZ) * (CIN / 32 / NBZ);
   constexpr int NBLK = 25 * MBZ * NBZ;
+  constexpr int NW = kNW;
   constexpr int PSX = wg_ps(NBZ * 32), PSY = wg_ps(MBZ * 32);
   a.nr_max = wg_nr_max(a.W);
   const size_t smem = 2 * (size_t(a.nr_max) * (a.W + 4) * PSX + size_t(kMT) * PSY);
   SEPT_REQUIRE(smem <= 160 * 1024 && a.nr_max * (a.W + 4) * (NBZ * 4) <= ((kXCH * 256 + 64 * NW - 1) / (64 * NW)) * 64 * NW, SEPT_ERR_UNSUPPORTED,
                "sept_conv5x5_backward_weight: W=%d is too wide for the LDS tile (%zu B)", a.W, smem);
+  SEPT_REQUIRE(smem >= size_t(NW) * MBZ * NBZ * 1024 * sizeof(float), SEPT_ERR_UNSUPPORTED,
+               "sept_conv5x5_backward_weight: W=%d leaves too little LDS for the final tap reduction", a.W);
   const long n_tiles = long(a.B) * ((a.H * a.W + kMT - 1) / kMT);
   const int G = int(std::min<long>(n_tiles, std::max(1, kTotalWG / Z)));
-  const void* fn = reinterpret_cast<const void*>(&sept_conv5x5_wgrad_kernel<CIN, COUT, MBZ, NBZ, NW>);
+  const void* fn = reinterpret_cast<const void*>(&sept_conv5x5_wgrad_kernel<CIN, COUT, MBZ, NBZ>);
   SEPT_HIP(sept::allow_max_lds(fn));
-  hipLaunchKernelGGL((sept_conv5x5_wgrad_kernel<CIN, COUT, MBZ, NBZ, NW>), dim3(G, 1, Z), dim3(64 * NW), smem, st, a);
+  hipLaunchKernelGGL((sept_conv5x5_wgrad_kernel<CIN, COUT, MBZ, NBZ>), dim3(G, 1, Z), dim3(64 * NW), smem, st, a);
   hipLaunchKernelGGL((sept_conv5x5_wgrad_finalize_kernel<CIN, COUT, MBZ, NBZ>), dim3(NBLK * 1024 / 64, Z),
                      dim3(256), 0, st, a.ws, G, dw);
   return sept::launch_check("sept_conv5x5_wgrad_kernel");
@@ -328,16 +373,9 @@ extern "C" int sept_conv5x5_backward_weight(const void* x, const void* dy, float
   SEPT_REQUIRE(B > 0 && H > 0 && W > 0, SEPT_ERR_INVALID, "sept_conv5x5_backward_weight: B=%d H=%d W=%d", B, H, W);
   WgArgs a{static_cast<const bf16*>(x), static_cast<const bf16*>(dy), ws, B, H, W, 0};
   hipStream_t st = static_cast<hipStream_t>(stream);
-  static const int nw = getenv("SEPT_WGRAD_NW") ? atoi(getenv("SEPT_WGRAD_NW")) : 8;   // tuning aid: 4 or 8 waves
-  if (nw == 4) {
-    if (cin == 32 && cout == 64) return launch_wgrad<32, 64, 2, 1, 4>(a, dw, st);
-    if (cin == 64 && cout == 128) return launch_wgrad<64, 128, 1, 2, 4>(a, dw, st);
-    if (cin == 128 && cout == 128) return launch_wgrad<128, 128, 1, 2, 4>(a, dw, st);
-  } else {
-    if (cin == 32 && cout == 64) return launch_wgrad<32, 64, 2, 1, 8>(a, dw, st);
-    if (cin == 64 && cout == 128) return launch_wgrad<64, 128, 1, 2, 8>(a, dw, st);
-    if (cin == 128 && cout == 128) return launch_wgrad<128, 128, 1, 2, 8>(a, dw, st);
-  }
+  if (cin == 32 && cout == 64) return launch_wgrad<32, 64, 2, 1>(a, dw, st);
+  if (cin == 64 && cout == 128) return launch_wgrad<64, 128, 1, 2>(a, dw, st);
+  if (cin == 128 && cout == 128) return launch_wgrad<128, 128, 1, 2>(a, dw, st);
   return sept::fail(SEPT_ERR_UNSUPPORTED,
                     "sept_conv5x5_backward_weight: cin=%d cout=%d (supported: 32->64, 64->128, 128->128)", cin, cout);
 }

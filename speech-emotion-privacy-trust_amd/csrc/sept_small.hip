@@ -55,14 +55,15 @@ __global__ void cloak_scale_mean_kernel(const float* rhos, float smin, float sma
 //            - scale_lambda * dscale/drho / (n * mean(scales))      [d/drho of -lambda*log(mean(scales))]
 // with g = dxa + gscale_b * dxb (dxb optional): the two branches' input gradients, the second
 // one through the gradient-reversal layer (gscale_b = -grl_lambda).
-// One workgroup per 64 elements k; wave j sums the batch items j, j+4, ... (four loads in flight)
-// and the four wave sums are combined in wave order through LDS: deterministic.
-__global__ __launch_bounds__(256) void cloak_bwd_kernel(const float* dxa, const float* dxb, float gscale_b,
-                                                        const float* rhos, const float* eps, const float* mask,
-                                                        float smin, float smax, float scale_lambda,
-                                                        const float* scale_mean, int B, long n_per, float* dlocs,
-                                                        float* drhos) {
-  __shared__ float part[4][64];
+// One workgroup of kCbWaves waves per 64 elements k; wave j sums the batch items j, j + kCbWaves, ... (four loads
+// in flight) and the wave sums are combined in wave order through LDS: deterministic.
+constexpr int kCbWaves = 16;
+__global__ __launch_bounds__(kCbWaves * 64) void cloak_bwd_kernel(const float* dxa, const float* dxb, float gscale_b,
+                                                                  const float* rhos, const float* eps, const float* mask,
+                                                                  float smin, float smax, float scale_lambda,
+                                                                  const float* scale_mean, int B, long n_per, float* dlocs,
+                                                                  float* drhos) {
+  __shared__ float part[kCbWaves][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long k = long(blockIdx.x) * 64 + lane;
   const long kc = min(k, n_per - 1);
@@ -73,16 +74,18 @@ __global__ __launch_bounds__(256) void cloak_bwd_kernel(const float* dxa, const 
   };
   float s0 = 0.f, s1 = 0.f;
   int b = wave;
-  for (; b + 12 < B; b += 16) {
-    const float g0 = item(b), g1 = item(b + 4), g2 = item(b + 8), g3 = item(b + 12);
+  for (; b + 3 * kCbWaves < B; b += 4 * kCbWaves) {
+    const float g0 = item(b), g1 = item(b + kCbWaves), g2 = item(b + 2 * kCbWaves), g3 = item(b + 3 * kCbWaves);
     s0 += g0 + g1;
     s1 += g2 + g3;
   }
-  for (; b < B; b += 4) s0 += item(b);
+  for (; b < B; b += kCbWaves) s0 += item(b);
   part[wave][lane] = s0 + s1;
   __syncthreads();
   if (wave != 0 || k >= n_per) return;
-  const float s = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+  float s = 0.f;
+#pragma unroll
+  for (int w = 0; w < kCbWaves; w += 4) s += (part[w][lane] + part[w + 1][lane]) + (part[w + 2][lane] + part[w + 3][lane]);
   const float th = tanhf(rhos[k]);
   const float dsc = (1.0f - th * th) * 0.5f * (smax - smin);
   const float m = mask ? mask[k] : 1.0f;
@@ -97,6 +100,7 @@ __global__ void scale_kernel(const float* x, float a, float* y, long n) { GRID_S
 __global__ void fill_kernel(float* y, float v, long n) { GRID_STRIDE(i, n) y[i] = v; }
 
 __global__ void mul_kernel(const float* x, const float* m, float* y, long n) { GRID_STRIDE(i, n) y[i] = x[i] * m[i]; }
+__global__ void add_kernel(const float* x, const float* y, float* out, long n) { GRID_STRIDE(i, n) out[i] = x[i] + y[i]; }
 // y = x * (*s): a scale that lives on the device (the upstream gradient of a scalar loss)
 __global__ void scale_dev_kernel(const float* x, const float* s, float* y, long n) {
   const float a = *s;
@@ -831,7 +835,7 @@ extern "C" int sept_cloak_backward(const float* dxa, const float* dxb, float gsc
                                    long n_per, void* stream) {
   SEPT_REQUIRE(dxa && rhos && eps && B > 0 && n_per > 0, SEPT_ERR_INVALID, "sept_cloak_backward: bad argument");
   SEPT_REQUIRE(scale_lambda == 0.f || scale_mean, SEPT_ERR_INVALID, "sept_cloak_backward: scale_mean required");
-  hipLaunchKernelGGL(cloak_bwd_kernel, dim3(int((n_per + 63) / 64)), dim3(256), 0, ST(stream), dxa, dxb, gscale_b,
+  hipLaunchKernelGGL(cloak_bwd_kernel, dim3(int((n_per + 63) / 64)), dim3(kCbWaves * 64), 0, ST(stream), dxa, dxb, gscale_b,
                      rhos, eps, mask, min_scale, max_scale, scale_lambda, scale_mean, B, n_per, dlocs, drhos);
   return sept::launch_check("cloak_bwd_kernel");
 }
@@ -862,6 +866,23 @@ extern "C" int sept_mul(const float* x, const float* m, float* y, long n, void* 
   SEPT_REQUIRE(x && m && y && n > 0, SEPT_ERR_INVALID, "sept_mul: bad argument");
   hipLaunchKernelGGL(mul_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, ST(stream), x, m, y, n);
   return sept::launch_check("mul_kernel");
+}
+
+// wall-clock stamp (100 MHz constant counter) written when the stream reaches this point: schedule diagnostics inside
+// a HIP-graph replay, where events cannot be recorded (tools/step_stamps.py)
+__global__ void stamp_kernel(long long* slot) { *slot = (long long)wall_clock64(); }
+
+extern "C" int sept_debug_stamp(long long* slot, void* stream) {
+  SEPT_REQUIRE(slot, SEPT_ERR_INVALID, "sept_debug_stamp: null slot");
+  hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, ST(stream), slot);
+  return sept::launch_check("stamp_kernel");
+}
+
+extern "C" int sept_add(const float* x, const float* y, float* out, long n, void* stream) {
+  if (n == 0) return SEPT_OK;
+  SEPT_REQUIRE(x && y && out && n > 0, SEPT_ERR_INVALID, "sept_add: bad argument");
+  hipLaunchKernelGGL(add_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, ST(stream), x, y, out, n);
+  return sept::launch_check("add_kernel");
 }
 
 extern "C" int sept_relu_dropout_forward(const float* x, const float* dropscale, float* y, long n, void* stream) {

@@ -71,6 +71,8 @@ SIGNATURES = {
     "sept_scale": (c_int, [c_void_p, c_float, c_void_p, c_long, c_void_p]),
     "sept_fill": (c_int, [c_void_p, c_float, c_long, c_void_p]),
     "sept_mul": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
+    "sept_debug_stamp": (c_int, [c_void_p, c_void_p]),
+    "sept_add": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
     "sept_relu_dropout_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
     "sept_relu_dropout_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
     "sept_mean_t_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -469,6 +469,11 @@ NO_WGRAD_FORK = set()
 _WG_STREAMS = {}
 _DEFERRED = {"on": False, "pending": []}
 _BWD_ORDER = int(os.environ.get("SEPT_BWD_ORDER", "0"))
+# functional.grl_train_step: 1 = each branch runs forward -> loss -> backward as one chain (the emotion branch does not
+# wait for the gender forward); 0 = the branches meet after their forward passes (measured faster: DESIGN.md section 8)
+DECOUPLED_BRANCHES = os.environ.get("SEPT_DECOUPLED", "0") == "1"
+# MFMA-heavy weight gradients of a branch network on the (deferred) side stream too
+BIG_WGRAD_SIDE = os.environ.get("SEPT_WGRAD_BIG_SIDE", "0") == "1"
 
 # HIP-graph capture and side streams.  On ROCm 7.2 hipStreamEndCapture aborts the PROCESS (core dump, no error
 # code) when a forked stream is joined into another FORKED stream inside a capture:
@@ -548,7 +553,7 @@ class _SideQueue:
 
     def big(self, fn, *operands):
         """MFMA-heavy weight gradients: on the side stream of a top-level network only"""
-        return fn() if (self.wg is None or self.nested) else self._run(fn, operands)
+        return fn() if (self.wg is None or (self.nested and not BIG_WGRAD_SIDE)) else self._run(fn, operands)
 
     def finish(self):
         if self.wg is None:
@@ -887,6 +892,165 @@ class GrlPairFn(torch.autograd.Function):
         grads.update(g2)
         gp = tuple(grads.get(p) if p.requires_grad else None for p in ctx.params)
         return (None, dlocs, drhos, None, None, None, None, None, None, None, None) + gp
+
+
+def grl_train_step(model, x, labels_emo, labels_gen, weights, gender_lambda, scale_lamda, use_scale_term=True, mask=None,
+                   pooling="mean", global_feature=None, before_cloak=None):
+    """One forward + loss + backward of two_d_cnn_lstm_syn_with_grl under the loss of train()
+    (training_cloak_with_grl.py:122-160), scheduled by hand instead of through the autograd tape:
+
+        cur:  [x = before_cloak()]   cloak -> xn ........................................ cloak backward(dx1, dx2, -lambda)
+        s1:                 emotion trunk(xn) -> CE -> d logits -> emotion data gradient dx1 ....^
+        s2:   rng, epsilon  gender trunk(xn)  -> CE -> d logits -> gender data + weight gradients dx2 ^
+
+    Each branch runs forward, its cross-entropy and its backward as ONE chain on its own stream: the emotion branch
+    (frozen: no operand preparation, no weight gradients) does not wait for the gender forward before it starts its
+    backward, so the launch-bound recurrent / head sections of one branch overlap the convolutions of the other, and the
+    loss section is one kernel per branch (no root-gradient fill, no upstream-gradient scale).  Same kernels, same
+    gradient slots as the autograd path (GrlPairFn + GrlStepLossFn), which computes exactly this.  `x` is (B, 1, H, W)
+    or None with `before_cloak` a callable that produces it on the current stream (the feature stage: its launches then
+    overlap the step's random-number kernels).  Returns (loss, logits_emotion, logits_gender); the gradients are in
+    .grad of the trainable parameters (views of their flat slots where the trainer packed them)."""
+    noise, emo, gen = model.intermed, model.original_model, model.gender_model
+    att = emo.att
+    pool = "flatten" if pooling is None else "mean"
+    locs, rhos = noise.locs, noise.rhos
+    dev = rhos.device
+    cur = torch.cuda.current_stream(dev)
+    two = CONCURRENT_BRANCHES and fork_allowed(dev)
+    capturing = torch.cuda.is_current_stream_capturing()
+    s1, s2 = branch_streams(dev)
+    with torch.no_grad():
+        ops.stamp("step start", dev)
+        # ---- random numbers of the step on s2 while the caller's feature stage runs on cur
+        def draws():
+            ops.rng(dev, "dropout").begin_step()
+            ops.rng(dev, "eps").begin_step()
+            return noise._epsilon(1)
+        if two and before_cloak is not None:
+            s2.wait_stream(cur)
+            with torch.cuda.stream(s2):
+                eps = draws()
+            x = before_cloak()
+            cur.wait_stream(s2)
+            if not capturing:
+                eps.record_stream(cur)
+        else:
+            eps = draws()
+            if before_cloak is not None:
+                x = before_cloak()
+        shape = x.shape
+        B = shape[0]
+        m = None if mask is None else mask.to(dev, torch.float32).contiguous()
+        smin, smax, lam = float(noise.min_scale), float(noise.max_scale), float(gen.conv[0].lambda_)
+        xn = ops.cloak_forward(x.detach().float().contiguous().view(B, -1), locs.detach(), rhos.detach(), eps, m, smin, smax)
+        xw = xn.view(B, shape[-2], shape[-1])
+        ops.stamp("cloak forward done")
+        need_dx = locs.requires_grad or rhos.requires_grad
+        P1, P2 = trunk_params(emo, 'emotion', att), trunk_params(gen, 'gender', att)
+        need_w2 = any(p.requires_grad for p in _param_list(P2))
+        need_w1 = any(p.requires_grad for p in _param_list(P1))
+        scale_mean = None
+        if use_scale_term and float(scale_lamda) != 0.0:
+            _, scale_mean = ops.cloak_scales(rhos.detach(), smin, smax, want_scales=False, want_mean=True)
+        loss_a = torch.empty((), dtype=torch.float32, device=dev)
+        loss_b = torch.empty((), dtype=torch.float32, device=dev)
+
+        def fwd(P):
+            tag = "emotion" if P is P1 else "gender"
+            ops.stamp(tag + " forward starts")
+            r = trunk_forward(xw, P, pool, need_grad=True, gfeat=global_feature)
+            ops.stamp(tag + " forward done")
+            return r
+
+        def bwd(P, logits, S, labels, coef, loss_slot, need_w, with_scale):
+            tag = "emotion" if P is P1 else "gender"
+            ops.stamp(tag + " backward starts")
+            d = ops.cross_entropy(logits, labels, weights, coef / B, loss_slot)
+            if with_scale and scale_mean is not None:
+                ops.loss_sub_log(loss_slot, scale_mean, float(scale_lamda))
+            r = trunk_backward(S, P, d, need_wgrad=need_w, need_dx=need_dx) if (need_w or need_dx) else (None, {})
+            ops.stamp(tag + " backward done")
+            return r
+
+        # (network, labels, loss coefficient, loss slot, weight gradients?, carries the scale term?) in the order the
+        # module's forward visits them (its dropout draws follow that order); _BWD_ORDER 0 enqueues the gender chain first
+        emo_args = (P1, labels_emo, 1.0, loss_a, need_w1, True)
+        gen_args = (P2, labels_gen, float(gender_lambda), loss_b, need_w2, False)
+        order = ((s1, emo_args), (s2, gen_args)) if _BWD_ORDER == 1 else ((s2, gen_args), (s1, emo_args))
+        res = {}
+        prev = _DEFERRED["on"]
+        if two:
+            def fork():
+                s1.wait_stream(cur)
+                s2.wait_stream(cur)
+
+            def join():
+                cur.wait_stream(s1)
+                cur.wait_stream(s2)
+
+            fork()
+            if not capturing:
+                xn.record_stream(s1)
+                xn.record_stream(s2)
+            _DEFERRED["on"] = WGRAD_STREAM     # the gender branch's small weight gradients fork; joined below, on `cur`
+            try:
+                if DECOUPLED_BRANCHES:         # forward -> loss -> backward as one chain per branch
+                    for st, (P, lab, coef, slot, nw, sc) in order:
+                        with torch.cuda.stream(st):
+                            logits, S = fwd(P)
+                            res[st] = (logits,) + bwd(P, logits, S, lab, coef, slot, nw, sc)
+                else:                          # the branches meet after their forward passes, as on the autograd tape
+                    saved = {}
+                    for st, (P, *_r) in order:
+                        with torch.cuda.stream(st):
+                            saved[st] = fwd(P)
+                    join()
+                    ops.stamp("forward joined")
+                    fork()
+                    for st, (P, lab, coef, slot, nw, sc) in order:
+                        with torch.cuda.stream(st):
+                            logits, S = saved[st]
+                            res[st] = (logits,) + bwd(P, logits, S, lab, coef, slot, nw, sc)
+                    saved.clear()
+            finally:
+                _DEFERRED["on"] = prev
+            join()
+            for wg, _keep in _DEFERRED["pending"]:
+                cur.wait_stream(wg)
+            _DEFERRED["pending"].clear()
+            (l1, dx1, g1), (l2, dx2, g2) = res[s1], res[s2]
+            if not capturing:
+                for t in (l1, l2, dx1, dx2, loss_a, loss_b):
+                    if t is not None:
+                        t.record_stream(cur)
+        else:
+            _DEFERRED["on"] = False
+            try:
+                for st, (P, lab, coef, slot, nw, sc) in order:
+                    logits, S = fwd(P)
+                    res[st] = (logits,) + bwd(P, logits, S, lab, coef, slot, nw, sc)
+            finally:
+                _DEFERRED["on"] = prev
+            (l1, dx1, g1), (l2, dx2, g2) = res[s1], res[s2]
+        if need_dx:
+            dlocs, drhos = ops.cloak_backward(dx1.view(B, -1), dx2.view(B, -1), -lam, rhos.detach(), eps, m, smin, smax,
+                                              scale_lambda=float(scale_lamda) if scale_mean is not None else 0.0,
+                                              scale_mean=scale_mean, need_locs=locs.requires_grad,
+                                              need_rhos=rhos.requires_grad,
+                                              out_locs=grad_out(locs) if locs.requires_grad else None,
+                                              out_rhos=grad_out(rhos) if rhos.requires_grad else None)
+            if locs.requires_grad:
+                locs.grad = dlocs
+            if rhos.requires_grad:
+                rhos.grad = drhos
+        loss = ops.add(loss_a, loss_b)
+        ops.stamp("gradients done")
+        for grads in (g1, g2):
+            for p, g in grads.items():
+                if p.requires_grad:
+                    p.grad = g.view(p.shape)
+    return loss, l1, l2
 
 
 class ScalesFn(torch.autograd.Function):

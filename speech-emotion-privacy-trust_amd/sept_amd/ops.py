@@ -1,5 +1,7 @@
 """Thin tensor-level wrappers over the C ABI (no autograd here; see sept_amd/functional.py).
 Activations are NHWC bf16 on the device; every function raises on CPU tensors."""
+import os
+
 import torch
 
 from ._lib import SeptError, lib, check, current_stream_ptr, require_cuda
@@ -617,6 +619,28 @@ def mul(x, m):
     y = torch.empty_like(x)
     check(lib.sept_mul(x.data_ptr(), m.data_ptr(), y.data_ptr(), x.numel(), _s(x)), "sept_mul")
     return y
+
+
+STAMPS = {"buf": None, "names": []}
+
+
+def stamp(name, device=None):
+    """SEPT_STAMPS=1: record the device wall clock when the current stream reaches this point (a 1-thread kernel; also
+    inside a HIP-graph capture, where every replay overwrites the slots).  tools/step_stamps.py prints them."""
+    if os.environ.get("SEPT_STAMPS", "0") != "1":
+        return
+    if STAMPS["buf"] is None:
+        STAMPS["buf"] = torch.zeros(256, dtype=torch.int64, device=device or "cuda")
+    if name not in STAMPS["names"]:
+        STAMPS["names"].append(name)
+    i = STAMPS["names"].index(name)
+    check(lib.sept_debug_stamp(STAMPS["buf"][i:].data_ptr(), current_stream_ptr(STAMPS["buf"].device)), "sept_debug_stamp")
+
+
+def add(x, y, out=None):
+    out = torch.empty_like(x) if out is None else out
+    check(lib.sept_add(x.data_ptr(), y.data_ptr(), out.data_ptr(), x.numel(), _s(x)), "sept_add")
+    return out
 
 
 def relu_dropout_forward(x, dropscale=None):

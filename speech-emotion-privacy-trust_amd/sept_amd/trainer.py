@@ -7,11 +7,18 @@ over ranks with ONE gradient all-reduce (RCCL) per step when a process group is 
 `FusedPipeline` prepends the feature half: waveforms -> mel (time-major) -> 200-frame windows
 every 50 frames, z-normalised -> the step (BASELINE.json config 5).
 """
+import os
+
 import torch
 
 from . import functional as SF
 from . import ops
 from .mel import LAYOUT_BTF, get_mel_plan
+
+
+# SEPT_HAND_SCHEDULED=0: the GRL step through the autograd tape (module forward, GrlStepLossFn, loss.backward()) instead
+# of functional.grl_train_step -- same kernels and gradient slots, the branches then meet at the loss
+HAND_SCHEDULED = os.environ.get("SEPT_HAND_SCHEDULED", "1") != "0"
 
 
 def _advance_rng(device):
@@ -298,12 +305,33 @@ class GrlTrainer(_TrainerBase):
 
     def _forward_backward(self, features, labels_emo, labels_gen, weights, mask=None, pooling="mean",
                           global_feature=None):
-        _advance_rng(features.device)
+        """`features`: the (B, 1, H, W) batch, or a callable that produces it on the current stream (FusedPipeline)."""
         SF.set_sync_bn(self.sync_bn and self.world > 1, self.pg)
+        if HAND_SCHEDULED and self._hand_schedulable(features):
+            # forward, loss and backward of both branches as two chains on two streams (functional.grl_train_step)
+            fn = features if callable(features) else None
+            loss, preds, preds_grl = SF.grl_train_step(
+                self.model, None if fn else features, labels_emo, labels_gen, weights, self.gender_lambda, self.scale_lamda,
+                use_scale_term=not self.suppression, mask=mask, pooling=pooling, global_feature=global_feature,
+                before_cloak=fn)
+            return loss, preds, preds_grl
+        if callable(features):
+            features = features()
+        _advance_rng(features.device)
         preds, preds_grl, _ = self.model(features, global_feature=global_feature, mask=mask, grl=False, pooling=pooling)
         loss = self.loss(preds, preds_grl, labels_emo, labels_gen, weights, training=True)
         SF.backward(loss)
         return loss.detach(), preds.detach(), preds_grl.detach()
+
+    def _hand_schedulable(self, features):
+        m = self.model
+        if not all(hasattr(m, a) for a in ("intermed", "original_model", "gender_model")):
+            return False
+        if not m.intermed.rhos.is_cuda:
+            return False
+        if callable(features):
+            return True
+        return features.is_cuda and features.dim() == 4 and features.shape[1] == 1 and not features.requires_grad
 
     def train_step(self, features, labels_emo, labels_gen, weights=None, mask=None, pooling="mean",
                    global_feature=None):
@@ -392,9 +420,11 @@ class FusedPipeline:
 
     def train_step(self, wav, labels_emo_w, labels_gen_w, weights_w=None):
         """labels/weights are per WINDOW (clip label repeated for each of its windows)."""
+        return self.trainer.train_step(lambda: self._batch(wav), labels_emo_w, labels_gen_w, weights_w)
+
+    def _batch(self, wav):
         x = self.features(wav)
-        return self.trainer.train_step(x.view(x.shape[0], 1, self.win, self.n_mels), labels_emo_w, labels_gen_w,
-                                       weights_w)
+        return x.view(x.shape[0], 1, self.win, self.n_mels)
 
     def capture(self, wav, labels_emo_w, labels_gen_w, weights_w=None):
         """Record features + forward + loss + backward (+ the optimiser update on a single rank) of ONE step into a
@@ -405,8 +435,6 @@ class FusedPipeline:
         tr = self.trainer
 
         def body():
-            x = self.features(wav)
-            return tr._forward_backward(x.view(x.shape[0], 1, self.win, self.n_mels), labels_emo_w, labels_gen_w,
-                                        weights_w)
+            return tr._forward_backward(lambda: self._batch(wav), labels_emo_w, labels_gen_w, weights_w)
 
         return tr._capture(body)

@@ -907,6 +907,61 @@ def test_captured_step_with_optimizer_and_scheduler_equals_eager(kind):
     assert torch.equal(res[0][0], res[1][0])
 
 
+@pytest.mark.parametrize("scale_lamda, with_dropout", [(0.05, False), (0.0, False), (0.05, True)])
+def test_hand_scheduled_step_equals_the_autograd_step(scale_lamda, with_dropout):
+    """functional.grl_train_step (each branch forward -> CE -> backward as one chain on its own stream, one cloak backward
+    kernel that also carries the scale-loss term) against the same step through the autograd tape (module forward,
+    GrlStepLossFn, loss.backward(): training_cloak_with_grl.py:138-169): identical parameters after three updates, bit for
+    bit -- with dropout active too (both draw from the same Philox sub-streams in the same order)."""
+    from sept_amd import trainer as T
+    from sept_amd import functional as SF
+    F = 80
+    x = closed_form_input(B, W, F).cuda()
+    le, lg, wts = (t.cuda() for t in closed_form_labels(B))
+    res = []
+    for hand in (False, True):
+        prev, T.HAND_SCHEDULED = T.HAND_SCHEDULED, hand
+        prev_order, SF._BWD_ORDER = SF._BWD_ORDER, 1     # emotion first: the module's order of dropout draws
+        try:
+            torch.manual_seed(11)
+            grl = build_grl(F).train()
+            if not with_dropout:
+                zero_dropout(grl)
+            tr = T.GrlTrainer(grl, optimizer="sgd", lr=0.02, gender_lambda=0.1, scale_lamda=scale_lamda, seed=5)
+            outs = [tr.train_step(x, le, lg, wts) for _ in range(3)]
+            torch.cuda.synchronize()
+            res.append((tr.flat.flat.clone(), [float(o[0]) for o in outs], outs[-1][1].clone(), outs[-1][2].clone()))
+        finally:
+            T.HAND_SCHEDULED, SF._BWD_ORDER = prev, prev_order
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][2], res[1][2]) and torch.equal(res[0][3], res[1][3])
+    assert res[0][1] == pytest.approx(res[1][1], rel=1e-6)     # (a + b) - c against (a - c) + b
+
+
+def test_hand_scheduled_step_with_frozen_cloak_parameters():
+    """locs / rhos without requires_grad: no data gradient is needed at all -- the emotion branch stops at its loss."""
+    from sept_amd import trainer as T
+    F = 80
+    x = closed_form_input(B, W, F).cuda()
+    le, lg, wts = (t.cuda() for t in closed_form_labels(B))
+    res = []
+    for hand in (False, True):
+        prev, T.HAND_SCHEDULED = T.HAND_SCHEDULED, hand
+        try:
+            grl = build_grl(F).train()
+            zero_dropout(grl)
+            grl.intermed.locs.requires_grad_(False)
+            grl.intermed.rhos.requires_grad_(False)
+            tr = T.GrlTrainer(grl, optimizer="sgd", lr=0.02, gender_lambda=0.1, scale_lamda=0.0)
+            for _ in range(2):
+                tr.train_step(x, le, lg, wts)
+            torch.cuda.synchronize()
+            res.append(tr.flat.flat.clone())
+        finally:
+            T.HAND_SCHEDULED = prev
+    assert torch.equal(res[0], res[1])
+
+
 def test_recurrent_shapes_outside_the_hip_path_say_what_is_supported():
     """baseline_models.py:191-193 builds any rnn_cell / hidden / layers; the HIP recurrences cover 2 bidirectional
     layers of hidden 64 or 128 -- anything else must fail with a message naming the supported set, never silently."""
