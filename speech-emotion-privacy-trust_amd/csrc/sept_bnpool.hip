@@ -64,9 +64,17 @@ __device__ __forceinline__ void channel_totals(const float* parts, int nparts, i
   __shared__ double red[256];
   const int which = threadIdx.x >> 7, t = threadIdx.x & 127;
   const float* p = parts + (size_t(which) * C + c) * nparts;
-  double acc = 0.0;
-  for (int i = t; i < nparts; i += 128) acc += double(p[i]);
-  red[threadIdx.x] = acc;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;   // four loads in flight: the launch sits on the critical chain
+  int i = t;
+  for (; i + 384 < nparts; i += 512) {
+    const float v0 = p[i], v1 = p[i + 128], v2 = p[i + 256], v3 = p[i + 384];
+    a0 += double(v0);
+    a1 += double(v1);
+    a2 += double(v2);
+    a3 += double(v3);
+  }
+  for (; i < nparts; i += 128) a0 += double(p[i]);
+  red[threadIdx.x] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   for (int k = 64; k > 0; k >>= 1) {
     if (t < k) red[threadIdx.x] += red[threadIdx.x + k];

@@ -440,6 +440,11 @@ struct sept_mel_plan {
   int* d_steps = nullptr;
   const void* kernel = nullptr;
   const char* kernel_name = nullptr;
+  // the one-frame-group tile of the same shape, for launches too small to fill the chip with the deep tile
+  const void* kernel_s = nullptr;
+  const char* kernel_name_s = nullptr;
+  int tile_s = 0;
+  size_t smem_s = 0;
 };
 
 namespace {
@@ -585,6 +590,18 @@ extern "C" int sept_mel_plan_create(int n_fft, int hop, int n_mels, const float*
   }
   SEPT_REQUIRE(p.smem > 0 && p.smem <= 160 * 1024, SEPT_ERR_UNSUPPORTED,
                "sept_mel_plan_create: tile needs %zu bytes of LDS", p.smem);
+  {
+    const Variant* deep = nullptr;
+    for (const Variant& v : kVariants)
+      if (v.n_fft == n_fft && v.hop == hop && !deep) deep = &v;
+    const Variant* shallow = deep + 1;
+    if (var == deep && shallow->smem(n_mels) <= 160 * 1024) {
+      p.kernel_s = shallow->fn;
+      p.kernel_name_s = shallow->name;
+      p.tile_s = shallow->tile;
+      p.smem_s = shallow->smem(n_mels);
+    }
+  }
 
   // ---- device tables ----
   const int N = p.N, N1 = p.N1, N2 = p.N2;
@@ -611,6 +628,7 @@ extern "C" int sept_mel_plan_create(int n_fft, int hop, int n_mels, const float*
   if (e == hipSuccess) e = up(reinterpret_cast<void**>(&h->d_btab), btab.data(), sizeof(float2) * btab.size());
   if (e == hipSuccess) e = up(reinterpret_cast<void**>(&h->d_steps), steps.data(), sizeof(int) * steps.size());
   if (e == hipSuccess) e = sept::allow_max_lds(h->kernel);
+  if (e == hipSuccess && h->kernel_s) e = sept::allow_max_lds(h->kernel_s);
   if (e != hipSuccess) {
     sept_mel_plan_destroy(h);
     return sept::fail(SEPT_ERR_HIP, "sept_mel_plan_create: %s", hipGetErrorString(e));
@@ -663,12 +681,30 @@ extern "C" int sept_mel_forward(const sept_mel_plan* plan, const float* wav, int
   a.T = 1 + L / plan->hop;
   a.F = plan->n_mels;
   a.layout = layout;
-  a.tiles_per_clip = (a.T + plan->tile - 1) / plan->tile;
+  // tile depth: workgroups are persistent, so a launch costs rounds = ceil(tiles / resident workgroups) tile times; a
+  // small batch (the 32-clip training step: 672 deep tiles on 512 workgroups = 2 rounds) is shorter with the half-size
+  // tile (1344 tiles = 3 rounds of half the length, plus its larger staging share)
+  const void* kernel = plan->kernel;
+  size_t smem = plan->smem;
+  int tile = plan->tile;
+  if (plan->kernel_s) {
+    auto rounds = [&](int t, size_t sm) {
+      const long n = long(B) * ((a.T + t - 1) / t);
+      const long res = 256L * (sm <= 80 * 1024 ? 2 : 1);
+      return double((n + res - 1) / res);
+    };
+    if (1.12 * rounds(plan->tile_s, plan->smem_s) * plan->tile_s < rounds(plan->tile, plan->smem) * plan->tile) {
+      kernel = plan->kernel_s;
+      smem = plan->smem_s;
+      tile = plan->tile_s;
+    }
+  }
+  a.tiles_per_clip = (a.T + tile - 1) / tile;
   // persistent workgroups (per-lane window / twiddle tables are loaded once, then many tiles)
   const long n_tiles = long(B) * a.tiles_per_clip;
-  const int wg_per_cu = plan->smem <= 80 * 1024 ? 2 : 1;
+  const int wg_per_cu = smem <= 80 * 1024 ? 2 : 1;
   dim3 grid(unsigned(std::min<long>(n_tiles, 256L * wg_per_cu))), block(kWaves * 64);
   void* args[] = {&a};
-  SEPT_HIP(hipLaunchKernel(plan->kernel, grid, block, args, plan->smem, static_cast<hipStream_t>(stream)));
+  SEPT_HIP(hipLaunchKernel(kernel, grid, block, args, smem, static_cast<hipStream_t>(stream)));
   return SEPT_OK;
 }
