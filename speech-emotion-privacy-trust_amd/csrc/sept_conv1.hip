@@ -826,6 +826,7 @@ __global__ __launch_bounds__(256) void sept_conv1_wgrad_mfma_kernel(const float*
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int tiles_per_img = (HW + kMT - 1) / kMT;
   const long n_tiles = long(B) * tiles_per_img;
+  const float inv_w = 1.0f / float(W);
   // contiguous tile range per workgroup (consecutive tiles share halo rows through this XCD's L2)
   for (long tile_id = n_tiles * blockIdx.x / gridDim.x; tile_id < n_tiles * (blockIdx.x + 1) / gridDim.x; ++tile_id) {
     const int b = tile_id / tiles_per_img, q0 = int(tile_id % tiles_per_img) * kMT;
@@ -840,16 +841,15 @@ __global__ __launch_bounds__(256) void sept_conv1_wgrad_mfma_kernel(const float*
       *reinterpret_cast<uint4*>(yt + size_t(t) * kDyPSt + c * 16) = v;
     }
     __syncthreads();
-    // this lane's 8-pixel group of each 16-pixel step: (row, column) advanced by 16 pixels per step, one division per tile
-    int gh, gw;
-    {
-      const int q = q0 + wave * (kMT / 4) + 8 * k_hi;
-      gh = q / W;
-      gw = q - gh * W;
-    }
-    const int last_q = HW - 8, last_h = last_q / W, last_w = last_q - last_h * W;   // groups past the image read the last one (dy = 0)
+    // All operands of the tile's kMT / 64 steps are requested first, then the MFMAs run: straight-line code (the row
+    // of a pixel group comes from one float multiply, exact for q < 2^24; every lane loads its 8 inputs unconditionally
+    // and the bias / padding columns are selected afterwards) -- per-element branches around the loads and a divergent
+    // row-advance loop made this loop several times longer than its four MFMAs.
+    const int last_q = HW - 8;   // groups past the image read the last one (dy = 0 there)
+    constexpr int NS = kMT / 64;
+    bf16x8 afrag[NS], bfrag[NS];
 #pragma unroll
-    for (int ks = 0; ks < kMT / 64; ++ks) {
+    for (int ks = 0; ks < NS; ++ks) {
       const int kb = wave * (kMT / 4) + ks * 16;  // first pixel of this 16-pixel step
       // A: dy^T fragment (two transposing reads of 4 pixels x 16 channels)
       const int ta = kb + 8 * k_hi + tr_q;
@@ -857,22 +857,21 @@ __global__ __launch_bounds__(256) void sept_conv1_wgrad_mfma_kernel(const float*
           (__attribute__((address_space(3))) bf16x4*)(reinterpret_cast<uintptr_t>(yt + size_t(ta) * kDyPSt + tr_ch * 2)));
       const bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
           (__attribute__((address_space(3))) bf16x4*)(reinterpret_cast<uintptr_t>(yt + size_t(ta + 4) * kDyPSt + tr_ch * 2)));
-      const bf16x8 afrag = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
+      afrag[ks] = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
       // B: 8 consecutive pixels (same image row: W % 8 == 0 and the group start is 8-aligned)
-      const bool inside = gh * W + gw <= last_q;
-      const int h = inside ? gh : last_h, w = inside ? gw : last_w;
-      const float* xp = xt + (h - h_first) * W4 + w + tapoff;
-      gw += 16;
-      while (gw >= W) {
-        gw -= W;
-        ++gh;
-      }
+      const int q = min(q0 + kb + 8 * k_hi, last_q);
+      const int gh = int((float(q) + 0.5f) * inv_w), gw = q - __mul24(gh, W);
+      const float* xp = xt + __mul24(gh - h_first, W4) + gw + tapoff;
       f32x8 xv;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) xv[e] = tap < kTaps ? xp[e] : (tap == kTaps ? 1.0f : 0.0f);
-      const bf16x8 bfrag = __builtin_convertvector(xv, bf16x8);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc, 0, 0, 0);
+      for (int e = 0; e < 8; ++e) xv[e] = xp[e];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xv[e] = tap < kTaps ? xv[e] : (tap == kTaps ? 1.0f : 0.0f);
+      bfrag[ks] = __builtin_convertvector(xv, bf16x8);
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < NS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[ks], bfrag[ks], acc, 0, 0, 0);
   }
   // fixed-order sum of the four waves, one [16][64] slab per workgroup
   float* red = reinterpret_cast<float*>(smem);

@@ -1,10 +1,9 @@
 set -e
 export TMPDIR=/tmp
-O=gpurun_out/r3i
+O=gpurun_out/r3k
 mkdir -p $O
-python -m pytest tests/test_mel_gpu.py tests/test_bn_conv1_gpu.py tests/test_model_gpu.py -m gpu -q --tb=line > $O/gpu_tests.log 2>&1 || true
+python -m pytest tests -m gpu -q --tb=line > $O/gpu_tests.log 2>&1 || true
 grep -E "^/root|^E |Error|passed|failed" $O/gpu_tests.log | cut -c1-300 | head -20
-python tools/bench_mel.py --batch 32 --iters 50
 for i in 1 2; do
 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_$i.json 2> $O/bench_$i.err
 python - <<PY
@@ -12,3 +11,4 @@ import json
 d=json.load(open("$O/bench_$i.json")); print(d["value"], d["ms_per_step"], d["roofline"]["kernel"], d["roofline"]["frac"], d["roofline"]["alone"]["frac"], d["reference_batch"]["ms_per_step"], d["config"]["feature_stage_ms"])
 PY
 done
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')"
