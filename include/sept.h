@@ -292,6 +292,23 @@ int sept_conv1_backward_data_bn(const void* pre, const void* dy_pooled, const fl
                                 double n_total, const float* w, float* wprep, float* dx, void* dpre_out, int B, int H,
                                 int W, void* stream);
 
+/* Block 1's data gradient WITHOUT a pre-activation-sized tensor (baseline_models.py:172-176 + autograd).  BatchNorm's
+ * input gradient is scd_c g (at the window maxima) + c0_c + c1_c v with v = conv1(x) + bias; conv1 has one input
+ * channel, so the data gradient of the dense part is a fixed linear map of x (a 9 x 9 filter away from the border, the
+ * exact tap-by-tap form on the two-pixel ring) and only the sparse part goes through the MFMA data-gradient kernel,
+ * whose loader expands it from the POOLED gradient and the window positions recorded by
+ * sept_bn_relu_pool_forward_argmax (one byte per pooled element; pool * pool = the ReLU cut it).  w_f32 / bias: conv1's
+ * weights (32, 1, 5, 5) and bias; sums / n_total as for sept_conv1_backward_data_bn; coef: SEPT_CONV1_COEF_FLOATS floats
+ * of scratch.  H even, W a multiple of 4 and <= 128. */
+#define SEPT_CONV1_COEF_FLOATS 2800
+int sept_bn_relu_pool_forward_argmax(const void* x, const float* mean, const float* invstd, const float* gamma,
+                                     const float* beta, const float* dropscale, void* y, void* idx_u8, int B, int H, int W,
+                                     int C, int pool, void* stream);
+int sept_conv1_backward_data_sparse(const void* dy_pooled, const void* idx_u8, const float* x, const float* w_f32,
+                                    const float* bias, const float* mean, const float* invstd, const float* gamma,
+                                    const float* dropscale, const float* sums, double n_total, const float* w, float* wprep,
+                                    float* coef, float* dx, int B, int H, int W, void* stream);
+
 /* conv1's weights in operand form: every sept_conv1_* entry point builds it into `wprep` from (w, bias) unless called
  * with w == NULL ("wprep is current"); sept_conv1_prep builds it explicitly so a caller can keep it across calls. */
 int sept_conv1_prep(const float* w, const float* bias, float* wprep, void* stream);

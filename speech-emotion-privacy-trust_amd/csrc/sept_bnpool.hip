@@ -170,6 +170,7 @@ struct BnFwdArgs {
   const float *mean, *invstd, *gamma, *beta, *drop;
   bf16* y;
   int B, H, W, C, pool;
+  unsigned char* idx;   // optional [B][H/P][W/P][C]: window position of the maximum (scan order, first one wins), P*P = ReLU inactive
 };
 
 template <int CPP, int P>
@@ -189,11 +190,21 @@ __global__ __launch_bounds__(256) void sept_bn_relu_pool_fwd_kernel(BnFwdArgs a)
 #pragma unroll
     for (int q = 0; q < P * P; ++q) xv[q] = load8(xp + (long(q / P) * a.W + q % P) * C);
     f32x8 m = {0, 0, 0, 0, 0, 0, 0, 0};  // relu floor
+    int arg[8] = {P * P, P * P, P * P, P * P, P * P, P * P, P * P, P * P};
 #pragma unroll
     for (int q = 0; q < P * P; ++q) {
       const f32x8 v = xv[q] * sc + sh;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], v[e]);
+      for (int e = 0; e < 8; ++e) {
+        arg[e] = v[e] > m[e] ? q : arg[e];   // strictly greater: the first maximum keeps the window (ATen's rule)
+        m[e] = fmaxf(m[e], v[e]);
+      }
+    }
+    if (a.idx) {
+      uint2 pk;
+      pk.x = unsigned(arg[0]) | unsigned(arg[1]) << 8 | unsigned(arg[2]) << 16 | unsigned(arg[3]) << 24;
+      pk.y = unsigned(arg[4]) | unsigned(arg[5]) << 8 | unsigned(arg[6]) << 16 | unsigned(arg[7]) << 24;
+      *reinterpret_cast<uint2*>(a.idx + px * C + chunk * 8) = pk;
     }
     if (a.drop) m *= loadf8(a.drop + long(b) * C + chunk * 8);
     store8(a.y + px * C + chunk * 8, m);
@@ -491,16 +502,14 @@ extern "C" int sept_bn_eval_stats(const float* running_mean, const float* runnin
   return sept::launch_check("sept_bn_eval_stats");
 }
 
-extern "C" int sept_bn_relu_pool_forward(const void* x, const float* mean, const float* invstd,
-                                         const float* gamma, const float* beta, const float* dropscale, void* y,
-                                         int B, int H, int W, int C, int pool, void* stream) {
-  SEPT_REQUIRE(B >= 0 && H > 0 && W > 0 && (pool == 1 || pool == 2), SEPT_ERR_INVALID,
-               "sept_bn_relu_pool_forward: B=%d H=%d W=%d pool=%d", B, H, W, pool);
+namespace {
+int bn_fwd_launch(const char* who, const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                  const float* dropscale, void* y, unsigned char* idx, int B, int H, int W, int C, int pool, void* stream) {
+  SEPT_REQUIRE(B >= 0 && H > 0 && W > 0 && (pool == 1 || pool == 2), SEPT_ERR_INVALID, "%s: B=%d H=%d W=%d pool=%d", who, B, H, W,
+               pool);
   if (B == 0) return SEPT_OK;
-  SEPT_REQUIRE(x && mean && invstd && gamma && beta && y, SEPT_ERR_INVALID,
-               "sept_bn_relu_pool_forward: null argument");
-  BnFwdArgs a{static_cast<const bf16*>(x), mean, invstd, gamma, beta, dropscale, static_cast<bf16*>(y),
-              B, H, W, C, pool};
+  SEPT_REQUIRE(x && mean && invstd && gamma && beta && y, SEPT_ERR_INVALID, "%s: null argument", who);
+  BnFwdArgs a{static_cast<const bf16*>(x), mean, invstd, gamma, beta, dropscale, static_cast<bf16*>(y), B, H, W, C, pool, idx};
   const long items = long(B) * (H / pool) * (W / pool) * (C / 8);
   const int grid = int(std::min<long>((items + 255) / 256, 4096));
   if (pool == 2) {
@@ -511,6 +520,24 @@ extern "C" int sept_bn_relu_pool_forward(const void* x, const float* mean, const
                                             static_cast<hipStream_t>(stream), a));
   }
   return sept::launch_check("sept_bn_relu_pool_fwd_kernel");
+}
+}  // namespace
+
+extern "C" int sept_bn_relu_pool_forward(const void* x, const float* mean, const float* invstd,
+                                         const float* gamma, const float* beta, const float* dropscale, void* y,
+                                         int B, int H, int W, int C, int pool, void* stream) {
+  return bn_fwd_launch("sept_bn_relu_pool_forward", x, mean, invstd, gamma, beta, dropscale, y, nullptr, B, H, W, C, pool, stream);
+}
+
+// the same pass that also records WHERE each window's maximum sits (one byte per pooled element; pool * pool = none:
+// the ReLU cut it): what the backward pass of block 1 needs instead of the pre-activation tensor
+// (sept_conv1_backward_data_sparse)
+extern "C" int sept_bn_relu_pool_forward_argmax(const void* x, const float* mean, const float* invstd, const float* gamma,
+                                                const float* beta, const float* dropscale, void* y, void* idx_u8, int B,
+                                                int H, int W, int C, int pool, void* stream) {
+  SEPT_REQUIRE(idx_u8 || B == 0, SEPT_ERR_INVALID, "sept_bn_relu_pool_forward_argmax: null index buffer");
+  return bn_fwd_launch("sept_bn_relu_pool_forward_argmax", x, mean, invstd, gamma, beta, dropscale, y,
+                       static_cast<unsigned char*>(idx_u8), B, H, W, C, pool, stream);
 }
 
 namespace {

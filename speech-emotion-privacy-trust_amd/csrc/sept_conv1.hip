@@ -620,13 +620,18 @@ struct C1BnArgs {
   float* dx;          // [B][H][W]
   bf16* dpre_out;     // [B][H][W][32] or null
   int B, H, W, rows_per_chunk;
+  const unsigned char* idx;   // SPARSE form: [B][H/2][W/2][32] window position of the maximum (4 = none), `pre` unused
 };
 
 __device__ __forceinline__ unsigned lane_xor4(unsigned v) {   // value of lane ^ 4 (ds_swizzle bit mode: and 0x1F, xor 4)
   return unsigned(__builtin_amdgcn_ds_swizzle(int(v), 0x101F));
 }
 
-__global__ __launch_bounds__(256, 3) void sept_conv1_dgrad_bnapply_kernel(C1BnArgs a) {
+// SPARSE: only the part of dpre that sits at the arg-max positions, scd * g_pooled, is formed -- from the pooled gradient
+// and the recorded positions, without reading `pre`; the dense rest (c0 + c1 * v, v = conv1(x) + bias) is linear in the
+// one-channel input and is added by sept_conv1_dense_dgrad_kernel.
+template <bool SPARSE>
+__global__ __launch_bounds__(256, SPARSE ? 4 : 3) void sept_conv1_dgrad_bnapply_kernel(C1BnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int H = a.H, W = a.W, W4 = W + 4;
   const int NP = (W4 + 31) / 32 * 32;
@@ -635,9 +640,10 @@ __global__ __launch_bounds__(256, 3) void sept_conv1_dgrad_bnapply_kernel(C1BnAr
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y;
   const int r0 = blockIdx.x * a.rows_per_chunk, r1 = min(H, r0 + a.rows_per_chunk);   // both even
-  const bf16* preb = a.pre + size_t(b) * H * W * kC;
+  const bf16* preb = SPARSE ? nullptr : a.pre + size_t(b) * H * W * kC;
   const bf16* dypb = a.dyp + size_t(b) * (H / 2) * (W / 2) * kC;
-  bf16* outb = a.dpre_out ? a.dpre_out + size_t(b) * H * W * kC : nullptr;
+  const unsigned char* idxb = SPARSE ? a.idx + size_t(b) * (H / 2) * (W / 2) * kC : nullptr;
+  bf16* outb = (!SPARSE && a.dpre_out) ? a.dpre_out + size_t(b) * H * W * kC : nullptr;
 
   for (int i = tid; i < 2 * NP * (kDyPS / 16); i += 256) reinterpret_cast<uint4*>(dyrow)[i] = make_uint4(0, 0, 0, 0);
   const int tap = lane & 31;
@@ -663,30 +669,59 @@ __global__ __launch_bounds__(256, 3) void sept_conv1_dgrad_bnapply_kernel(C1BnAr
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int ch = 8 * cg + e;
-    const float is = a.invstd[ch], mu = a.mean[ch];
+    const float is = a.invstd[ch];
     sc[e] = a.gamma[ch] * is;
-    sh[e] = __builtin_fmaf(-mu, sc[e], a.beta[ch]);
     scd[e] = sc[e] * (a.drop ? a.drop[size_t(b) * kC + ch] : 1.0f);
-    c1[e] = -sc[e] * (a.sums[kC + ch] * a.inv_n) * is;
-    c0[e] = -sc[e] * (a.sums[ch] * a.inv_n) - c1[e] * mu;
+    if constexpr (!SPARSE) {
+      const float mu = a.mean[ch];
+      sh[e] = __builtin_fmaf(-mu, sc[e], a.beta[ch]);
+      c1[e] = -sc[e] * (a.sums[kC + ch] * a.inv_n) * is;
+      c0[e] = -sc[e] * (a.sums[ch] * a.inv_n) - c1[e] * mu;
+    } else {
+      sh[e] = c1[e] = c0[e] = 0.f;
+    }
   }
   // raw data of one window column of a row pair: pre rows y (even) and y + 1, two pixels each; the pooled gradient
   struct Raw {
     uint4 a0, a1, b0, b1, g;
+    uint2 ix;
   };
   const int wcc = min(wc, W / 2 - 1);      // idle threads re-read the last window (never stored)
   auto gload = [&](int y, Raw& r) {        // y even; clamped addresses (rows outside the image are zeroed at use)
     const int yc = min(max(y, 0), H - 2);
-    const bf16* ra = preb + (size_t(yc) * W + 2 * wcc) * kC + cg * 8;
-    r.a0 = *reinterpret_cast<const uint4*>(ra);
-    r.a1 = *reinterpret_cast<const uint4*>(ra + kC);
-    r.b0 = *reinterpret_cast<const uint4*>(ra + size_t(W) * kC);
-    r.b1 = *reinterpret_cast<const uint4*>(ra + size_t(W) * kC + kC);
+    if constexpr (!SPARSE) {
+      const bf16* ra = preb + (size_t(yc) * W + 2 * wcc) * kC + cg * 8;
+      r.a0 = *reinterpret_cast<const uint4*>(ra);
+      r.a1 = *reinterpret_cast<const uint4*>(ra + kC);
+      r.b0 = *reinterpret_cast<const uint4*>(ra + size_t(W) * kC);
+      r.b1 = *reinterpret_cast<const uint4*>(ra + size_t(W) * kC + kC);
+    } else {
+      r.ix = *reinterpret_cast<const uint2*>(idxb + (size_t(yc >> 1) * (W / 2) + wcc) * kC + cg * 8);
+    }
     r.g = *reinterpret_cast<const uint4*>(dypb + (size_t(yc >> 1) * (W / 2) + wcc) * kC + cg * 8);
   };
   // dpre chunks of the window's four pixels: row y (da[0], da[1]) and row y + 1 (db[0], db[1])
   auto apply = [&](int y, const Raw& r, uint4 (&da)[2], uint4 (&db)[2]) {
     const bool inside = y >= 0 && y < H;
+    if constexpr (SPARSE) {
+      const bf16x8 gq = __builtin_bit_cast(bf16x8, r.g);
+      bf16x8 o0, o1, o2, o3;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const unsigned k = ((e < 4 ? r.ix.x : r.ix.y) >> (8 * (e & 3))) & 0xffu;
+        const bf16 g = (bf16)(float(gq[e]) * scd[e]), z0 = (bf16)0.f;
+        o0[e] = k == 0 ? g : z0;
+        o1[e] = k == 1 ? g : z0;
+        o2[e] = k == 2 ? g : z0;
+        o3[e] = k == 3 ? g : z0;
+      }
+      const uint4 z = make_uint4(0, 0, 0, 0);
+      da[0] = inside ? __builtin_bit_cast(uint4, o0) : z;
+      da[1] = inside ? __builtin_bit_cast(uint4, o1) : z;
+      db[0] = inside ? __builtin_bit_cast(uint4, o2) : z;
+      db[1] = inside ? __builtin_bit_cast(uint4, o3) : z;
+      return;
+    }
     const bf16x8 v0 = __builtin_bit_cast(bf16x8, r.a0), v1 = __builtin_bit_cast(bf16x8, r.a1);
     const bf16x8 v2 = __builtin_bit_cast(bf16x8, r.b0), v3 = __builtin_bit_cast(bf16x8, r.b1);
     const bf16x8 gq = __builtin_bit_cast(bf16x8, r.g);
@@ -1357,8 +1392,179 @@ extern "C" int sept_conv1_backward_data_bn(const void* pre, const void* dy_poole
   rows += rows & 1;                                   // pooling windows must not straddle chunks
   chunks = (H + rows - 1) / rows;
   C1BnArgs a{static_cast<const bf16*>(pre), static_cast<const bf16*>(dy_pooled), mean, invstd, gamma, beta, dropscale, sums,
-             float(1.0 / n_total), wprep, dx, static_cast<bf16*>(dpre_out), B, H, W, rows};
-  SEPT_HIP(sept::allow_max_lds(reinterpret_cast<const void*>(&sept_conv1_dgrad_bnapply_kernel)));
-  hipLaunchKernelGGL(sept_conv1_dgrad_bnapply_kernel, dim3(chunks, B), dim3(256), smem_r, st, a);
+             float(1.0 / n_total), wprep, dx, static_cast<bf16*>(dpre_out), B, H, W, rows, nullptr};
+  SEPT_HIP(sept::allow_max_lds(reinterpret_cast<const void*>(&sept_conv1_dgrad_bnapply_kernel<false>)));
+  hipLaunchKernelGGL(sept_conv1_dgrad_bnapply_kernel<false>, dim3(chunks, B), dim3(256), smem_r, st, a);
   return sept::launch_check("sept_conv1_dgrad_bnapply_kernel");
+}
+
+// ---- block 1's data gradient without any pre-activation-sized tensor ------------------------------------------------------
+// BatchNorm's input gradient is dpre[c,q] = scd_c g[c,q] (at the arg-max positions) + c0_c + c1_c v[c,q], v = conv1(x) + bias.
+// conv1 has ONE input channel, so the data gradient of the dense part is a fixed linear map of the input itself:
+//   dx_dense[p] = sum_{t : p - off(t) inside} ( V[t] + sum_s M[t,s] x~[p - off(t) + off(s)] ),
+//   V[t] = sum_c w[c,t] (c0_c + c1_c bias_c),   M[t,s] = sum_c c1_c w[c,t] w[c,s]          (x~ = x, zero outside)
+// = sumV + (K9 * x~)[p] with the 9 x 9 kernel K9[u] = sum_{s - t = u} M[t,s] wherever all 25 taps are inside, minus the
+// terms of the taps that fall outside for the two-pixel border ring.  So the backward pass of block 1 reads the pooled
+// gradient (1/4 of the pixels), one position byte per pooled element and the 4-byte input -- not the 64-byte-per-pixel
+// pre-activation tensor (516 MB of traffic in sept_bn_bwd_apply_kernel<4,2> + 229 MB here at 224 windows).
+// Border handling: a tap t only contributes where its source pixel p - off(t) is inside the image, so the 9 x 9 kernel
+// depends on how close p is to each border -- 5 row classes (row 0, row 1, middle, row H-2, row H-1) x 5 column classes.
+// The coefficient kernel forms all 25 kernels K9[class][u] = sum_{t allowed in class, s = t + u} M[t,s] and constants
+// Vc[class] = sum_{t allowed} V[t]; the dense pass is then ONE 81-tap filter per pixel with the class picked by position.
+constexpr int kCoefStride = 112;  // 9 kernel rows of 12 floats (9 taps + 3 pad: 16-byte rows), then the constant + 3 pad
+constexpr int kCoefConst = 108;
+constexpr int kCoefClasses = 25;
+
+__device__ __forceinline__ bool tap_allowed(int cls, int tq) {   // cls 0..4, tq = tap row (or column) 0..4
+  return cls == 0 ? tq <= 2 : cls == 1 ? tq <= 3 : cls == 2 ? true : cls == 3 ? tq >= 1 : tq >= 2;
+}
+
+__global__ __launch_bounds__(256) void sept_conv1_dense_coef_kernel(const float* w, const float* bias, const float* mean,
+                                                                    const float* invstd, const float* gamma,
+                                                                    const float* sums, float inv_n, float* coef) {
+  __shared__ float c0s[kC], c1s[kC], ws[kC * kTaps], Ms[kTaps * kTaps], Vs[kTaps];
+  const int tid = threadIdx.x;
+  if (tid < kC) {
+    const float is = invstd[tid], sc = gamma[tid] * is;
+    const float c1 = -sc * (sums[kC + tid] * inv_n) * is;
+    c1s[tid] = c1;
+    c0s[tid] = -sc * (sums[tid] * inv_n) - c1 * mean[tid] + c1 * (bias ? bias[tid] : 0.f);   // c0 + c1 * bias
+  }
+  for (int i = tid; i < kC * kTaps; i += 256) ws[i] = w[i];
+  __syncthreads();
+  for (int i = tid; i < kTaps * kTaps; i += 256) {
+    const int t = i / kTaps, s2 = i % kTaps;
+    float m = 0.f;
+    for (int c = 0; c < kC; ++c) m = __builtin_fmaf(c1s[c] * ws[c * kTaps + t], ws[c * kTaps + s2], m);
+    Ms[i] = m;
+  }
+  if (tid < kTaps) {
+    float v = 0.f;
+    for (int c = 0; c < kC; ++c) v = __builtin_fmaf(ws[c * kTaps + tid], c0s[c], v);
+    Vs[tid] = v;
+  }
+  __syncthreads();
+  // one workgroup per border class (each recomputes the small M / V tables above)
+  const int cls = blockIdx.x, rc = cls / 5, cc = cls % 5;
+  if (tid < kCoefStride) {
+    float k = 0.f;
+    const int ur = tid / 12 - 4, uc = tid % 12 - 4;
+    if (tid < kCoefConst && uc <= 4) {   // K9[cls][u], u = off(s) - off(t)
+      for (int tr = 0; tr < 5; ++tr)
+        for (int tc = 0; tc < 5; ++tc) {
+          const int sr = tr + ur, sc2 = tc + uc;
+          if (sr >= 0 && sr < 5 && sc2 >= 0 && sc2 < 5 && tap_allowed(rc, tr) && tap_allowed(cc, tc))
+            k += Ms[(tr * 5 + tc) * kTaps + sr * 5 + sc2];
+        }
+    } else if (tid == kCoefConst) {      // the constant
+      for (int t = 0; t < kTaps; ++t)
+        if (tap_allowed(rc, t / 5) && tap_allowed(cc, t % 5)) k += Vs[t];
+    }
+    coef[cls * kCoefStride + tid] = k;
+  }
+}
+
+// dx[p] += Vc[class(p)] + sum_u K9[class(p)][u] x~[p + u].  A workgroup owns `rows` image rows (input rows + 4 halo
+// rows and the 25 kernels in LDS); a thread four neighbouring pixels of a row: a 12-wide input window and the 9 kernel
+// taps per kernel row serve all four (three + three 16-byte LDS reads per 36 multiply-adds).  The first and last group of
+// a row, whose pixels differ in column class, are done pixel by pixel in a second phase.
+__device__ __forceinline__ int border_class(int v, int n) { return v == 0 ? 0 : v == 1 ? 1 : v == n - 2 ? 3 : v == n - 1 ? 4 : 2; }
+
+__global__ __launch_bounds__(256) void sept_conv1_dense_dgrad_kernel(const float* __restrict__ x, const float* __restrict__ coef,
+                                                                     float* __restrict__ dx, int B, int H, int W, int rows) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* ks = reinterpret_cast<float*>(smem);          // [25][kCoefStride]
+  float* xt = ks + kCoefClasses * kCoefStride;         // [rows + 8][W + 8], zero outside the image
+  const int W8 = W + 8, tid = threadIdx.x;
+  const int b = blockIdx.y, r0 = blockIdx.x * rows;
+  const float* xb = x + size_t(b) * H * W;
+  for (int i = tid; i < kCoefClasses * kCoefStride / 4; i += 256) reinterpret_cast<float4*>(ks)[i] = reinterpret_cast<const float4*>(coef)[i];
+  for (int i = tid; i < (rows + 8) * W8; i += 256) {
+    const int rr = i / W8, cc = i - rr * W8;
+    const int h = r0 - 4 + rr, w0 = cc - 4;
+    xt[i] = (h >= 0 && h < H && w0 >= 0 && w0 < W) ? xb[size_t(h) * W + w0] : 0.f;
+  }
+  __syncthreads();
+  const int groups = W / 4, inner = groups - 2;        // groups 1 .. groups-2 of a row: all four pixels in column class 2
+  for (int i = tid; i < rows * inner; i += 256) {
+    const int rr = i / inner, c0 = (i - rr * inner + 1) * 4;
+    const int h = r0 + rr;
+    if (h >= H) continue;
+    const float* kc = ks + (border_class(h, H) * 5 + 2) * kCoefStride;
+    const float kv = kc[kCoefConst];
+    float acc[4] = {kv, kv, kv, kv};
+#pragma unroll
+    for (int ur = 0; ur < 9; ++ur) {
+      const float4* row = reinterpret_cast<const float4*>(xt + (rr + ur) * W8 + c0);
+      const float4 p0 = row[0], p1 = row[1], p2 = row[2];
+      const float4* krow = reinterpret_cast<const float4*>(kc + ur * 12);
+      const float4 k0 = krow[0], k1 = krow[1], k2 = krow[2];
+      const float v[12] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w};
+      const float k[9] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w, k2.x};
+#pragma unroll
+      for (int uc = 0; uc < 9; ++uc)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_fmaf(k[uc], v[uc + j], acc[j]);
+    }
+    float4* o = reinterpret_cast<float4*>(dx + (size_t(b) * H + h) * W + c0);
+    float4 cur = *o;
+    cur.x += acc[0];
+    cur.y += acc[1];
+    cur.z += acc[2];
+    cur.w += acc[3];
+    *o = cur;
+  }
+  // the two edge groups of every row, one pixel per thread
+  for (int i = tid; i < rows * 8; i += 256) {
+    const int rr = i >> 3, e = i & 7;
+    const int h = r0 + rr, c = e < 4 ? e : W - 8 + e;
+    if (h >= H) continue;
+    const float* kc = ks + (border_class(h, H) * 5 + border_class(c, W)) * kCoefStride;
+    float a0 = kc[kCoefConst], a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int ur = 0; ur < 9; ur += 3)
+#pragma unroll
+      for (int uc = 0; uc < 9; ++uc) {
+        a0 = __builtin_fmaf(kc[ur * 12 + uc], xt[(rr + ur) * W8 + c + uc], a0);
+        a1 = __builtin_fmaf(kc[(ur + 1) * 12 + uc], xt[(rr + ur + 1) * W8 + c + uc], a1);
+        a2 = __builtin_fmaf(kc[(ur + 2) * 12 + uc], xt[(rr + ur + 2) * W8 + c + uc], a2);
+      }
+    dx[(size_t(b) * H + h) * W + c] += a0 + (a1 + a2);
+  }
+}
+
+// coef: kCoefFloats floats of workspace (overwritten).  sums / n_total as for sept_conv1_backward_data_bn; idx_u8 from
+// sept_bn_relu_pool_forward_argmax.  H, W even, W a multiple of 4 and <= 128.
+extern "C" int sept_conv1_backward_data_sparse(const void* dy_pooled, const void* idx_u8, const float* x, const float* w_f32,
+                                               const float* bias, const float* mean, const float* invstd, const float* gamma,
+                                               const float* dropscale, const float* sums, double n_total, const float* w,
+                                               float* wprep, float* coef, float* dx, int B, int H, int W, void* stream) {
+  if (int e = conv1_check("sept_conv1_backward_data_sparse", B, H, W)) return e;
+  if (B == 0) return SEPT_OK;
+  SEPT_REQUIRE(dy_pooled && idx_u8 && x && w_f32 && mean && invstd && gamma && sums && wprep && coef && dx && n_total > 0,
+               SEPT_ERR_INVALID, "sept_conv1_backward_data_sparse: null argument");
+  SEPT_REQUIRE(H % 2 == 0 && W % 4 == 0 && W * 4 <= 512 && H >= 4 && W >= 8, SEPT_ERR_UNSUPPORTED,
+               "sept_conv1_backward_data_sparse: H=%d W=%d (needs even H >= 4, W a multiple of 4 in 8 .. 128)", H, W);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (w)
+    hipLaunchKernelGGL(sept_conv1_prep_kernel, dim3((kTaps * kC + 255) / 256), dim3(256), 0, st, w,
+                       static_cast<const float*>(nullptr), wprep);
+  hipLaunchKernelGGL(sept_conv1_dense_coef_kernel, dim3(kCoefClasses), dim3(256), 0, st, w_f32, bias, mean, invstd, gamma, sums,
+                     float(1.0 / n_total), coef);
+  const int NP = (W + 4 + 31) / 32 * 32;
+  const size_t smem_r = size_t(2) * NP * kDyPS + size_t(2) * NP * kZS * sizeof(float);
+  const int per_cu = int(std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / smem_r)));
+  int chunks = std::max(1, std::min((H + 15) / 16, 256 * per_cu / std::max(B, 1)));
+  int rows = (H + chunks - 1) / chunks;
+  rows += rows & 1;                                   // pooling windows must not straddle chunks
+  chunks = (H + rows - 1) / rows;
+  C1BnArgs a{nullptr, static_cast<const bf16*>(dy_pooled), mean, invstd, gamma, nullptr, dropscale, sums,
+             float(1.0 / n_total), wprep, dx, nullptr, B, H, W, rows, static_cast<const unsigned char*>(idx_u8)};
+  SEPT_HIP(sept::allow_max_lds(reinterpret_cast<const void*>(&sept_conv1_dgrad_bnapply_kernel<true>)));
+  hipLaunchKernelGGL(sept_conv1_dgrad_bnapply_kernel<true>, dim3(chunks, B), dim3(256), smem_r, st, a);
+  const int drows = std::max(1, 256 / std::max(1, W / 4 - 2));   // image rows per workgroup: one four-pixel group per thread
+  const size_t smem_d = sizeof(float) * (size_t(kCoefClasses) * kCoefStride + size_t(drows + 8) * (W + 8));
+  hipLaunchKernelGGL(sept_conv1_dense_dgrad_kernel, dim3((H + drows - 1) / drows, B), dim3(256), smem_d, st, x, coef, dx, B, H, W,
+                     drows);
+  return sept::launch_check("sept_conv1_backward_data_sparse");
 }

@@ -208,7 +208,7 @@ def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None, gfeat=Non
                 drop = d2[li] if d2 is not None else masks[("c", li)]
             out = ops.conv1_bn_relu_pool_forward(x, cv.weight, cv.bias, mean, invstd, bn.weight, bn.bias, drop, prep=c1p)
             S.blocks.append(SimpleNamespace(inp=None, pre=None, out=out, mean=mean, invstd=invstd, drop=drop, pool=pool, h=h,
-                                            w=w, bn_train=bn.training, sync=False, l1_fused=True))
+                                            w=w, bn_train=bn.training, sync=False, l1_fused=True, idx=None))
             act = out
             h, w = h // pool, w // pool
             continue
@@ -244,9 +244,15 @@ def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None, gfeat=Non
         if train and (P.drop_ps[li] > 0 or "drop2d" in inj):
             d2 = inj.get("drop2d")
             drop = d2[li] if d2 is not None else masks[("c", li)]
-        out = ops.bn_relu_pool_forward(pre, mean, invstd, bn.weight, bn.bias, drop, pool)
+        idx = None
+        if (li == 0 and need_grad and L1_SPARSE and bn.training and pool == 2 and not _SYNC_BN["on"] and h % 2 == 0
+                and h >= 4 and w % 8 == 0 and w <= 128 and not cv.weight.requires_grad):
+            # block 1's backward pass will work from the pooled gradient + the window positions (conv1_backward_data_sparse)
+            out, idx = ops.bn_relu_pool_forward(pre, mean, invstd, bn.weight, bn.bias, drop, pool, want_argmax=True)
+        else:
+            out = ops.bn_relu_pool_forward(pre, mean, invstd, bn.weight, bn.bias, drop, pool)
         S.blocks.append(SimpleNamespace(inp=act, pre=pre, out=out, mean=mean, invstd=invstd, drop=drop, pool=pool, h=h, w=w,
-                                        bn_train=bn.training, sync=_SYNC_BN["on"] and bn.training, l1_fused=False))
+                                        bn_train=bn.training, sync=_SYNC_BN["on"] and bn.training, l1_fused=False, idx=idx))
         act = out
         h, w = h // pool, w // pool
     # ---- GRU: (B, T=h, D = w*C) with NHWC feature order (w, c) ----
@@ -463,6 +469,10 @@ BN_SUMS_IN_DGRAD = os.environ.get("SEPT_BN_DGRAD_SUMS", "1") != "0"
 # loader's serial chain (load -> apply -> LDS -> MFMA -> LDS -> gather) and lengthens every step more than the
 # 229 MB it saves; SEPT_BN_APPLY_DGRAD=1 selects it (tests keep it correct).
 BN_APPLY_IN_DGRAD = os.environ.get("SEPT_BN_APPLY_DGRAD", "0") == "1"
+# block 1's backward pass of a network WITHOUT conv1 weight gradient (the frozen emotion model) from the pooled gradient +
+# recorded arg-max positions + the input, no pre-activation-sized tensor (ops.conv1_backward_data_sparse; -1.7 % step
+# time).  SEPT_L1_SPARSE=0: BatchNorm backward apply pass + dense data gradient as for the trainable one
+L1_SPARSE = os.environ.get("SEPT_L1_SPARSE", "1") != "0"
 # BatchNorm statistics of the 5x5 conv layers from the conv kernel's epilogue (SEPT_CONV_STATS=0: a separate pass)
 CONV_FUSED_STATS = os.environ.get("SEPT_CONV_STATS", "1") != "0"
 NO_WGRAD_FORK = set()
@@ -624,6 +634,18 @@ def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq, go
         if not blk.bn_train:
             raise SeptError("backward through an eval-mode BatchNorm is not implemented on the HIP path")
         want_bn = need_wgrad and bn.weight.requires_grad
+        if (li == 0 and getattr(blk, "idx", None) is not None and need_dx and not blk.sync
+                and not (need_wgrad and cv.weight.requires_grad)):
+            # block 1 of a network without conv1 weight gradient (the frozen emotion model): no pre-activation-sized tensor
+            # is read or written -- sparse part on the MFMA data-gradient kernel, dense part as a linear map of the input
+            dx, dgamma, dbeta = ops.conv1_backward_data_sparse(
+                S.x, blk.pre, dact, blk.idx, blk.mean, blk.invstd, bn.weight, bn.bias, blk.drop, cv.weight, cv.bias,
+                presums=presums, need_param_grads=want_bn, out_gamma=gout(bn.weight) if want_bn else None,
+                out_beta=gout(bn.bias) if want_bn else None, prep=_conv1_operand(cv), y=blk.out if BN_POOLED_SUMS else None)
+            if want_bn:
+                put(bn.weight, dgamma)
+                put(bn.bias, dbeta)
+            continue
         if (li == 0 and BN_APPLY_IN_DGRAD and need_dx and not blk.l1_fused and not blk.sync and blk.pool == 2
                 and blk.pre.shape[1] % 2 == 0 and blk.pre.shape[2] % 2 == 0 and blk.pre.shape[2] <= 128):
             # block 1: the BatchNorm backward apply pass lives in conv1's data-gradient row loader -- the 64-byte-per-

@@ -290,10 +290,17 @@ def bn_eval_stats(running_mean, running_var, eps=1e-5):
     return mean, invstd
 
 
-def bn_relu_pool_forward(x, mean, invstd, gamma, beta, dropscale=None, pool=2):
+def bn_relu_pool_forward(x, mean, invstd, gamma, beta, dropscale=None, pool=2, want_argmax=False):
+    """-> pooled bf16 output; with want_argmax also the uint8 window position of every maximum (pool * pool = none)."""
     require_cuda(x, mean, invstd, gamma, beta)
     B, H, W, C = x.shape
     y = torch.empty((B, H // pool, W // pool, C), dtype=torch.bfloat16, device=x.device)
+    if want_argmax:
+        idx = torch.empty((B, H // pool, W // pool, C), dtype=torch.uint8, device=x.device)
+        check(lib.sept_bn_relu_pool_forward_argmax(x.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+                                                   beta.data_ptr(), _p(dropscale), y.data_ptr(), idx.data_ptr(), B, H, W, C,
+                                                   pool, _s(x)), "sept_bn_relu_pool_forward_argmax")
+        return y, idx
     check(lib.sept_bn_relu_pool_forward(x.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
                                         beta.data_ptr(), _p(dropscale), y.data_ptr(), B, H, W, C, pool, _s(x)),
           "sept_bn_relu_pool_forward")
@@ -409,6 +416,45 @@ def conv1_backward_data_bn(pre, dy, mean, invstd, gamma, beta, dropscale, w, pre
                                           beta.data_ptr(), _p(dropscale), sums.data_ptr(), float(B) * H * W, wptr, wp.data_ptr(),
                                           dx.data_ptr(), _p(dpre), B, H, W, _s(pre)), "sept_conv1_backward_data_bn")
     return dx, dpre, dgamma, dbeta
+
+
+def conv1_backward_data_sparse(x, pre, dy, idx, mean, invstd, gamma, beta, dropscale, w, bias, presums=None,
+                               need_param_grads=True, out_gamma=None, out_beta=None, prep=None, y=None):
+    """Backward of block 1 down to the gradient of the network input without a pre-activation-sized tensor: the pooled
+    gradient dy (B,H/2,W/2,32) bf16 and the arg-max positions idx (uint8, from bn_relu_pool_forward(want_argmax=True))
+    feed the sparse part of conv1's data gradient, the dense part is a linear map of the input x (B,H,W) fp32
+    (include/sept.h).  `pre` is only read by the channel-sum pass when a chunk has a tiny |gamma|.  Returns
+    (dx (B,H,W) fp32, dgamma, dbeta)."""
+    require_cuda(x, dy, idx, w)
+    B, H, W = x.shape
+    C = 32
+    dev = x.device
+    ws = workspace("bn", lib.sept_bn_workspace_floats(C), dev)
+    sums = torch.empty(2 * C, dtype=torch.float32, device=dev)
+    dgamma = dbeta = None
+    if need_param_grads:
+        dgamma = torch.empty(C, dtype=torch.float32, device=dev) if out_gamma is None else out_gamma
+        dbeta = torch.empty(C, dtype=torch.float32, device=dev) if out_beta is None else out_beta
+    if presums is not None:
+        parts, nparts = presums
+        check(lib.sept_bn_backward_sums_presummed(dy.data_ptr(), pre.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                                  gamma.data_ptr(), beta.data_ptr(), _p(dropscale), parts.data_ptr(), nparts,
+                                                  ws.data_ptr(), sums.data_ptr(), _p(dgamma), _p(dbeta), B, H, W, C, 2,
+                                                  _s(pre)), "sept_bn_backward_sums_presummed")
+    else:
+        check(lib.sept_bn_relu_pool_backward_reduce(dy.data_ptr(), pre.data_ptr(), _p(y), mean.data_ptr(), invstd.data_ptr(),
+                                                    gamma.data_ptr(), beta.data_ptr(), _p(dropscale), ws.data_ptr(),
+                                                    sums.data_ptr(), _p(dgamma), _p(dbeta), B, H, W, C, 2, _s(pre)),
+              "sept_bn_relu_pool_backward_reduce")
+    dx = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    coef = torch.empty(2800, dtype=torch.float32, device=dev)
+    wptr, wp = _c1w(x, w, prep, "conv1_prep_bwd")
+    wf = w.detach().contiguous()
+    check(lib.sept_conv1_backward_data_sparse(dy.data_ptr(), idx.data_ptr(), x.data_ptr(), wf.data_ptr(), _p(bias),
+                                              mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), _p(dropscale),
+                                              sums.data_ptr(), float(B) * H * W, wptr, wp.data_ptr(), coef.data_ptr(),
+                                              dx.data_ptr(), B, H, W, _s(x)), "sept_conv1_backward_data_sparse")
+    return dx, dgamma, dbeta
 
 
 def conv5x5_backward_weight(x, dy, out=None):

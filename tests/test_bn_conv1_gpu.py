@@ -276,3 +276,46 @@ def test_conv1_data_gradient_with_batchnorm_apply_folded_in(B, H, W, drop, want_
     scale = float(want_dx.abs().max())
     assert torch.allclose(dx, want_dx, rtol=2e-2, atol=2e-3 * scale), float((dx - want_dx).abs().max()) / scale
     assert float((dx - want_dx).norm() / want_dx.norm()) < 3e-3
+
+
+@pytest.mark.parametrize("B, H, W, drop", [(3, 16, 24, False), (2, 20, 80, True), (4, 8, 16, True), (2, 200, 80, False)])
+def test_block1_data_gradient_from_pooled_gradient_and_argmax_positions(B, H, W, drop):
+    """sept_conv1_backward_data_sparse: block 1's backward pass (Dropout2d, MaxPool, ReLU, training-mode BatchNorm, conv1:
+    baseline_models.py:172-176) down to the gradient of the network input WITHOUT a pre-activation-sized tensor -- the
+    sparse part (pooled gradient at the recorded arg-max positions) through the MFMA data-gradient kernel, the dense part
+    (BatchNorm's mean terms) as a linear map of the one-channel input (9 x 9 filter + the exact border ring).  Against
+    torch autograd through the same chain in fp32 (arg-max decisions on the stored bf16 pre-activations, as the HIP
+    forward takes them) and against the separate HIP passes."""
+    import torch.nn.functional as Fn
+    from sept_amd import ops
+    g = torch.Generator().manual_seed(7 * H + W + B)
+    x = torch.randn(B, H, W, generator=g).cuda()
+    w = (torch.randn(32, 1, 5, 5, generator=g) * 0.25).cuda()
+    bias = (0.1 * torch.randn(32, generator=g)).cuda()
+    gamma = (1 + 0.3 * torch.randn(32, generator=g)).cuda()
+    beta = (0.2 * torch.randn(32, generator=g)).cuda()
+    dmask = ((torch.rand(B, 32, generator=g) > 0.2).float() * 1.25).cuda() if drop else None
+    pre = ops.conv1_forward(x, w, bias)
+    mean, invstd = ops.bn_stats(pre)
+    y, idx = ops.bn_relu_pool_forward(pre, mean, invstd, gamma, beta, dmask, 2, want_argmax=True)
+    assert torch.equal(y, ops.bn_relu_pool_forward(pre, mean, invstd, gamma, beta, dmask, 2))
+    assert idx.dtype == torch.uint8 and int(idx.max()) <= 4
+    dy = torch.randn(B, H // 2, W // 2, 32, generator=g).bfloat16().cuda()
+    dx, dg, db = ops.conv1_backward_data_sparse(x, pre, dy, idx, mean, invstd, gamma, beta, dmask, w, bias, y=y)
+    # the separate HIP passes (held to torch by the tests above)
+    dpre_t, want_dg, want_db = ops.bn_relu_pool_backward(dy, pre, mean, invstd, gamma, beta, dmask, 2, y=y)
+    hip_dx = ops.conv1_backward_data(dpre_t, w)
+    assert torch.allclose(dg, want_dg, rtol=1e-5, atol=1e-6) and torch.allclose(db, want_db, rtol=1e-5, atol=1e-6)
+    # torch autograd in fp32
+    pr = pre.float().permute(0, 3, 1, 2).contiguous().requires_grad_()
+    out = Fn.max_pool2d(Fn.relu(Fn.batch_norm(pr, None, None, gamma, beta, training=True, eps=1e-5)), 2)
+    if dmask is not None:
+        out = out * dmask[:, :, None, None]
+    out.backward(dy.float().permute(0, 3, 1, 2))
+    ref_dx = torch.nn.grad.conv2d_input((B, 1, H, W), w, pr.grad, padding=2)[:, 0]
+    scale = float(ref_dx.abs().max())
+    err_new = float((dx - ref_dx).norm() / ref_dx.norm())
+    err_old = float((hip_dx - ref_dx).norm() / ref_dx.norm())
+    assert err_new < 6e-3, (err_new, err_old)
+    assert torch.allclose(dx, ref_dx, rtol=2e-2, atol=4e-3 * scale), float((dx - ref_dx).abs().max()) / scale
+    assert float((dx - hip_dx).norm() / hip_dx.norm()) < 8e-3
