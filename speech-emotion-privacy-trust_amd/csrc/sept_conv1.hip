@@ -1470,22 +1470,69 @@ __global__ __launch_bounds__(256) void sept_conv1_dense_coef_kernel(const float*
 // a row, whose pixels differ in column class, are done pixel by pixel in a second phase.
 __device__ __forceinline__ int border_class(int v, int n) { return v == 0 ? 0 : v == 1 ? 1 : v == n - 2 ? 3 : v == n - 1 ? 4 : 2; }
 
+constexpr int kDenseStage = 10;   // input elements a thread stages (covers (rows + 8) x (W + 8) <= 2560)
 __global__ __launch_bounds__(256) void sept_conv1_dense_dgrad_kernel(const float* __restrict__ x, const float* __restrict__ coef,
-                                                                     float* __restrict__ dx, int B, int H, int W, int rows) {
+                                                                     float* __restrict__ dx, int B, int H, int W, int rows, int W8) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* ks = reinterpret_cast<float*>(smem);          // [25][kCoefStride]
-  float* xt = ks + kCoefClasses * kCoefStride;         // [rows + 8][W + 8], zero outside the image
-  const int W8 = W + 8, tid = threadIdx.x;
+  // [rows + 8][W8], zero outside the image.  The row pitch W8 >= W + 8 is chosen = 4 * (groups per row) mod 64, so the
+  // 16-byte reads of consecutive threads stay bank-contiguous across a row change (with pitch W + 8 59 % of this kernel's
+  // LDS cycles were bank conflicts)
+  float* xt = ks + kCoefClasses * kCoefStride;
+  float* part = xt + (rows + 8) * W8;                  // [rows * 8][3] partial sums of the edge pixels
+  const int WS = W + 8, tid = threadIdx.x;
   const int b = blockIdx.y, r0 = blockIdx.x * rows;
   const float* xb = x + size_t(b) * H * W;
-  for (int i = tid; i < kCoefClasses * kCoefStride / 4; i += 256) reinterpret_cast<float4*>(ks)[i] = reinterpret_cast<const float4*>(coef)[i];
-  for (int i = tid; i < (rows + 8) * W8; i += 256) {
-    const int rr = i / W8, cc = i - rr * W8;
-    const int h = r0 - 4 + rr, w0 = cc - 4;
-    xt[i] = (h >= 0 && h < H && w0 >= 0 && w0 < W) ? xb[size_t(h) * W + w0] : 0.f;
+  // unconditional (clamped) loads, all in flight together, then the LDS stores: a load under a per-element branch waits
+  // for its own round trip before the next one is issued (8 dependent round trips per workgroup: 38 of this kernel's
+  // first 95 us)
+  {
+    const int n = (rows + 8) * WS;
+    const float inv = 1.0f / float(WS);
+    float v[kDenseStage];
+    bool ok[kDenseStage];
+    int dst[kDenseStage];
+#pragma unroll
+    for (int j = 0; j < kDenseStage; ++j) {
+      const int i = min(tid + 256 * j, n - 1);
+      const int rr = int((float(i) + 0.5f) * inv), cc = i - rr * WS;
+      const int h = r0 - 4 + rr, w0 = cc - 4;
+      ok[j] = h >= 0 && h < H && w0 >= 0 && w0 < W;
+      dst[j] = rr * W8 + cc;
+      v[j] = xb[size_t(min(max(h, 0), H - 1)) * W + min(max(w0, 0), W - 1)];
+    }
+    for (int i = tid; i < kCoefClasses * kCoefStride / 4; i += 256) reinterpret_cast<float4*>(ks)[i] = reinterpret_cast<const float4*>(coef)[i];
+#pragma unroll
+    for (int j = 0; j < kDenseStage; ++j)
+      if (tid + 256 * j < n) xt[dst[j]] = ok[j] ? v[j] : 0.f;
   }
   __syncthreads();
   const int groups = W / 4, inner = groups - 2;        // groups 1 .. groups-2 of a row: all four pixels in column class 2
+  // the two edge groups of every row (their four pixels differ in column class): a thread takes three kernel rows of one
+  // group, with the four pixels' own kernels; partial sums meet in LDS.  16-byte reads throughout.
+  for (int i = tid; i < rows * 6; i += 256) {
+    const int grp = i / 3, third = i - grp * 3;
+    const int rr = grp >> 1, c0 = (grp & 1) ? W - 4 : 0;
+    const int rcls = border_class(min(r0 + rr, H - 1), H) * 5;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int ur = 3 * third + q;
+      const float4* row = reinterpret_cast<const float4*>(xt + (rr + ur) * W8 + c0);
+      const float4 p0 = row[0], p1 = row[1], p2 = row[2];
+      const float v[12] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4* krow = reinterpret_cast<const float4*>(ks + (rcls + border_class(c0 + j, W)) * kCoefStride + ur * 12);
+        const float4 k0 = krow[0], k1 = krow[1], k2 = krow[2];
+        const float k[9] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w, k2.x};
+#pragma unroll
+        for (int uc = 0; uc < 9; ++uc) acc[j] = __builtin_fmaf(k[uc], v[uc + j], acc[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) part[(grp * 4 + j) * 3 + third] = acc[j];
+  }
   for (int i = tid; i < rows * inner; i += 256) {
     const int rr = i / inner, c0 = (i - rr * inner + 1) * 4;
     const int h = r0 + rr;
@@ -1514,22 +1561,13 @@ __global__ __launch_bounds__(256) void sept_conv1_dense_dgrad_kernel(const float
     cur.w += acc[3];
     *o = cur;
   }
-  // the two edge groups of every row, one pixel per thread
-  for (int i = tid; i < rows * 8; i += 256) {
+  __syncthreads();
+  for (int i = tid; i < rows * 8; i += 256) {   // pixel i = (row, side, j): part[i][0..2]
     const int rr = i >> 3, e = i & 7;
     const int h = r0 + rr, c = e < 4 ? e : W - 8 + e;
     if (h >= H) continue;
-    const float* kc = ks + (border_class(h, H) * 5 + border_class(c, W)) * kCoefStride;
-    float a0 = kc[kCoefConst], a1 = 0.f, a2 = 0.f;
-#pragma unroll
-    for (int ur = 0; ur < 9; ur += 3)
-#pragma unroll
-      for (int uc = 0; uc < 9; ++uc) {
-        a0 = __builtin_fmaf(kc[ur * 12 + uc], xt[(rr + ur) * W8 + c + uc], a0);
-        a1 = __builtin_fmaf(kc[(ur + 1) * 12 + uc], xt[(rr + ur + 1) * W8 + c + uc], a1);
-        a2 = __builtin_fmaf(kc[(ur + 2) * 12 + uc], xt[(rr + ur + 2) * W8 + c + uc], a2);
-      }
-    dx[(size_t(b) * H + h) * W + c] += a0 + (a1 + a2);
+    const float kv = ks[(border_class(h, H) * 5 + border_class(c, W)) * kCoefStride + kCoefConst];
+    dx[(size_t(b) * H + h) * W + c] += kv + (part[3 * i] + part[3 * i + 1] + part[3 * i + 2]);
   }
 }
 
@@ -1562,9 +1600,13 @@ extern "C" int sept_conv1_backward_data_sparse(const void* dy_pooled, const void
              float(1.0 / n_total), wprep, dx, nullptr, B, H, W, rows, static_cast<const unsigned char*>(idx_u8)};
   SEPT_HIP(sept::allow_max_lds(reinterpret_cast<const void*>(&sept_conv1_dgrad_bnapply_kernel<true>)));
   hipLaunchKernelGGL(sept_conv1_dgrad_bnapply_kernel<true>, dim3(chunks, B), dim3(256), smem_r, st, a);
-  const int drows = std::max(1, 256 / std::max(1, W / 4 - 2));   // image rows per workgroup: one four-pixel group per thread
-  const size_t smem_d = sizeof(float) * (size_t(kCoefClasses) * kCoefStride + size_t(drows + 8) * (W + 8));
+  // image rows per workgroup: one four-pixel group per thread, within what kDenseStage elements per thread can stage
+  const int drows = std::max(1, std::min(256 / std::max(1, W / 4 - 2), 256 * kDenseStage / (W + 8) - 8));
+  int pitch = W + 8;
+  while (pitch % 64 != (4 * (W / 4 - 2)) % 64) pitch += 4;
+  const size_t smem_d = sizeof(float) * (size_t(kCoefClasses) * kCoefStride + size_t(drows + 8) * pitch + size_t(drows) * 24);
+  SEPT_REQUIRE((drows + 8) * (W + 8) <= 256 * kDenseStage, SEPT_ERR_UNSUPPORTED, "sept_conv1_backward_data_sparse: W=%d", W);
   hipLaunchKernelGGL(sept_conv1_dense_dgrad_kernel, dim3((H + drows - 1) / drows, B), dim3(256), smem_d, st, x, coef, dx, B, H, W,
-                     drows);
+                     drows, pitch);
   return sept::launch_check("sept_conv1_backward_data_sparse");
 }

@@ -1,6 +1,6 @@
 set -e
 export TMPDIR=/tmp
-O=gpurun_out/r4e
+O=gpurun_out/r4h
 mkdir -p $O
 python -m pytest tests -m gpu -q --tb=line > $O/gpu_tests.log 2>&1 || true
 grep -E "^/root|^E |Error|passed|failed" $O/gpu_tests.log | cut -c1-300 | head -20
@@ -11,4 +11,3 @@ import json
 d=json.load(open("$O/bench_$i.json")); print(d["value"], d["ms_per_step"], d["roofline"]["kernel"], d["roofline"]["frac"], d["roofline"]["alone"]["frac"], d["reference_batch"]["ms_per_step"])
 PY
 done
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')"
