@@ -38,35 +38,44 @@ struct C1Args {
   int B, H, W;
 };
 
-// stage rows [h_first-2, h_last+2] x cols [-2, W+2) of a single-channel fp32 image
-__device__ __forceinline__ void stage_x(const float* xb, float* tile, int h_first, int NR, int H, int W) {
-  const int W4 = W + 4;
-  for (int row = threadIdx.x / 64; row < NR; row += 4) {      // one wave per row: no per-element division
-    const int h = h_first - 2 + row;
-    const bool hin = h >= 0 && h < H;
-    for (int col = threadIdx.x & 63; col < W4; col += 64) {
-      const int w = col - 2;
-      tile[row * W4 + col] = (hin && w >= 0 && w < W) ? xb[size_t(h) * W + w] : 0.f;
+// Stage rows [h_first-2, h_last+2] x cols [-2, W+2) of a single-channel fp32 image: `put(i, v)` receives element i of the
+// [NR][W + 4] tile.  Loads are unconditional (clamped addresses, zero selected afterwards) and issued four at a time
+// before their stores: a load under a per-element branch waits for its own round trip before the next one is issued
+// (six dependent HBM / L2 round trips per 256-pixel tile in the first version of these loaders).
+template <class Put>
+__device__ __forceinline__ void stage_rows(const float* xb, int h_first, int NR, int H, int W, Put&& put) {
+  const int W4 = W + 4, n = NR * W4;
+  const float inv = 1.0f / float(W4);
+  for (int base = threadIdx.x; base < n; base += 4 * 256) {
+    float v[4];
+    bool ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = min(base + 256 * j, n - 1);
+      const int row = int((float(i) + 0.5f) * inv), col = i - row * W4;
+      const int h = h_first - 2 + row, w = col - 2;
+      ok[j] = h >= 0 && h < H && w >= 0 && w < W;
+      v[j] = xb[size_t(min(max(h, 0), H - 1)) * W + min(max(w, 0), W - 1)];
     }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (base + 256 * j < n) put(base + 256 * j, ok[j] ? v[j] : 0.f);
   }
+}
+
+__device__ __forceinline__ void stage_x(const float* xb, float* tile, int h_first, int NR, int H, int W) {
+  stage_rows(xb, h_first, NR, H, W, [&](int i, float v) { tile[i] = v; });
 }
 
 // the same rows with every sample already split into its two bf16 halves, packed (hi << 16 | lo): the MFMA forward
 // builds its split im2col operands from these words with two byte-permutes per pair of taps, where splitting at every
 // USE (each staged sample is read by 25 taps) cost four conversions per tap and made the kernel VALU-bound
 __device__ __forceinline__ void stage_x_split(const float* xb, unsigned* tile, int h_first, int NR, int H, int W) {
-  const int W4 = W + 4;
-  for (int row = threadIdx.x / 64; row < NR; row += 4) {      // one wave per row: no per-element division
-    const int h = h_first - 2 + row;
-    const bool hin = h >= 0 && h < H;
-    for (int col = threadIdx.x & 63; col < W4; col += 64) {
-      const int w = col - 2;
-      const float v = (hin && w >= 0 && w < W) ? xb[size_t(h) * W + w] : 0.f;
-      const bf16 hi = (bf16)v;
-      const bf16 lo = (bf16)(v - float(hi));
-      tile[row * W4 + col] = (unsigned(__builtin_bit_cast(unsigned short, hi)) << 16) | __builtin_bit_cast(unsigned short, lo);
-    }
-  }
+  stage_rows(xb, h_first, NR, H, W, [&](int i, float v) {
+    const bf16 hi = (bf16)v;
+    const bf16 lo = (bf16)(v - float(hi));
+    tile[i] = (unsigned(__builtin_bit_cast(unsigned short, hi)) << 16) | __builtin_bit_cast(unsigned short, lo);
+  });
 }
 
 // Weight operands in the form the kernels read them with SCALAR loads (uniform addresses, so
@@ -862,20 +871,37 @@ __global__ __launch_bounds__(256) void sept_conv1_wgrad_mfma_kernel(const float*
   const int tiles_per_img = (HW + kMT - 1) / kMT;
   const long n_tiles = long(B) * tiles_per_img;
   const float inv_w = 1.0f / float(W);
-  // contiguous tile range per workgroup (consecutive tiles share halo rows through this XCD's L2)
-  for (long tile_id = n_tiles * blockIdx.x / gridDim.x; tile_id < n_tiles * (blockIdx.x + 1) / gridDim.x; ++tile_id) {
+  // contiguous tile range per workgroup (consecutive tiles share halo rows through this XCD's L2).  The dy tile of the
+  // NEXT tile (16 KB, the HBM stream of this kernel) is fetched into registers while the current one is computed on:
+  // four unconditional 16-byte loads per thread in flight together -- fetched under per-chunk branches right before
+  // their LDS stores they were four dependent HBM round trips per tile (80 % of this kernel's wave time waiting)
+  constexpr int NY = kMT * 4 / 256;
+  uint4 dyr[NY];
+  const long tile_end = n_tiles * (blockIdx.x + 1) / gridDim.x;
+  auto fetch_dy = [&](long tile_id) {
+    const long tc = min(tile_id, n_tiles - 1);
+    const int b = int(tc / tiles_per_img), q0 = int(tc % tiles_per_img) * kMT;
+    const bf16* dyb = dy + (size_t(b) * HW + q0) * kC;
+#pragma unroll
+    for (int j = 0; j < NY; ++j) {
+      const int i = tid + 256 * j, t = i >> 2, c = i & 3;
+      dyr[j] = *reinterpret_cast<const uint4*>(dyb + size_t(min(t, HW - 1 - q0)) * kC + c * 8);
+    }
+  };
+  long tile_id = n_tiles * blockIdx.x / gridDim.x;
+  if (tile_id < tile_end) fetch_dy(tile_id);
+  for (; tile_id < tile_end; ++tile_id) {
     const int b = tile_id / tiles_per_img, q0 = int(tile_id % tiles_per_img) * kMT;
     const int h_first = q0 / W, h_last = min(q0 + kMT - 1, HW - 1) / W;
     __syncthreads();
     stage_x(x + size_t(b) * HW, xt, h_first, h_last - h_first + 5, H, W);
-    const bf16* dyb = dy + (size_t(b) * HW + q0) * kC;
-    for (int i = tid; i < kMT * 4; i += 256) {
-      const int t = i >> 2, c = i & 3;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (q0 + t < HW) v = *reinterpret_cast<const uint4*>(dyb + size_t(t) * kC + c * 8);
-      *reinterpret_cast<uint4*>(yt + size_t(t) * kDyPSt + c * 16) = v;
+#pragma unroll
+    for (int j = 0; j < NY; ++j) {
+      const int i = tid + 256 * j, t = i >> 2, c = i & 3;
+      *reinterpret_cast<uint4*>(yt + size_t(t) * kDyPSt + c * 16) = q0 + t < HW ? dyr[j] : make_uint4(0, 0, 0, 0);
     }
-    __syncthreads();
+    fetch_dy(tile_id + 1);   // past the range: re-reads a valid tile, never stored
+    sept::lds_barrier();     // LDS-only wait: the loads just issued stay in flight across the barrier
     // All operands of the tile's kMT / 64 steps are requested first, then the MFMAs run: straight-line code (the row
     // of a pixel group comes from one float multiply, exact for q < 2^24; every lane loads its 8 inputs unconditionally
     // and the bias / padding columns are selected afterwards) -- per-element branches around the loads and a divergent

@@ -1,6 +1,6 @@
 set -e
 export TMPDIR=/tmp
-O=gpurun_out/r4h
+O=gpurun_out/r4j
 mkdir -p $O
 python -m pytest tests -m gpu -q --tb=line > $O/gpu_tests.log 2>&1 || true
 grep -E "^/root|^E |Error|passed|failed" $O/gpu_tests.log | cut -c1-300 | head -20
