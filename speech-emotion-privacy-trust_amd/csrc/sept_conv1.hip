@@ -239,22 +239,38 @@ __global__ __launch_bounds__(256) void sept_conv1_fwd_mfma_kernel(const float* _
   }
   if constexpr (STATS) {
     __syncthreads();   // the staged rows are no longer needed: the exchange reuses their LDS
-    float* ex = reinterpret_cast<float*>(smem);   // [256 lanes][kStatLd]: 16 sums, 16 sums of squares
+    // [32 values][256 lanes] (value-major: conflict-free writes, 16-byte reads along the lanes), then [64][4] partials.
+    // Every thread adds one run of 32 lanes; four partials per statistic meet in a second, tiny stage -- the first
+    // version had 64 threads walk 128 LDS values each, one dependent read at a time, while 192 threads waited.
+    float* ex = reinterpret_cast<float*>(smem);
+    float* ex2 = ex + 32 * 256;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      ex[threadIdx.x * kStatLd + r] = rs[r];
-      ex[threadIdx.x * kStatLd + 16 + r] = rss[r];
+      ex[r * 256 + threadIdx.x] = rs[r];
+      ex[(16 + r) * 256 + threadIdx.x] = rss[r];
+    }
+    __syncthreads();
+    {
+      // thread = (statistic o = (which, channel), run p = wave): channel 8j + 4*hf + i lives in register 4j + i of the
+      // lanes with half hf, i.e. lanes p * 64 + hf * 32 + 0..31
+      const int o = threadIdx.x & 63, p = threadIdx.x >> 6;
+      const int which = o / kC, ch = o % kC;
+      const int j = ch >> 3, hf = (ch >> 2) & 1, i = ch & 3;
+      const float4* run = reinterpret_cast<const float4*>(ex + (which * 16 + 4 * j + i) * 256 + p * 64 + hf * 32);
+      float t = 0.f;
+#pragma unroll
+      for (int l = 0; l < 8; ++l) {
+        const float4 v = run[l];
+        t += (v.x + v.y) + (v.z + v.w);
+      }
+      ex2[o * 4 + p] = t;
     }
     __syncthreads();
     if (threadIdx.x < 2 * kC) {
-      // thread = (which statistic, channel); channel 8j + 4*hf + i lives in register 4j + i of the lanes with half hf
-      const int which = threadIdx.x / kC, ch = threadIdx.x % kC;
-      const int j = ch >> 3, hf = (ch >> 2) & 1, i = ch & 3;
-      float t = 0.f;
-      for (int w = 0; w < 4; ++w)
-        for (int l = 0; l < 32; ++l) t += ex[(w * 64 + hf * 32 + l) * kStatLd + which * 16 + 4 * j + i];
+      const float4 v = reinterpret_cast<const float4*>(ex2)[threadIdx.x];
       // transposed partials [64][workgroups]: the finalize pass reads each statistic contiguously
-      stats[size_t(threadIdx.x) * (size_t(gridDim.x) * gridDim.y) + size_t(blockIdx.y) * gridDim.x + blockIdx.x] = t;
+      stats[size_t(threadIdx.x) * (size_t(gridDim.x) * gridDim.y) + size_t(blockIdx.y) * gridDim.x + blockIdx.x] =
+          (v.x + v.y) + (v.z + v.w);
     }
   }
 }

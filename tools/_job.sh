@@ -1,13 +1,7 @@
 set -e
 export TMPDIR=/tmp
-O=gpurun_out/r4j
+O=gpurun_out/r4k
 mkdir -p $O
-python -m pytest tests -m gpu -q --tb=line > $O/gpu_tests.log 2>&1 || true
-grep -E "^/root|^E |Error|passed|failed" $O/gpu_tests.log | cut -c1-300 | head -20
-for i in 1 2; do
-python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_$i.json 2> $O/bench_$i.err
-python - <<PY
-import json
-d=json.load(open("$O/bench_$i.json")); print(d["value"], d["ms_per_step"], d["roofline"]["kernel"], d["roofline"]["frac"], d["roofline"]["alone"]["frac"], d["reference_batch"]["ms_per_step"])
-PY
-done
+python -m pytest tests/test_bn_conv1_gpu.py -m gpu -q --tb=short -x > $O/t.log 2>&1 || true
+tail -3 $O/t.log
+timeout -k 10 300 python tools/bench_parts2.py 2>&1 | head -6
