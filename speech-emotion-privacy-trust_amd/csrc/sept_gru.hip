@@ -31,7 +31,10 @@ struct GruArgs {
   int B, T;
 };
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// the gate nonlinearities sit on the 25-step serial chain: one exp + one hardware reciprocal each (1 ulp; an IEEE division
+// is ten dependent instructions, ocml's tanhf thirty)
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 
 // sum of a value over the two lanes of a pair (lane ^ 1), by DPP quad_perm [1,0,3,2]
 __device__ __forceinline__ float pair_sum(float v) {
@@ -44,7 +47,7 @@ __device__ __forceinline__ float pair_sum(float v) {
 template <int kH>
 __global__ __launch_bounds__(kBS * kH * 2) void sept_gru_fwd_kernel(GruArgs a) {
   constexpr int kHH = kH / 2;
-  __shared__ __attribute__((aligned(16))) float hs[kBS][kH];
+  __shared__ __attribute__((aligned(16))) float hs[2][kBS][kH];   // ping-pong: one barrier per step
   const int s = threadIdx.x / (2 * kH), j = (threadIdx.x >> 1) % kH, half = threadIdx.x & 1;
   // a sample index past the batch is clamped (the surplus lanes recompute and rewrite the last
   // sample's values): the loop body then has no divergent branches, which lets the compiler
@@ -61,7 +64,7 @@ __global__ __launch_bounds__(kBS * kH * 2) void sept_gru_fwd_kernel(GruArgs a) {
   // the bias rides in the first lane of the pair so that the pair sum carries it once
   const float br = half ? 0.f : a.bhh[dir][j], bz = half ? 0.f : a.bhh[dir][kH + j], bn = half ? 0.f : a.bhh[dir][2 * kH + j];
   float h = 0.f;
-  if (!half) hs[s][j] = 0.f;
+  if (!half) hs[0][s][j] = 0.f;
   // the input-projection terms of the NEXT step are fetched while this step's FMAs run
   auto gi_at = [&](int step, float& gr, float& gz, float& gn) {
     const int st = min(step, a.T - 1);
@@ -91,21 +94,24 @@ __global__ __launch_bounds__(kBS * kH * 2) void sept_gru_fwd_kernel(GruArgs a) {
     const int t = dir == 0 ? step : a.T - 1 - step;
     float ngr, ngz, ngn;
     gi_at(step + 1, ngr, ngz, ngn);
-    float ar = br, az = bz, an = bn;
+    float ar = br, az = bz, an = bn, ar2 = 0.f, az2 = 0.f, an2 = 0.f;   // two chains per gate: half the dependent depth
+    const float* hc = &hs[step & 1][s][half * kHH];
 #pragma unroll
-    for (int k = 0; k < kHH; k += 4) {
-      const float4 hv = *reinterpret_cast<const float4*>(&hs[s][half * kHH + k]);
+    for (int k = 0; k < kHH; k += 8) {
+      const float4 hv = *reinterpret_cast<const float4*>(hc + k), hw = *reinterpret_cast<const float4*>(hc + k + 4);
       ar = fmaf(wr[k], hv.x, ar); ar = fmaf(wr[k + 1], hv.y, ar); ar = fmaf(wr[k + 2], hv.z, ar); ar = fmaf(wr[k + 3], hv.w, ar);
       az = fmaf(wz[k], hv.x, az); az = fmaf(wz[k + 1], hv.y, az); az = fmaf(wz[k + 2], hv.z, az); az = fmaf(wz[k + 3], hv.w, az);
       an = fmaf(wn[k], hv.x, an); an = fmaf(wn[k + 1], hv.y, an); an = fmaf(wn[k + 2], hv.z, an); an = fmaf(wn[k + 3], hv.w, an);
+      ar2 = fmaf(wr[k + 4], hw.x, ar2); ar2 = fmaf(wr[k + 5], hw.y, ar2); ar2 = fmaf(wr[k + 6], hw.z, ar2); ar2 = fmaf(wr[k + 7], hw.w, ar2);
+      az2 = fmaf(wz[k + 4], hw.x, az2); az2 = fmaf(wz[k + 5], hw.y, az2); az2 = fmaf(wz[k + 6], hw.z, az2); az2 = fmaf(wz[k + 7], hw.w, az2);
+      an2 = fmaf(wn[k + 4], hw.x, an2); an2 = fmaf(wn[k + 5], hw.y, an2); an2 = fmaf(wn[k + 6], hw.z, an2); an2 = fmaf(wn[k + 7], hw.w, an2);
     }
-    ar = pair_sum(ar); az = pair_sum(az); an = pair_sum(an);   // both lanes of the pair now hold the full sums
+    ar = pair_sum(ar + ar2); az = pair_sum(az + az2); an = pair_sum(an + an2);   // both lanes of the pair now hold the full sums
     const float r = sigmoidf_(gr + ar), z = sigmoidf_(gz + az);
-    const float n = tanhf(gn + r * an);
+    const float n = tanhf_(gn + r * an);
     h = (1.f - z) * n + z * h;
-    sept::lds_barrier();   // LDS-only wait: global prefetches / stores stay in flight across the barrier
-    hs[s][j] = h;          // both lanes of the pair write the same value
-    sept::lds_barrier();
+    hs[(step + 1) & 1][s][j] = h;   // both lanes of the pair write the same value; the other buffer is still being read
+    sept::lds_barrier();            // LDS-only wait: global prefetches / stores stay in flight across the barrier
     store_step(t, half ? n : h, half ? an : r, half ? an : z);
     gr = ngr; gz = ngz; gn = ngn;
   }
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(kBS * kH * 2) void sept_gru_fwd_kernel(GruArgs a) {
 template <int kH>
 __global__ __launch_bounds__(kBS * kH * 2) void sept_gru_bwd_kernel(GruArgs a) {
   constexpr int kHH = kH / 2;
-  __shared__ __attribute__((aligned(16))) float ds[kBS][3 * kH];
+  __shared__ __attribute__((aligned(16))) float ds[2][kBS][3 * kH];   // ping-pong: one barrier per step
   const int s = threadIdx.x / (2 * kH), j = (threadIdx.x >> 1) % kH, half = threadIdx.x & 1;
   const int dir = blockIdx.y, b = min(blockIdx.x * kBS + s, a.B - 1);   // clamped, see the forward kernel
   // column j of W_hr, W_hz, W_hn: dh_prev[j] = sum_i W[i][j] * dgh[i]; each lane of the pair owns
@@ -173,19 +179,20 @@ __global__ __launch_bounds__(kBS * kH * 2) void sept_gru_bwd_kernel(GruArgs a) {
     const float dr_pre = dn_pre * hn * r * (1.f - r);
     const float dz_pre = dz * z * (1.f - z);
     store_step(t, dr_pre, dz_pre, half ? dhn : dn_pre, half ? hp : dr_pre);
+    float* dc = ds[step & 1][s];
+    dc[j] = dr_pre; dc[kH + j] = dz_pre; dc[2 * kH + j] = dhn;   // same values from both lanes
     sept::lds_barrier();   // LDS-only wait: global prefetches / stores stay in flight across the barrier
-    ds[s][j] = dr_pre; ds[s][kH + j] = dz_pre; ds[s][2 * kH + j] = dhn;   // same values from both lanes
-    sept::lds_barrier();
-    float acc = half ? 0.f : carry;
+    float acc = half ? 0.f : carry, accz = 0.f, accn = 0.f;   // three chains instead of one of 96 dependent FMAs
 #pragma unroll
     for (int i = 0; i < kHH; i += 4) {
-      const float4 vr = *reinterpret_cast<const float4*>(&ds[s][half * kHH + i]);
-      const float4 vz = *reinterpret_cast<const float4*>(&ds[s][kH + half * kHH + i]);
-      const float4 vn = *reinterpret_cast<const float4*>(&ds[s][2 * kH + half * kHH + i]);
+      const float4 vr = *reinterpret_cast<const float4*>(&dc[half * kHH + i]);
+      const float4 vz = *reinterpret_cast<const float4*>(&dc[kH + half * kHH + i]);
+      const float4 vn = *reinterpret_cast<const float4*>(&dc[2 * kH + half * kHH + i]);
       acc = fmaf(wr[i], vr.x, acc); acc = fmaf(wr[i + 1], vr.y, acc); acc = fmaf(wr[i + 2], vr.z, acc); acc = fmaf(wr[i + 3], vr.w, acc);
-      acc = fmaf(wz[i], vz.x, acc); acc = fmaf(wz[i + 1], vz.y, acc); acc = fmaf(wz[i + 2], vz.z, acc); acc = fmaf(wz[i + 3], vz.w, acc);
-      acc = fmaf(wn[i], vn.x, acc); acc = fmaf(wn[i + 1], vn.y, acc); acc = fmaf(wn[i + 2], vn.z, acc); acc = fmaf(wn[i + 3], vn.w, acc);
+      accz = fmaf(wz[i], vz.x, accz); accz = fmaf(wz[i + 1], vz.y, accz); accz = fmaf(wz[i + 2], vz.z, accz); accz = fmaf(wz[i + 3], vz.w, accz);
+      accn = fmaf(wn[i], vn.x, accn); accn = fmaf(wn[i + 1], vn.y, accn); accn = fmaf(wn[i + 2], vn.z, accn); accn = fmaf(wn[i + 3], vn.w, accn);
     }
+    acc += accz + accn;
     dh = pair_sum(acc);
     cur = nxt;
   }

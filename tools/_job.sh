@@ -1,9 +1,14 @@
 set -e
 export TMPDIR=/tmp
-O=gpurun_out/r4m
+O=gpurun_out/r5c
 mkdir -p $O
-SEPT_BENCH_DEVICE=0 SEPT_BENCH_BACKEND=gloo timeout -k 10 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-baseline > $O/dp2.json 2> $O/dp2.err || tail -20 $O/dp2.err
+python -m pytest tests -m gpu -q --tb=line > $O/gpu_tests.log 2>&1 || true
+grep -E "^/root|^E |Error|passed|failed" $O/gpu_tests.log | cut -c1-300 | head -20
+python tools/bench_gru.py
+for i in 1 2; do
+python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_$i.json 2> $O/bench_$i.err
 python - <<PY
 import json
-d=json.loads(open("$O/dp2.json").read().strip().splitlines()[-1]); print(d["n_gpus"], d["value"], d["ms_per_step"], d["config"].get("host_enqueue_ms_per_step"), d["config"]["parallelism"])
+d=json.load(open("$O/bench_$i.json")); print(d["value"], d["ms_per_step"], d["roofline"]["kernel"], d["roofline"]["frac"], d["roofline"]["alone"]["frac"], d["reference_batch"]["ms_per_step"])
 PY
+done
