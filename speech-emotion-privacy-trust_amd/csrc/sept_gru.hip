@@ -183,14 +183,21 @@ __global__ __launch_bounds__(kBS * kH * 2) void sept_gru_bwd_kernel(GruArgs a) {
     dc[j] = dr_pre; dc[kH + j] = dz_pre; dc[2 * kH + j] = dhn;   // same values from both lanes
     sept::lds_barrier();   // LDS-only wait: global prefetches / stores stay in flight across the barrier
     float acc = half ? 0.f : carry, accz = 0.f, accn = 0.f;   // three chains instead of one of 96 dependent FMAs
+    // all 3 kHH / 4 LDS reads are requested before the first FMA (the scheduling barrier keeps hipcc from pairing each
+    // read with its use again: one wave per SIMD, nothing else hides an LDS round trip)
+    float4 vr[kHH / 4], vz[kHH / 4], vn[kHH / 4];
 #pragma unroll
-    for (int i = 0; i < kHH; i += 4) {
-      const float4 vr = *reinterpret_cast<const float4*>(&dc[half * kHH + i]);
-      const float4 vz = *reinterpret_cast<const float4*>(&dc[kH + half * kHH + i]);
-      const float4 vn = *reinterpret_cast<const float4*>(&dc[2 * kH + half * kHH + i]);
-      acc = fmaf(wr[i], vr.x, acc); acc = fmaf(wr[i + 1], vr.y, acc); acc = fmaf(wr[i + 2], vr.z, acc); acc = fmaf(wr[i + 3], vr.w, acc);
-      accz = fmaf(wz[i], vz.x, accz); accz = fmaf(wz[i + 1], vz.y, accz); accz = fmaf(wz[i + 2], vz.z, accz); accz = fmaf(wz[i + 3], vz.w, accz);
-      accn = fmaf(wn[i], vn.x, accn); accn = fmaf(wn[i + 1], vn.y, accn); accn = fmaf(wn[i + 2], vn.z, accn); accn = fmaf(wn[i + 3], vn.w, accn);
+    for (int i = 0; i < kHH / 4; ++i) {
+      vr[i] = *reinterpret_cast<const float4*>(&dc[half * kHH + 4 * i]);
+      vz[i] = *reinterpret_cast<const float4*>(&dc[kH + half * kHH + 4 * i]);
+      vn[i] = *reinterpret_cast<const float4*>(&dc[2 * kH + half * kHH + 4 * i]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < kHH / 4; ++i) {
+      acc = fmaf(wr[4 * i], vr[i].x, acc); acc = fmaf(wr[4 * i + 1], vr[i].y, acc); acc = fmaf(wr[4 * i + 2], vr[i].z, acc); acc = fmaf(wr[4 * i + 3], vr[i].w, acc);
+      accz = fmaf(wz[4 * i], vz[i].x, accz); accz = fmaf(wz[4 * i + 1], vz[i].y, accz); accz = fmaf(wz[4 * i + 2], vz[i].z, accz); accz = fmaf(wz[4 * i + 3], vz[i].w, accz);
+      accn = fmaf(wn[4 * i], vn[i].x, accn); accn = fmaf(wn[4 * i + 1], vn[i].y, accn); accn = fmaf(wn[4 * i + 2], vn[i].z, accn); accn = fmaf(wn[4 * i + 3], vn[i].w, accn);
     }
     acc += accz + accn;
     dh = pair_sum(acc);

@@ -1,14 +1,7 @@
 set -e
 export TMPDIR=/tmp
-O=gpurun_out/r5c
+O=gpurun_out/r5d
 mkdir -p $O
-python -m pytest tests -m gpu -q --tb=line > $O/gpu_tests.log 2>&1 || true
-grep -E "^/root|^E |Error|passed|failed" $O/gpu_tests.log | cut -c1-300 | head -20
+python -m pytest tests/test_small_ops_gpu.py -m gpu -q --tb=short -x -k "gru" > $O/t.log 2>&1 || true
+tail -2 $O/t.log
 python tools/bench_gru.py
-for i in 1 2; do
-python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_$i.json 2> $O/bench_$i.err
-python - <<PY
-import json
-d=json.load(open("$O/bench_$i.json")); print(d["value"], d["ms_per_step"], d["roofline"]["kernel"], d["roofline"]["frac"], d["roofline"]["alone"]["frac"], d["reference_batch"]["ms_per_step"])
-PY
-done
