@@ -938,6 +938,39 @@ def test_hand_scheduled_step_equals_the_autograd_step(scale_lamda, with_dropout)
     assert res[0][1] == pytest.approx(res[1][1], rel=1e-6)     # (a + b) - c against (a - c) + b
 
 
+@pytest.mark.parametrize("att, pooling, weighted, masked", [("self_att", "mean", False, True), ("self_att", "mean", True, False)])
+def test_hand_scheduled_step_covers_the_wrapper_options(att, pooling, weighted, masked):
+    """The hand-scheduled step on the other forms train() can take (training_cloak_with_grl.py:122-169): attention in both
+    branches, a suppression mask on the cloak, an unweighted loss, Adam -- the same parameters as the autograd path, bit
+    for bit."""
+    from model import cloak_models as cm
+    from sept_amd import trainer as T
+    F = 80
+    x = closed_form_input(B, W, F).cuda()
+    le, lg, wts = (t.cuda() for t in closed_form_labels(B))
+    mask = (torch.rand(1, W, F, generator=torch.Generator().manual_seed(3)) > 0.3).float().cuda() if masked else None
+    res = []
+    for hand in (False, True):
+        prev, T.HAND_SCHEDULED = T.HAND_SCHEDULED, hand
+        try:
+            emo = _mk_opt("emotion", att, 0, "emotion.")
+            gen = _mk_opt("gender", att, 0, "gender.")
+            noise = cm.cloak_noise(torch.zeros(1, W, F), torch.ones(1, W, F), torch.tensor(0.01), torch.tensor(10.0), "cuda")
+            noise.load_state_dict(closed_form_state(noise, prefix="noise."))
+            noise.eps = closed_form_eps(W, F).cuda()
+            grl = cm.two_d_cnn_lstm_syn_with_grl(emo, gen, noise, 0.1).cuda().train()
+            zero_dropout(grl)
+            tr = T.GrlTrainer(grl, optimizer="adam", lr=5e-3, gender_lambda=0.1, scale_lamda=0.05)
+            outs = [tr.train_step(x, le, lg, wts if weighted else None, mask=mask, pooling=pooling) for _ in range(2)]
+            torch.cuda.synchronize()
+            res.append((tr.flat.flat.clone(), outs[-1][1].clone(), outs[-1][2].clone(), float(outs[-1][0])))
+        finally:
+            T.HAND_SCHEDULED = prev
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    assert res[0][3] == pytest.approx(res[1][3], rel=1e-6)
+
+
 def test_hand_scheduled_step_with_frozen_cloak_parameters():
     """locs / rhos without requires_grad: no data gradient is needed at all -- the emotion branch stops at its loss."""
     from sept_amd import trainer as T
