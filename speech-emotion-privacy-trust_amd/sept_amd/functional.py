@@ -125,6 +125,28 @@ def trunk_params(model, head: str, att="model"):
                            training=model.training)
 
 
+def prepare_operands(P, W_in):
+    """Build every derived operand of a network whose weights changed since the last build: conv1's operand block, the
+    bf16 conv operands in both orientations, the packed GRU input matrices (the cache entries trunk_forward /
+    trunk_backward look up).  They depend on the weights only, so a step can build them beside its feature stage instead
+    of in front of each consumer: nine 5 us launches that otherwise sit on the trainable branch's critical chain."""
+    for li, cv in enumerate(P.convs):
+        if li == 0:
+            _conv1_operand(cv)
+        else:
+            _cached("convfwd", cv.weight, lambda cv=cv: ops.conv5x5_prep_weights(cv.weight, 0))
+            _cached("convdgrad", cv.weight, lambda cv=cv: ops.conv5x5_prep_weights(cv.weight, 1))
+    w = W_in
+    for pool in P.pools:
+        w //= pool
+    C = P.convs[-1].weight.shape[0]
+    r = P.rnn
+    for layer in range(2):
+        wif, wir = getattr(r, f"weight_ih_l{layer}"), getattr(r, f"weight_ih_l{layer}_reverse")
+        bif, bir = getattr(r, f"bias_ih_l{layer}"), getattr(r, f"bias_ih_l{layer}_reverse")
+        _cached_pair(f"wih_cat{layer}", wif, wir, lambda: _gru_cat_weights(wif, wir, bif, bir, layer, C, w))
+
+
 def _drop_mask(shape, device, p=DROP_P):
     """0 / (1/(1-p)) scale mask from the device's Philox stream (one HIP launch)."""
     return ops.rng(device, "dropout").dropout_mask(shape, p)
@@ -1073,6 +1095,168 @@ def grl_train_step(model, x, labels_emo, labels_gen, weights, gender_lambda, sca
                 if p.requires_grad:
                     p.grad = g.view(p.shape)
     return loss, l1, l2
+
+
+class SegmentSched:
+    """Capture of a multi-stream step as ONE HIP GRAPH PER CHAIN, replayed on real streams.
+
+    A single captured graph leaves the placement of its parallel chains to the HIP-graph executor, which deals nodes to
+    four hardware queues by the graph's shape ((queue + 1) mod 4 per extra edge of a depth-first walk): any change of
+    the graph reshuffles which chains share an in-order queue, and two long chains on one queue serialise (measured:
+    2.3 -> 2.6-2.7 ms per step after moving nine small launches).  Here every `run(stream, fn)`
+    records fn's launches into a graph of its own (its own memory pool: concurrently replayed graphs must not recycle
+    each other's temporaries) and `wait(a, b)` becomes a real stream dependency at replay time, so the chains run on the
+    streams -- hence the hardware queues -- the code names."""
+
+    def __init__(self, device):
+        self.device = device
+        self.main = torch.cuda.Stream(device=device)
+        self.plan, self.keep = [], []
+
+    def run(self, stream, fn):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"), capture_origin():
+            r = fn()
+        self.plan.append(("launch", g, stream))
+        self.keep.append(r)       # results cross segment boundaries: they stay allocated in their segment's pool
+        return r
+
+    def wait(self, a, b):
+        self.plan.append(("wait", a, b))
+
+    def replay(self):
+        cur = torch.cuda.current_stream(self.device)
+        self.main.wait_stream(cur)
+        for op, x, y in self.plan:
+            if op == "wait":
+                x.wait_stream(y)
+            else:
+                with torch.cuda.stream(y):
+                    x.replay()
+        cur.wait_stream(self.main)
+
+
+def grl_train_step_segmented(sched, model, x, labels_emo, labels_gen, weights, gender_lambda, scale_lamda,
+                             use_scale_term=True, mask=None, pooling="mean", global_feature=None, before_cloak=None,
+                             tail=None):
+    """grl_train_step recorded through a SegmentSched: the same kernels in the same per-stream order, as six graphs
+    (draws + weight-only operand builds | features + cloak | two forward chains | two loss + backward chains | cloak
+    backward + `tail`, e.g. gradient placement and the optimiser).  Capture only -- nothing executes here."""
+    noise, emo, gen = model.intermed, model.original_model, model.gender_model
+    att = emo.att
+    pool = "flatten" if pooling is None else "mean"
+    locs, rhos = noise.locs, noise.rhos
+    dev = rhos.device
+    cur = sched.main
+    s1, s2 = branch_streams(dev)
+    P1, P2 = trunk_params(emo, 'emotion', att), trunk_params(gen, 'gender', att)
+    need_dx = locs.requires_grad or rhos.requires_grad
+    need_w1 = any(p.requires_grad for p in _param_list(P1))
+    need_w2 = any(p.requires_grad for p in _param_list(P2))
+    smin, smax, lam = float(noise.min_scale), float(noise.max_scale), float(gen.conv[0].lambda_)
+    m = None if mask is None else mask.to(dev, torch.float32).contiguous()
+    st = SimpleNamespace()
+    with torch.no_grad():
+        def draws():        # s2: the step's random numbers and its weight-only work, beside the feature stage
+            ops.rng(dev, "dropout").begin_step()
+            ops.rng(dev, "eps").begin_step()
+            st.eps = noise._epsilon(1)
+            w_in = rhos.shape[-1]
+            prepare_operands(P2, w_in)
+            prepare_operands(P1, w_in)
+
+        def features():     # main
+            ops.stamp("step start", dev)
+            st.x = before_cloak() if before_cloak is not None else x
+
+        def cloak():        # main
+            shape = st.x.shape
+            st.B = B = shape[0]
+            st.xn = ops.cloak_forward(st.x.detach().float().contiguous().view(B, -1), locs.detach(), rhos.detach(), st.eps, m,
+                                      smin, smax)
+            st.xw = st.xn.view(B, shape[-2], shape[-1])
+            st.scale_mean = None
+            if use_scale_term and float(scale_lamda) != 0.0:
+                _, st.scale_mean = ops.cloak_scales(rhos.detach(), smin, smax, want_scales=False, want_mean=True)
+            st.loss_a = torch.empty((), dtype=torch.float32, device=dev)
+            st.loss_b = torch.empty((), dtype=torch.float32, device=dev)
+            ops.stamp("cloak forward done")
+
+        def fwd(P, tag):
+            def body():
+                ops.stamp(tag + " forward starts")
+                r = trunk_forward(st.xw, P, pool, need_grad=True, gfeat=global_feature)
+                ops.stamp(tag + " forward done")
+                return r
+            return body
+
+        def bwd(P, tag, saved, labels, coef, slot_name, need_w, with_scale):
+            def body():
+                logits, S = saved()
+                slot = getattr(st, slot_name)
+                ops.stamp(tag + " backward starts")
+                d = ops.cross_entropy(logits, labels, weights, coef / st.B, slot)
+                if with_scale and st.scale_mean is not None:
+                    ops.loss_sub_log(slot, st.scale_mean, float(scale_lamda))
+                prev = _DEFERRED["on"]
+                _DEFERRED["on"] = WGRAD_STREAM      # small weight gradients fork inside this segment ...
+                try:
+                    r = trunk_backward(S, P, d, need_wgrad=need_w, need_dx=need_dx) if (need_w or need_dx) else (None, {})
+                finally:
+                    _DEFERRED["on"] = prev
+                here = torch.cuda.current_stream(dev)
+                for wg, _keep in _DEFERRED["pending"]:
+                    here.wait_stream(wg)            # ... and rejoin its capture stream before it ends
+                _DEFERRED["pending"].clear()
+                ops.stamp(tag + " backward done")
+                return (logits,) + r
+            return body
+
+        def last():         # main
+            (l1, dx1, g1), (l2, dx2, g2) = st.r1, st.r2
+            if need_dx:
+                dlocs, drhos = ops.cloak_backward(dx1.view(st.B, -1), dx2.view(st.B, -1), -lam, rhos.detach(), st.eps, m, smin,
+                                                  smax, scale_lambda=float(scale_lamda) if st.scale_mean is not None else 0.0,
+                                                  scale_mean=st.scale_mean, need_locs=locs.requires_grad,
+                                                  need_rhos=rhos.requires_grad,
+                                                  out_locs=grad_out(locs) if locs.requires_grad else None,
+                                                  out_rhos=grad_out(rhos) if rhos.requires_grad else None)
+                if locs.requires_grad:
+                    locs.grad = dlocs
+                if rhos.requires_grad:
+                    rhos.grad = drhos
+            st.loss = ops.add(st.loss_a, st.loss_b)
+            ops.stamp("gradients done")
+            for grads in (g1, g2):
+                for p, g in grads.items():
+                    if p.requires_grad:
+                        p.grad = g.view(p.shape)
+            if tail is not None:
+                tail()
+
+        sched.wait(s2, cur)
+        sched.run(s2, draws)
+        if before_cloak is not None:
+            sched.run(cur, features)
+        else:
+            st.x = x
+        sched.wait(cur, s2)
+        sched.run(cur, cloak)
+        sched.wait(s1, cur)
+        sched.wait(s2, cur)
+        st.f2 = sched.run(s2, fwd(P2, "gender"))
+        st.f1 = sched.run(s1, fwd(P1, "emotion"))
+        if not DECOUPLED_BRANCHES:      # the branches meet after their forward passes (the schedule measured faster)
+            sched.wait(cur, s1)
+            sched.wait(cur, s2)
+            sched.wait(s1, cur)
+            sched.wait(s2, cur)
+        st.r2 = sched.run(s2, bwd(P2, "gender", lambda: st.f2, labels_gen, float(gender_lambda), "loss_b", need_w2, False))
+        st.r1 = sched.run(s1, bwd(P1, "emotion", lambda: st.f1, labels_emo, 1.0, "loss_a", need_w1, True))
+        sched.wait(cur, s1)
+        sched.wait(cur, s2)
+        sched.run(cur, last)
+    return st.loss, st.r1[0], st.r2[0]
 
 
 class ScalesFn(torch.autograd.Function):

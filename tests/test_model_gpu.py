@@ -971,6 +971,34 @@ def test_hand_scheduled_step_covers_the_wrapper_options(att, pooling, weighted, 
     assert res[0][3] == pytest.approx(res[1][3], rel=1e-6)
 
 
+def test_segmented_capture_equals_eager():
+    """SEPT_SEGMENTED=1 (functional.SegmentSched): the step captured as one HIP graph per chain and replayed on real
+    streams -- an alternative to the single captured graph whose chains the graph executor places -- gives the same
+    parameters as eager steps, bit for bit, under a learning-rate schedule."""
+    from sept_amd import trainer as T
+    F = 80
+    x = closed_form_input(B, W, F).cuda()
+    le, lg, wts = (t.cuda() for t in closed_form_labels(B))
+    res = []
+    for seg in (False, True):
+        prev, T.SEGMENTED = T.SEGMENTED, seg
+        try:
+            grl = build_grl(F).train()
+            zero_dropout(grl)
+            tr = T.GrlTrainer(grl, optimizer="sgd", lr=0.02, gender_lambda=0.1, scale_lamda=0.05)
+            sched = torch.optim.lr_scheduler.StepLR(tr.optimizer, step_size=1, gamma=0.5)
+            tr.train_step(x, le, lg, wts)
+            step = tr.capture(x, le, lg, wts) if seg else (lambda: tr.train_step(x, le, lg, wts))
+            for _ in range(3):
+                sched.step()
+                step()
+            torch.cuda.synchronize()
+            res.append(tr.flat.flat.clone())
+        finally:
+            T.SEGMENTED = prev
+    assert torch.equal(res[0], res[1])
+
+
 def test_hand_scheduled_step_with_frozen_cloak_parameters():
     """locs / rhos without requires_grad: no data gradient is needed at all -- the emotion branch stops at its loss."""
     from sept_amd import trainer as T

@@ -1,18 +1,11 @@
 set -e
 export TMPDIR=/tmp
-O=gpurun_out/r5g
+O=gpurun_out/r5i
 mkdir -p $O
-run() { n=$1; shift
-  env "$@" python bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-ref-batch > $O/bench_$n.json 2> $O/bench_$n.err || { tail -5 $O/bench_$n.err; return 0; }
-  python - <<PY
+python -m pytest tests -m gpu -q --tb=line > $O/gpu_tests.log 2>&1 || true
+grep -E "^/root|^E |Error|passed|failed" $O/gpu_tests.log | cut -c1-300 | head -20
+python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_1.json 2> $O/bench_1.err
+python - <<PY
 import json
-d=json.load(open("$O/bench_$n.json")); print("$n", d["value"], d["ms_per_step"])
+d=json.load(open("$O/bench_1.json")); print(d["value"], d["ms_per_step"], d["roofline"]["kernel"], d["roofline"]["frac"], d["roofline"]["alone"]["frac"], d["reference_batch"]["ms_per_step"])
 PY
-}
-run q4 A=1
-run q6 DEBUG_HIP_FORCE_GRAPH_QUEUES=6
-run q8 DEBUG_HIP_FORCE_GRAPH_QUEUES=8
-run q12 DEBUG_HIP_FORCE_GRAPH_QUEUES=12
-run q16 DEBUG_HIP_FORCE_GRAPH_QUEUES=16
-run q5 DEBUG_HIP_FORCE_GRAPH_QUEUES=5
-run q3 DEBUG_HIP_FORCE_GRAPH_QUEUES=3
