@@ -64,8 +64,20 @@ __device__ __forceinline__ void wave_lds_sync() {
 // double precision, then a shuffle tree combines them -- deterministic for a given nparts.
 __device__ __forceinline__ double wave_sum_partials(const float* ws, int nparts, size_t stride, size_t idx) {
   const int lane = threadIdx.x & 63;
-  double s = 0.0;
-  for (int p = lane; p < nparts; p += 64) s += double(ws[size_t(p) * stride + idx]);
+  // four loads in flight per lane: with one accumulator and a run-time trip count every load waited for the one before
+  // it (16 dependent round trips for 1024 slabs -- the finalize kernels using this sit on the critical chain)
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int p = lane;
+  for (; p + 192 < nparts; p += 256) {
+    const float a = ws[size_t(p) * stride + idx], b = ws[size_t(p + 64) * stride + idx];
+    const float c = ws[size_t(p + 128) * stride + idx], d = ws[size_t(p + 192) * stride + idx];
+    s0 += double(a);
+    s1 += double(b);
+    s2 += double(c);
+    s3 += double(d);
+  }
+  for (; p < nparts; p += 64) s0 += double(ws[size_t(p) * stride + idx]);
+  double s = (s0 + s1) + (s2 + s3);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
   return s;
