@@ -506,6 +506,12 @@ _BWD_ORDER = int(os.environ.get("SEPT_BWD_ORDER", "0"))
 DECOUPLED_BRANCHES = os.environ.get("SEPT_DECOUPLED", "0") == "1"
 # MFMA-heavy weight gradients of a branch network on the (deferred) side stream too
 BIG_WGRAD_SIDE = os.environ.get("SEPT_WGRAD_BIG_SIDE", "0") == "1"
+# functional.grl_train_step: this many of the trainable branch's 5 x 5 weight gradients (layer 3 first) run inside the
+# FROZEN branch's chain (in front of its block 1) instead of inside their own: the trainable branch is the longer one by
+# exactly its weight gradients (measured: it finished 240 us after the frozen one), so the two backward chains then end
+# within 90 us of each other (-1.2 % step time; 2 or 3 moved: no better).  SEPT_WGRAD_TAIL=0 keeps them at home.
+TAIL_WGRADS = int(os.environ.get("SEPT_WGRAD_TAIL", "1"))
+_TAIL_WGRADS = {"list": None, "max": 0, "ran": 0, "taken": 0}
 
 # HIP-graph capture and side streams.  On ROCm 7.2 hipStreamEndCapture aborts the PROCESS (core dump, no error
 # code) when a forked stream is joined into another FORKED stream inside a capture:
@@ -597,6 +603,24 @@ class _SideQueue:
             self.keep.clear()
 
 
+def _run_tail_wgrads(device):
+    """Run the weight gradients the OTHER branch handed over (trunk_backward with _TAIL_WGRADS set), on the current stream:
+    each waits for the event that marks its operands ready."""
+    tail = _TAIL_WGRADS["list"]
+    if not tail:
+        return
+    here = torch.cuda.current_stream(device)
+    capturing = torch.cuda.is_current_stream_capturing()
+    while tail and tail[0][0] is not None:
+        ev, fn, operands = tail.pop(0)
+        here.wait_event(ev)
+        if not capturing:
+            for t in operands:
+                t.record_stream(here)
+        fn()
+        _TAIL_WGRADS["ran"] += 1
+
+
 def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq, gout):
     """The recurrent layers and the conv stack of trunk_backward, from the gradient of the last recurrent output."""
     B, T = S.B, S.T
@@ -655,6 +679,8 @@ def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq, go
         blk, cv, bn = S.blocks[li], P.convs[li], P.bns[li]
         if not blk.bn_train:
             raise SeptError("backward through an eval-mode BatchNorm is not implemented on the HIP path")
+        if li == 0 and not need_wgrad:
+            _run_tail_wgrads(dact.device)   # the other branch's deferred weight gradients, in front of this branch's block 1
         want_bn = need_wgrad and bn.weight.requires_grad
         if (li == 0 and getattr(blk, "idx", None) is not None and need_dx and not blk.sync
                 and not (need_wgrad and cv.weight.requires_grad)):
@@ -719,9 +745,22 @@ def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq, go
                 dx = ops.conv1_backward_data(dpre, cv.weight, prep=_conv1_operand(cv))
         else:
             if need_wgrad and cv.weight.requires_grad:
-                put(cv.weight, sq.big(lambda blk=blk, dpre=dpre: ops.conv5x5_backward_weight(blk.inp, dpre,
-                                                                                             out=gout(cv.weight)),
-                                      dpre, blk.inp))
+                tail = _TAIL_WGRADS["list"]
+                if tail is not None and _TAIL_WGRADS["taken"] < _TAIL_WGRADS["max"]:
+                    _TAIL_WGRADS["taken"] += 1
+                    # handed to the caller, which runs it at the END of the OTHER branch's chain (grl_train_step): the
+                    # trainable branch is the longer one by exactly its weight gradients
+                    dw = gout(cv.weight)
+                    dw = dw if dw is not None else torch.empty_like(cv.weight)
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(dpre.device))
+                    tail.append((ev, lambda blk=blk, dpre=dpre, dw=dw: ops.conv5x5_backward_weight(blk.inp, dpre, out=dw),
+                                 (dpre, blk.inp)))
+                    put(cv.weight, dw)
+                else:
+                    put(cv.weight, sq.big(lambda blk=blk, dpre=dpre: ops.conv5x5_backward_weight(blk.inp, dpre,
+                                                                                                 out=gout(cv.weight)),
+                                          dpre, blk.inp))
                 # the conv bias feeds straight into a training-mode BatchNorm, whose backward has
                 # zero channel sum by construction: d(bias) == 0 (the reference gets rounding noise)
                 ob = gout(cv.bias)
@@ -1052,10 +1091,18 @@ def grl_train_step(model, x, labels_emo, labels_gen, weights, gender_lambda, sca
                     join()
                     ops.stamp("forward joined")
                     fork()
-                    for st, (P, lab, coef, slot, nw, sc) in order:
-                        with torch.cuda.stream(st):
-                            logits, S = saved[st]
-                            res[st] = (logits,) + bwd(P, logits, S, lab, coef, slot, nw, sc)
+                    # the trainable branch first (it hands over weight gradients), the frozen branch picks them up in
+                    # front of its block 1; whatever is left runs behind the frozen branch
+                    _TAIL_WGRADS.update(list=[] if TAIL_WGRADS > 0 else None, max=TAIL_WGRADS, ran=0, taken=0)
+                    try:
+                        for st, (P, lab, coef, slot, nw, sc) in order:
+                            with torch.cuda.stream(st):
+                                logits, S = saved[st]
+                                res[st] = (logits,) + bwd(P, logits, S, lab, coef, slot, nw, sc)
+                        with torch.cuda.stream(s1):
+                            _run_tail_wgrads(dev)
+                    finally:
+                        _TAIL_WGRADS["list"] = None
                     saved.clear()
             finally:
                 _DEFERRED["on"] = prev

@@ -7,6 +7,8 @@ and the ones that do not.  Pure torch, no libsept.  Run one mode per process on 
                                                          #   / cap_n4 / cap_n5: "the monitored command dumped core")
     python tools/repro_capture_nested_join.py origin     # origin -> s1 -> wg, ORIGIN joins wg : works (cap_n1)
     python tools/repro_capture_nested_join.py multifork  # origin -> wg1, origin -> wg2        : works (cap_multifork)
+    python tools/repro_capture_nested_join.py sibling    # origin -> s1, origin -> s2, s1 waits for an event of s2,
+                                                         #   both joined at the origin           : see DESIGN.md section 8
 
 What sept_amd does about it: functional.fork_allowed() -- inside a capture a side stream is only forked when its
 join lands on the capture's origin stream (published by capture_origin() in the trainers' capture()); any other
@@ -38,6 +40,22 @@ def main(mode):
                 origin.wait_stream(wg)        # the same fork, joined at the origin: fine
             origin.wait_stream(s1)
             out = c + d
+        elif mode == "sibling":
+            s1.wait_stream(origin)
+            wg.wait_stream(origin)
+            with torch.cuda.stream(wg):
+                c = a + 1
+                ev = torch.cuda.Event()
+                ev.record(wg)
+                c2 = c * 3
+            with torch.cuda.stream(s1):
+                d = a - 1
+                s1.wait_event(ev)             # a forked stream waits for a point of its SIBLING's chain
+                e = c + d
+            origin.wait_stream(wg)
+            origin.wait_stream(s1)
+            out = e + c2
+            c = d = out
         else:
             wg.wait_stream(origin)
             wg2.wait_stream(origin)
