@@ -277,6 +277,28 @@ __global__ void window_norm_kernel(const float* mel, const float* mean, const fl
   }
 }
 
+// window_norm_kernel and cloak_fwd_kernel in one pass (same arithmetic, same order): the windows of the training step
+// are only ever read by the cloak, so the 14 MB tensor between them and one launch on the step's serial preamble go away
+__global__ void window_cloak_kernel(const float* mel, const float* mean, const float* stdv, const float* locs,
+                                    const float* rhos, const float* eps, const float* mask, float smin, float smax, float* xn,
+                                    int B, int T, int F, int win, int shift, int nwin) {
+  const long total = long(B) * nwin * win * F;
+  const long n_per = long(win) * F;
+  GRID_STRIDE(i, total) {
+    const int f = i % F;
+    const int t = (i / F) % win;
+    const long bw = i / n_per;
+    const int wi = bw % nwin;
+    const long b = bw / nwin;
+    const int src_t = wi * shift + t;
+    float v = src_t < T ? mel[(b * T + src_t) * F + f] : 0.f;
+    if (mean) v = (v - mean[f]) / (stdv[f] + 1e-5f);
+    const long k = i % n_per;
+    const float m = mask ? mask[k] : 1.0f;
+    xn[i] = v * m + locs[k] + cloak_scale(rhos[k], smin, smax) * (eps[k] * m);
+  }
+}
+
 // ---------------- one_d_cnn_lstm pieces (baseline_models.py:47-62) ----------------
 // Conv1d(k=5, pad=2) over time on channels-last data is a product with the unfolded input:
 // col[b][t][k*C + c] = x[b][t + k - 2][c] (zero outside [0, T)); the product itself is sept_gemm.
@@ -802,6 +824,18 @@ extern "C" int sept_cloak_forward(const float* x, const float* locs, const float
   hipLaunchKernelGGL(cloak_fwd_kernel, dim3(blocks_for(total)), dim3(kThreads), 0, ST(stream), x, locs, rhos, eps,
                      0L, mask, min_scale, max_scale, xn, n_per, total);
   return sept::launch_check("cloak_fwd_kernel");
+}
+
+extern "C" int sept_window_norm_cloak(const float* mel, const float* mean, const float* stdv, const float* locs,
+                                      const float* rhos, const float* eps, const float* mask, float min_scale, float max_scale,
+                                      float* xn, int B, int T, int F, int win, int shift, int nwin, void* stream) {
+  SEPT_REQUIRE(B >= 0 && T > 0 && F > 0 && win > 0 && shift > 0 && nwin > 0, SEPT_ERR_INVALID, "sept_window_norm_cloak: bad shape");
+  if (B == 0) return SEPT_OK;
+  SEPT_REQUIRE(mel && locs && rhos && eps && xn && (!mean == !stdv), SEPT_ERR_INVALID, "sept_window_norm_cloak: null argument");
+  const long total = long(B) * nwin * win * F;
+  hipLaunchKernelGGL(window_cloak_kernel, dim3(blocks_for(total)), dim3(kThreads), 0, ST(stream), mel, mean, stdv, locs, rhos,
+                     eps, mask, min_scale, max_scale, xn, B, T, F, win, shift, nwin);
+  return sept::launch_check("window_cloak_kernel");
 }
 
 extern "C" int sept_cloak_forward_rows(const float* x, const float* locs, const float* rhos, const float* eps,

@@ -1026,7 +1026,10 @@ def grl_train_step(model, x, labels_emo, labels_gen, weights, gender_lambda, sca
         B = shape[0]
         m = None if mask is None else mask.to(dev, torch.float32).contiguous()
         smin, smax, lam = float(noise.min_scale), float(noise.max_scale), float(gen.conv[0].lambda_)
-        xn = ops.cloak_forward(x.detach().float().contiguous().view(B, -1), locs.detach(), rhos.detach(), eps, m, smin, smax)
+        if isinstance(x, ops.LazyWindows):   # the feature stage's windows are formed inside the cloak kernel
+            xn = ops.window_norm_cloak(x, locs.detach(), rhos.detach(), eps, m, smin, smax)
+        else:
+            xn = ops.cloak_forward(x.detach().float().contiguous().view(B, -1), locs.detach(), rhos.detach(), eps, m, smin, smax)
         xw = xn.view(B, shape[-2], shape[-1])
         ops.stamp("cloak forward done")
         need_dx = locs.requires_grad or rhos.requires_grad
@@ -1219,8 +1222,11 @@ def grl_train_step_segmented(sched, model, x, labels_emo, labels_gen, weights, g
         def cloak():        # main
             shape = st.x.shape
             st.B = B = shape[0]
-            st.xn = ops.cloak_forward(st.x.detach().float().contiguous().view(B, -1), locs.detach(), rhos.detach(), st.eps, m,
-                                      smin, smax)
+            if isinstance(st.x, ops.LazyWindows):
+                st.xn = ops.window_norm_cloak(st.x, locs.detach(), rhos.detach(), st.eps, m, smin, smax)
+            else:
+                st.xn = ops.cloak_forward(st.x.detach().float().contiguous().view(B, -1), locs.detach(), rhos.detach(), st.eps,
+                                          m, smin, smax)
             st.xw = st.xn.view(B, shape[-2], shape[-1])
             st.scale_mean = None
             if use_scale_term and float(scale_lamda) != 0.0:

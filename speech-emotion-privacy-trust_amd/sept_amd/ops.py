@@ -847,6 +847,34 @@ def window_norm(mel_btf, mean=None, std=None, win=200, shift=50):
     return out
 
 
+class LazyWindows:
+    """The normalised windows of a mel batch that have not been written yet: the cloak consumes them in the same
+    kernel that forms them (window_norm_cloak); materialise() gives the plain tensor to any other consumer."""
+
+    def __init__(self, mel_btf, mean, std, win, shift):
+        self.mel, self.mean, self.std, self.win, self.shift = mel_btf, mean, std, win, shift
+        B, T, F = mel_btf.shape
+        self.nwin = 1 if T < win else (T - win) // shift + 1
+        self.shape = (B * self.nwin, 1, win, F)
+        self.device = mel_btf.device
+
+    def materialise(self):
+        return window_norm(self.mel, self.mean, self.std, self.win, self.shift).view(self.shape)
+
+
+def window_norm_cloak(lw, locs, rhos, eps, mask, min_scale, max_scale):
+    """LazyWindows -> cloaked windows (B * nwin, win * F): window_norm + cloak_forward in one kernel."""
+    require_cuda(lw.mel, locs, rhos, eps)
+    B, T, F = lw.mel.shape
+    xn = torch.empty((B * lw.nwin, lw.win * F), dtype=torch.float32, device=lw.device)
+    if eps.numel() != lw.win * F:
+        raise SeptError("window_norm_cloak takes one epsilon for the whole batch")
+    check(lib.sept_window_norm_cloak(lw.mel.data_ptr(), _p(lw.mean), _p(lw.std), locs.data_ptr(), rhos.data_ptr(), eps.data_ptr(),
+                                     _p(mask), float(min_scale), float(max_scale), xn.data_ptr(), B, T, F, lw.win, lw.shift,
+                                     lw.nwin, _s(lw.mel)), "sept_window_norm_cloak")
+    return xn
+
+
 def softmax_mean(logits, nwin):
     """logits (B*nwin, C) -> (mean softmax probabilities (B, C), argmax (B,) int64)."""
     require_cuda(logits)

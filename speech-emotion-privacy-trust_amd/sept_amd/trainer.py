@@ -320,6 +320,8 @@ class GrlTrainer(_TrainerBase):
             return loss, preds, preds_grl
         if callable(features):
             features = features()
+        if isinstance(features, ops.LazyWindows):
+            features = features.materialise()
         _advance_rng(features.device)
         preds, preds_grl, _ = self.model(features, global_feature=global_feature, mask=mask, grl=False, pooling=pooling)
         loss = self.loss(preds, preds_grl, labels_emo, labels_gen, weights, training=True)
@@ -469,8 +471,9 @@ class FusedPipeline:
         return self.trainer.train_step(lambda: self._batch(wav), labels_emo_w, labels_gen_w, weights_w)
 
     def _batch(self, wav):
-        x = self.features(wav)
-        return x.view(x.shape[0], 1, self.win, self.n_mels)
+        """The step's input: the windows of the mel batch, left unformed (ops.LazyWindows) -- the hand-scheduled step
+        forms them inside its cloak kernel; every other consumer materialises them."""
+        return ops.LazyWindows(self.plan.forward(wav, LAYOUT_BTF), self.mean, self.std, self.win, self.shift)
 
     def capture(self, wav, labels_emo_w, labels_gen_w, weights_w=None):
         """Record features + forward + loss + backward (+ the optimiser update on a single rank) of ONE step into a

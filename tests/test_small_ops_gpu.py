@@ -394,3 +394,26 @@ def test_lstm_layer_forward_backward(B, T, H):
     ops.gemm_raw(dg2, 2 * G, 1, P["weight_ih_l0"], K, 1, dx, K, B * T, K, G)
     ops.gemm_raw(dg2[:, G:], 2 * G, 1, P["weight_ih_l0_reverse"], K, 1, dx, K, B * T, K, G, beta=1.0)
     assert torch.allclose(dx.cpu().view(B, T, K), x.grad, rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("T, masked, normed", [(501, False, True), (501, True, True), (120, True, False)])
+def test_windows_formed_inside_the_cloak_kernel(T, masked, normed):
+    """sept_window_norm_cloak (the fused pipeline's step input: preprocess_adversary_data.py:30-35,131 windows +
+    cloak_models.py:45-58 noise in one pass) is bit-identical to sept_window_norm followed by sept_cloak_forward,
+    short (zero-padded) clips included."""
+    from sept_amd import ops
+    g = torch.Generator().manual_seed(T)
+    B, F, win, shift = 3, 80, 200, 50
+    mel = torch.randn(B, T, F, generator=g).cuda()
+    mean = torch.randn(F, generator=g).cuda() if normed else None
+    std = (torch.rand(F, generator=g) + 0.5).cuda() if normed else None
+    locs = (0.1 * torch.randn(1, win, F, generator=g)).cuda()
+    rhos = torch.randn(1, win, F, generator=g).cuda()
+    eps = (0.1 * torch.randn(1, win, F, generator=g)).cuda()
+    mask = (torch.rand(1, win, F, generator=g) > 0.3).float().cuda() if masked else None
+    lw = ops.LazyWindows(mel, mean, std, win, shift)
+    got = ops.window_norm_cloak(lw, locs, rhos, eps, mask, 0.01, 10.0)
+    x = ops.window_norm(mel, mean, std, win, shift)
+    want = ops.cloak_forward(x.view(x.shape[0], -1), locs, rhos, eps, mask, 0.01, 10.0)
+    assert lw.shape == (x.shape[0], 1, win, F) and torch.equal(lw.materialise().view_as(x), x)
+    assert torch.equal(got, want)
