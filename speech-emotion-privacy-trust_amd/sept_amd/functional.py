@@ -181,7 +181,25 @@ def _drop_masks(device, specs):
     return out
 
 
-def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None, gfeat=None):
+def step_masks(P, B, H, device, inj=None):
+    """Every dropout mask one training-mode forward of network P needs at batch B and input height H, drawn up front in
+    one launch per distinct p (keys: ('c', layer), 'rnn', 'dense'); entries covered by `inj` (explicit test masks) are left
+    out.  trunk_forward draws them itself unless they are handed in (grl_train_step draws both networks' masks on its
+    random-number chain, beside the feature stage)."""
+    inj = inj or {}
+    t_out = H
+    for pool in P.pools:
+        t_out //= pool
+    specs = [(("c", li), (B, cv.weight.shape[0]), P.drop_ps[li]) for li, cv in enumerate(P.convs)
+             if "drop2d" not in inj]
+    if "rnn" not in inj:
+        specs.append(("rnn", (B, t_out, 2 * P.rnn.hidden_size), P.rnn.dropout))
+    if "dense" not in inj:
+        specs.append(("dense", (B, P.dense1.weight.shape[0]), P.dense_p))
+    return _drop_masks(device, specs)
+
+
+def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None, gfeat=None, masks=None):
     """x (B, H, W) fp32 CUDA -> logits (B, C).  Returns (logits, saved) where `saved` holds
     what trunk_backward needs.  BatchNorm uses batch statistics (and updates the running
     buffers) when the module is in train mode -- also for a frozen model (SURVEY.md F8);
@@ -195,18 +213,8 @@ def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None, gfeat=Non
     S = SimpleNamespace(x=x, blocks=[], train=train, pooling=pooling, B=B)
     act = None
     h, w = H, W
-    masks = {}
-    if train:   # every mask the step needs, drawn up front (injected ones take precedence below)
-        t_out = H
-        for pool in P.pools:
-            t_out //= pool
-        specs = [(("c", li), (B, cv.weight.shape[0]), P.drop_ps[li]) for li, cv in enumerate(P.convs)
-                 if "drop2d" not in inj]
-        if "rnn" not in inj:
-            specs.append(("rnn", (B, t_out, 2 * P.rnn.hidden_size), P.rnn.dropout))
-        if "dense" not in inj:
-            specs.append(("dense", (B, P.dense1.weight.shape[0]), P.dense_p))
-        masks = _drop_masks(dev, specs)
+    if masks is None:   # every mask the step needs, drawn up front (injected ones take precedence below)
+        masks = step_masks(P, B, H, dev, inj) if train else {}
     for li, (cv, bn, pool) in enumerate(zip(P.convs, P.bns, P.pools)):
         cout = cv.weight.shape[0]
         if li == 0 and pool == 2 and not _SYNC_BN["on"] and ops.conv1_fused_supported(H, W) and \
@@ -511,9 +519,12 @@ BIG_WGRAD_SIDE = os.environ.get("SEPT_WGRAD_BIG_SIDE", "0") == "1"
 # exactly its weight gradients (measured: it finished 240 us after the frozen one), so the two backward chains then end
 # within 90 us of each other (-1.2 % step time; 2 or 3 moved: no better).  SEPT_WGRAD_TAIL=0 keeps them at home.
 TAIL_WGRADS = int(os.environ.get("SEPT_WGRAD_TAIL", "1"))
-# functional.grl_train_step: the trainable network's weight-only operand builds (nine 5 us launches) on the random-number
-# chain beside the feature stage instead of in front of their consumers (-0.4 % step time; SEPT_HOIST_OPERANDS=0: in place)
-HOIST_OPERANDS = os.environ.get("SEPT_HOIST_OPERANDS", "1") != "0"
+# functional.grl_train_step experiments: the trainable network's weight-only operand builds / both
+# networks' dropout masks on the random-number chain beside the feature stage instead of in front of their consumers.
+# Each takes launches off a critical chain, and each measured SLOWER (2.32 / 2.28 against 2.265 ms per step in one call):
+# they lengthen the chain the cloak waits for and change the captured graph's shape.  Off.
+HOIST_OPERANDS = os.environ.get("SEPT_HOIST_OPERANDS", "0") == "1"
+HOIST_MASKS = os.environ.get("SEPT_HOIST_MASKS", "0") == "1"
 _TAIL_WGRADS = {"list": None, "max": 0, "ran": 0, "taken": 0}
 
 # HIP-graph capture and side streams.  On ROCm 7.2 hipStreamEndCapture aborts the PROCESS (core dump, no error
@@ -1013,16 +1024,26 @@ def grl_train_step(model, x, labels_emo, labels_gen, weights, gender_lambda, sca
             ops.rng(dev, "dropout").begin_step()
             ops.rng(dev, "eps").begin_step()
             return noise._epsilon(1)
+        masks1 = masks2 = None
         if two and before_cloak is not None:
-            s2.wait_stream(cur)
+            s2.wait_stream(cur)             # recorded BEFORE the feature stage is enqueued: s2 runs beside it
+            x = before_cloak()
             with torch.cuda.stream(s2):
                 eps = draws()
-                if HOIST_OPERANDS:   # the trainable network's weight-only operand builds, beside the feature stage
-                    prepare_operands(trunk_params(gen, 'gender', att), rhos.shape[-1])
-            x = before_cloak()
+                Pe, Pg = trunk_params(emo, 'emotion', att), trunk_params(gen, 'gender', att)
+                if HOIST_MASKS:      # both networks' dropout masks (in the module's order: emotion, gender)
+                    if Pe.training:
+                        masks1 = step_masks(Pe, x.shape[0], x.shape[-2], dev)
+                    if Pg.training:
+                        masks2 = step_masks(Pg, x.shape[0], x.shape[-2], dev)
+                if HOIST_OPERANDS:   # the trainable network's weight-only operand builds
+                    prepare_operands(Pg, rhos.shape[-1])
             cur.wait_stream(s2)
             if not capturing:
                 eps.record_stream(cur)
+                for mk, st_ in ((masks1, s1), (masks2, s2)):
+                    for t in (mk or {}).values():
+                        t.record_stream(st_)
         else:
             eps = draws()
             if before_cloak is not None:
@@ -1050,7 +1071,7 @@ def grl_train_step(model, x, labels_emo, labels_gen, weights, gender_lambda, sca
         def fwd(P):
             tag = "emotion" if P is P1 else "gender"
             ops.stamp(tag + " forward starts")
-            r = trunk_forward(xw, P, pool, need_grad=True, gfeat=global_feature)
+            r = trunk_forward(xw, P, pool, need_grad=True, gfeat=global_feature, masks=masks1 if P is P1 else masks2)
             ops.stamp(tag + " forward done")
             return r
 
