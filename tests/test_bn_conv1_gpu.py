@@ -278,7 +278,8 @@ def test_conv1_data_gradient_with_batchnorm_apply_folded_in(B, H, W, drop, want_
     assert float((dx - want_dx).norm() / want_dx.norm()) < 3e-3
 
 
-@pytest.mark.parametrize("B, H, W, drop", [(3, 16, 24, False), (2, 20, 80, True), (4, 8, 16, True), (2, 200, 80, False)])
+@pytest.mark.parametrize("B, H, W, drop", [(3, 16, 24, False), (2, 20, 80, True), (4, 8, 16, True), (2, 200, 80, False),
+                                         (2, 12, 128, True)])
 def test_block1_data_gradient_from_pooled_gradient_and_argmax_positions(B, H, W, drop):
     """sept_conv1_backward_data_sparse: block 1's backward pass (Dropout2d, MaxPool, ReLU, training-mode BatchNorm, conv1:
     baseline_models.py:172-176) down to the gradient of the network input WITHOUT a pre-activation-sized tensor -- the

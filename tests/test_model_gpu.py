@@ -907,15 +907,14 @@ def test_captured_step_with_optimizer_and_scheduler_equals_eager(kind):
     assert torch.equal(res[0][0], res[1][0])
 
 
-@pytest.mark.parametrize("scale_lamda, with_dropout", [(0.05, False), (0.0, False), (0.05, True)])
-def test_hand_scheduled_step_equals_the_autograd_step(scale_lamda, with_dropout):
+@pytest.mark.parametrize("scale_lamda, with_dropout, F", [(0.05, False, 80), (0.0, False, 80), (0.05, True, 80), (0.05, True, 128)])
+def test_hand_scheduled_step_equals_the_autograd_step(scale_lamda, with_dropout, F):
     """functional.grl_train_step (each branch forward -> CE -> backward as one chain on its own stream, one cloak backward
     kernel that also carries the scale-loss term) against the same step through the autograd tape (module forward,
     GrlStepLossFn, loss.backward(): training_cloak_with_grl.py:138-169): identical parameters after three updates, bit for
     bit -- with dropout active too (both draw from the same Philox sub-streams in the same order)."""
     from sept_amd import trainer as T
     from sept_amd import functional as SF
-    F = 80
     x = closed_form_input(B, W, F).cuda()
     le, lg, wts = (t.cuda() for t in closed_form_labels(B))
     res = []
