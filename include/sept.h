@@ -241,10 +241,12 @@ int sept_cloak_forward(const float* x, const float* locs, const float* rhos, con
                        float min_scale, float max_scale, float* xn, int B, long n_per, void* stream);
 /* sept_window_norm followed by sept_cloak_forward in one pass (preprocess_adversary_data.py:30-35,131 +
  * cloak_models.py:45-58 on the windows of a training step): mel (B, T, F) -> xn (B * nwin, win * F); one epsilon
- * (win * F) for the whole batch; mean / stdv (F) both NULL = no normalisation.  Bit-identical to the two calls. */
+ * (win * F) for the whole batch; mean / stdv (F) both NULL = no normalisation.  Bit-identical to the two calls.
+ * n_per = the element count of locs / rhos / eps (/ mask): the entry refuses anything but win * F (a feature plan whose
+ * window or mel count differs from the cloak's parameters would index them out of bounds). */
 int sept_window_norm_cloak(const float* mel, const float* mean, const float* stdv, const float* locs, const float* rhos,
                            const float* eps, const float* mask, float min_scale, float max_scale, float* xn, int B, int T,
-                           int F, int win, int shift, int nwin, void* stream);
+                           int F, int win, int shift, int nwin, long n_per, void* stream);
 /* forward with eps[eps_rows][n_per], eps_rows = 1 (as sept_cloak_forward) or B: one epsilon per row -- the test()
  * loops (training_cloak_with_grl.py:72-83, adversary_cloak_evaluation.py:66-96) run ONE window per forward, so
  * cloak_noise.sample_noise draws a fresh epsilon for every window; the batched inference path keeps that. */

@@ -828,8 +828,11 @@ extern "C" int sept_cloak_forward(const float* x, const float* locs, const float
 
 extern "C" int sept_window_norm_cloak(const float* mel, const float* mean, const float* stdv, const float* locs,
                                       const float* rhos, const float* eps, const float* mask, float min_scale, float max_scale,
-                                      float* xn, int B, int T, int F, int win, int shift, int nwin, void* stream) {
+                                      float* xn, int B, int T, int F, int win, int shift, int nwin, long n_per,
+                                      void* stream) {
   SEPT_REQUIRE(B >= 0 && T > 0 && F > 0 && win > 0 && shift > 0 && nwin > 0, SEPT_ERR_INVALID, "sept_window_norm_cloak: bad shape");
+  SEPT_REQUIRE(n_per == long(win) * F, SEPT_ERR_INVALID,
+               "sept_window_norm_cloak: the cloak parameters hold %ld elements, the windows are %d x %d", n_per, win, F);
   if (B == 0) return SEPT_OK;
   SEPT_REQUIRE(mel && locs && rhos && eps && xn && (!mean == !stdv), SEPT_ERR_INVALID, "sept_window_norm_cloak: null argument");
   const long total = long(B) * nwin * win * F;

@@ -72,7 +72,7 @@ SIGNATURES = {
     "sept_fill": (c_int, [c_void_p, c_float, c_long, c_void_p]),
     "sept_mul": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
     "sept_debug_stamp": (c_int, [c_void_p, c_void_p]),
-    "sept_window_norm_cloak": (c_int, [c_void_p] * 7 + [c_float, c_float, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "sept_window_norm_cloak": (c_int, [c_void_p] * 7 + [c_float, c_float, c_void_p] + [c_int] * 6 + [c_long, c_void_p]),
     "sept_add": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
     "sept_relu_dropout_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
     "sept_relu_dropout_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p]),

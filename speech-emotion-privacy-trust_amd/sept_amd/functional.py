@@ -163,17 +163,23 @@ def set_sync_bn(enabled: bool, group=None):
     _SYNC_BN["group"] = group
 
 
-def _drop_masks(device, specs):
+# Philox call-site ids of the two networks of the GRL step: their masks must not depend on which branch the host
+# enqueues first (the hand-scheduled step enqueues the gender chain first, the autograd path the emotion one)
+SITE_EMOTION, SITE_GENDER = 1000, 2000
+
+
+def _drop_masks(device, specs, site=None):
     """All dropout scale masks of one forward in one launch per distinct p: `specs` is a list of
-    (key, shape, p); returns {key: mask} for the entries with p > 0."""
+    (key, shape, p); returns {key: mask} for the entries with p > 0.  `site`: first explicit Philox call-site id
+    (one per distinct p), None = the stream's sequential numbering."""
     out = {}
     by_p = {}
     for key, shape, p in specs:
         if p > 0:
             by_p.setdefault(float(p), []).append((key, shape))
-    for p, items in by_p.items():
+    for k, (p, items) in enumerate(by_p.items()):
         sizes = [(math.prod(shape) + 7) // 8 * 8 for _, shape in items]
-        flat = ops.rng(device, "dropout").dropout_mask((sum(sizes),), p)
+        flat = ops.rng(device, "dropout").dropout_mask((sum(sizes),), p, site=None if site is None else site + k)
         off = 0
         for (key, shape), n in zip(items, sizes):
             out[key] = flat[off:off + math.prod(shape)].view(shape)
@@ -181,7 +187,7 @@ def _drop_masks(device, specs):
     return out
 
 
-def step_masks(P, B, H, device, inj=None):
+def step_masks(P, B, H, device, inj=None, site=None):
     """Every dropout mask one training-mode forward of network P needs at batch B and input height H, drawn up front in
     one launch per distinct p (keys: ('c', layer), 'rnn', 'dense'); entries covered by `inj` (explicit test masks) are left
     out.  trunk_forward draws them itself unless they are handed in (grl_train_step draws both networks' masks on its
@@ -196,10 +202,10 @@ def step_masks(P, B, H, device, inj=None):
         specs.append(("rnn", (B, t_out, 2 * P.rnn.hidden_size), P.rnn.dropout))
     if "dense" not in inj:
         specs.append(("dense", (B, P.dense1.weight.shape[0]), P.dense_p))
-    return _drop_masks(device, specs)
+    return _drop_masks(device, specs, site)
 
 
-def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None, gfeat=None, masks=None):
+def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None, gfeat=None, masks=None, rng_site=None):
     """x (B, H, W) fp32 CUDA -> logits (B, C).  Returns (logits, saved) where `saved` holds
     what trunk_backward needs.  BatchNorm uses batch statistics (and updates the running
     buffers) when the module is in train mode -- also for a frozen model (SURVEY.md F8);
@@ -214,7 +220,7 @@ def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None, gfeat=Non
     act = None
     h, w = H, W
     if masks is None:   # every mask the step needs, drawn up front (injected ones take precedence below)
-        masks = step_masks(P, B, H, dev, inj) if train else {}
+        masks = step_masks(P, B, H, dev, inj, rng_site) if train else {}
     for li, (cv, bn, pool) in enumerate(zip(P.convs, P.bns, P.pools)):
         cout = cv.weight.shape[0]
         if li == 0 and pool == 2 and not _SYNC_BN["on"] and ops.conv1_fused_supported(H, W) and \
@@ -917,20 +923,21 @@ class GrlPairFn(torch.autograd.Function):
                 xn.record_stream(s1)
                 xn.record_stream(s2)
             with torch.cuda.stream(s1):
-                l1, S1 = trunk_forward(xw, P1, pooling, need_grad=need, gfeat=gfeat)
+                l1, S1 = trunk_forward(xw, P1, pooling, need_grad=need, gfeat=gfeat, rng_site=SITE_EMOTION)
             with torch.cuda.stream(s2):
-                l2, S2 = trunk_forward(xw, P2, pooling, need_grad=need, gfeat=gfeat)
+                l2, S2 = trunk_forward(xw, P2, pooling, need_grad=need, gfeat=gfeat, rng_site=SITE_GENDER)
             cur.wait_stream(s1)
             cur.wait_stream(s2)
             if not capturing:
                 l1.record_stream(cur)
                 l2.record_stream(cur)
         else:
-            l1, S1 = trunk_forward(xw, P1, pooling, need_grad=need, gfeat=gfeat)
-            l2, S2 = trunk_forward(xw, P2, pooling, need_grad=need, gfeat=gfeat)
+            l1, S1 = trunk_forward(xw, P1, pooling, need_grad=need, gfeat=gfeat, rng_site=SITE_EMOTION)
+            l2, S2 = trunk_forward(xw, P2, pooling, need_grad=need, gfeat=gfeat, rng_site=SITE_GENDER)
         ctx.S, ctx.P, ctx.two = (S1, S2), (P1, P2), two
         ctx.params, ctx.n1, ctx.cfg = params, n1, cfg
         ctx.cloak = (locs, rhos, eps, mask)
+        ctx.per_row = eps.numel() != rhos.numel()
         ctx.need_cloak = (locs.requires_grad, rhos.requires_grad)
         ctx.need_w = (any(p.requires_grad for p in params[:n1]), any(p.requires_grad for p in params[n1:]))
         noisy = xn.view(shape)
@@ -943,6 +950,8 @@ class GrlPairFn(torch.autograd.Function):
         locs, rhos, eps, mask = ctx.cloak
         smin, smax, lam = ctx.cfg
         need_dx = any(ctx.need_cloak)
+        if need_dx and ctx.per_row:   # as CloakFn.backward: the cloak backward kernel reads ONE epsilon for the batch
+            raise SeptError("per-window epsilon is an inference mode (test() loops); training draws one epsilon per step")
         dev = d1.device
         two = ctx.two and fork_allowed(dev)
         prev = _DEFERRED["on"]
@@ -970,6 +979,10 @@ class GrlPairFn(torch.autograd.Function):
             for wg, _keep in _DEFERRED["pending"]:
                 cur.wait_stream(wg)
             _DEFERRED["pending"].clear()
+            if not torch.cuda.is_current_stream_capturing():   # allocated on s1 / s2, consumed on cur
+                for t in (dx1, dx2):
+                    if t is not None:
+                        t.record_stream(cur)
         else:
             _DEFERRED["on"] = False
             try:
@@ -1033,9 +1046,9 @@ def grl_train_step(model, x, labels_emo, labels_gen, weights, gender_lambda, sca
                 Pe, Pg = trunk_params(emo, 'emotion', att), trunk_params(gen, 'gender', att)
                 if HOIST_MASKS:      # both networks' dropout masks (in the module's order: emotion, gender)
                     if Pe.training:
-                        masks1 = step_masks(Pe, x.shape[0], x.shape[-2], dev)
+                        masks1 = step_masks(Pe, x.shape[0], x.shape[-2], dev, site=SITE_EMOTION)
                     if Pg.training:
-                        masks2 = step_masks(Pg, x.shape[0], x.shape[-2], dev)
+                        masks2 = step_masks(Pg, x.shape[0], x.shape[-2], dev, site=SITE_GENDER)
                 if HOIST_OPERANDS:   # the trainable network's weight-only operand builds
                     prepare_operands(Pg, rhos.shape[-1])
             cur.wait_stream(s2)
@@ -1071,7 +1084,8 @@ def grl_train_step(model, x, labels_emo, labels_gen, weights, gender_lambda, sca
         def fwd(P):
             tag = "emotion" if P is P1 else "gender"
             ops.stamp(tag + " forward starts")
-            r = trunk_forward(xw, P, pool, need_grad=True, gfeat=global_feature, masks=masks1 if P is P1 else masks2)
+            r = trunk_forward(xw, P, pool, need_grad=True, gfeat=global_feature, masks=masks1 if P is P1 else masks2,
+                              rng_site=SITE_EMOTION if P is P1 else SITE_GENDER)
             ops.stamp(tag + " forward done")
             return r
 
@@ -1085,8 +1099,9 @@ def grl_train_step(model, x, labels_emo, labels_gen, weights, gender_lambda, sca
             ops.stamp(tag + " backward done")
             return r
 
-        # (network, labels, loss coefficient, loss slot, weight gradients?, carries the scale term?) in the order the
-        # module's forward visits them (its dropout draws follow that order); _BWD_ORDER 0 enqueues the gender chain first
+        # (network, labels, loss coefficient, loss slot, weight gradients?, carries the scale term?); _BWD_ORDER 0 enqueues the
+        # gender chain first -- the dropout draws of a network use its own Philox call site (SITE_EMOTION / SITE_GENDER), so
+        # the masks do not depend on the enqueue order, nor on hand-scheduled vs autograd, capture vs eager
         emo_args = (P1, labels_emo, 1.0, loss_a, need_w1, True)
         gen_args = (P2, labels_gen, float(gender_lambda), loss_b, need_w2, False)
         order = ((s1, emo_args), (s2, gen_args)) if _BWD_ORDER == 1 else ((s2, gen_args), (s1, emo_args))
@@ -1264,7 +1279,8 @@ def grl_train_step_segmented(sched, model, x, labels_emo, labels_gen, weights, g
         def fwd(P, tag):
             def body():
                 ops.stamp(tag + " forward starts")
-                r = trunk_forward(st.xw, P, pool, need_grad=True, gfeat=global_feature)
+                r = trunk_forward(st.xw, P, pool, need_grad=True, gfeat=global_feature,
+                                  rng_site=SITE_EMOTION if P is P1 else SITE_GENDER)
                 ops.stamp(tag + " forward done")
                 return r
             return body

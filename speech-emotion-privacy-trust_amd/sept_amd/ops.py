@@ -608,6 +608,9 @@ def gru_backward(dout, out, gates, whh_f, whh_r):
 def cloak_forward(x, locs, rhos, eps, mask, min_scale, max_scale):
     B = x.shape[0]
     n_per = locs.numel()
+    if x.numel() != B * n_per or rhos.numel() != n_per or (mask is not None and mask.numel() != n_per):
+        raise SeptError(f"cloak_forward: x {tuple(x.shape)} must hold B x {n_per} elements with locs / rhos / mask of {n_per} "
+                        f"(rhos {rhos.numel()}" + (f", mask {mask.numel()})" if mask is not None else ")"))
     xn = torch.empty_like(x)
     if eps.numel() != n_per:   # one epsilon per row (batched sliding-window inference)
         if eps.numel() != B * n_per:
@@ -867,11 +870,17 @@ def window_norm_cloak(lw, locs, rhos, eps, mask, min_scale, max_scale):
     require_cuda(lw.mel, locs, rhos, eps)
     B, T, F = lw.mel.shape
     xn = torch.empty((B * lw.nwin, lw.win * F), dtype=torch.float32, device=lw.device)
-    if eps.numel() != lw.win * F:
+    n_per = lw.win * F
+    if eps.numel() != n_per:
         raise SeptError("window_norm_cloak takes one epsilon for the whole batch")
+    # the kernel indexes locs / rhos / mask with k = i % (win * F): a feature plan whose window or mel count differs from
+    # the cloak's (1, win, F) parameters would read them out of bounds on the device
+    if locs.numel() != n_per or rhos.numel() != n_per or (mask is not None and mask.numel() != n_per):
+        raise SeptError(f"window_norm_cloak: windows are {lw.win} x {F} = {n_per} elements, the cloak holds locs "
+                        f"{locs.numel()}, rhos {rhos.numel()}" + (f", mask {mask.numel()}" if mask is not None else ""))
     check(lib.sept_window_norm_cloak(lw.mel.data_ptr(), _p(lw.mean), _p(lw.std), locs.data_ptr(), rhos.data_ptr(), eps.data_ptr(),
                                      _p(mask), float(min_scale), float(max_scale), xn.data_ptr(), B, T, F, lw.win, lw.shift,
-                                     lw.nwin, _s(lw.mel)), "sept_window_norm_cloak")
+                                     lw.nwin, locs.numel(), _s(lw.mel)), "sept_window_norm_cloak")
     return xn
 
 
@@ -936,10 +945,13 @@ class Rng:
         check(lib.sept_counter_add(self.counter.data_ptr(), 1, _s(self.counter)), "sept_counter_add")
         self.sub = 0
 
-    def dropout_mask(self, shape, p):
+    def dropout_mask(self, shape, p, site=None):
+        """`site`: an explicit call-site id (>= 1000) instead of the next sequential one -- draws that must not depend on
+        the order in which the host enqueues them (the two networks of the GRL step) name their site."""
         out = torch.empty(shape, dtype=torch.float32, device=self.counter.device)
+        sub = self._next() if site is None else (int(site) << 40)
         check(lib.sept_dropout_mask(out.data_ptr(), out.numel(), float(p), self.seed, self.counter.data_ptr(),
-                                    self._next(), _s(out)), "sept_dropout_mask")
+                                    sub, _s(out)), "sept_dropout_mask")
         return out
 
     def normal(self, shape, mean=0.0, std=1.0):

@@ -135,14 +135,25 @@ class SeptOptimizer(torch.optim.Optimizer):
     """The handle torch's learning-rate schedulers need (StepLR(10, 0.5) for SGD, ReduceLROnPlateau for Adam:
     training_cloak_with_grl.py:418,421): a torch.optim.Optimizer whose single param group carries `lr`; the
     trainer reads it before every step / replay and writes a changed value to the device scalar the HIP optimiser
-    kernels read.  step() runs the trainer's fused update; zero_grad() clears the flat-buffer views."""
+    kernels read.  step() is what a reference-style loop (`zero_grad(); loss.backward(); optimizer.step()`,
+    training_cloak_with_grl.py:167-169) calls after its own backward: it places every gradient in the flat buffer
+    (gather_grads: autograd hands some over as separate tensors, e.g. the cloak's rhos), all-reduces it over the process
+    group when there is one, and runs the fused update -- the three things train_step() does behind the backward pass.
+    zero_grad() clears the flat-buffer views."""
 
     def __init__(self, trainer):
         self._trainer = trainer
         super().__init__([trainer.flat.flat], {"lr": trainer.lr})
 
     def step(self, closure=None):
-        self._trainer.optimizer_step()
+        if closure is not None:
+            raise NotImplementedError("SeptOptimizer.step(closure): run the backward pass first, then step()")
+        t = self._trainer
+        t._sync_lr()
+        t.flat.gather_grads()
+        if t.world > 1:
+            t._allreduce_grads()
+        t.optimizer_step()
 
     def zero_grad(self, set_to_none=True):
         self._trainer.flat.zero_grad()
@@ -235,6 +246,8 @@ class _TrainerBase:
             ops.adam_step_dev(w, g, self._state[0], self._state[1], self.lr_dev, self.betas[0], self.betas[1],
                               self.eps, self.weight_decay, self.step_dev, gscale)
         SF.invalidate_weight_cache()  # parameters changed through raw pointers
+        # torch's schedulers warn "lr_scheduler.step() before optimizer.step()" unless the handle saw a step
+        self.optimizer._opt_called = True
 
     def _allreduce_grads(self):
         """The one exchange of a data-parallel step: sum of the active prefix of the flat gradient buffer over the
@@ -354,17 +367,18 @@ class GrlTrainer(_TrainerBase):
         self.optimizer_step()
         return out
 
-    def capture(self, features, labels_emo, labels_gen, weights=None, mask=None, pooling="mean"):
+    def capture(self, features, labels_emo, labels_gen, weights=None, mask=None, pooling="mean", global_feature=None):
         """Record ONE step over the given STATIC input tensors into a HIP graph; returns replay().  On a single
         rank the optimiser (SGD or Adam: rate and step count are device scalars) is part of the graph; with a
         process group the graph ends at the gradients, and replay() then runs the all-reduce and the update.
         Refill the inputs with copy_() between replays; call after at least one eager step.  `features` may be a
         callable producing the batch on the current stream (FusedPipeline)."""
         if SEGMENTED and HAND_SCHEDULED and self._hand_schedulable(features) and SF.CONCURRENT_BRANCHES:
-            return self._capture_segmented(features, labels_emo, labels_gen, weights, mask, pooling)
-        return self._capture(lambda: self._forward_backward(features, labels_emo, labels_gen, weights, mask, pooling))
+            return self._capture_segmented(features, labels_emo, labels_gen, weights, mask, pooling, global_feature)
+        return self._capture(lambda: self._forward_backward(features, labels_emo, labels_gen, weights, mask, pooling,
+                                                            global_feature))
 
-    def _capture_segmented(self, features, labels_emo, labels_gen, weights, mask, pooling):
+    def _capture_segmented(self, features, labels_emo, labels_gen, weights, mask, pooling, global_feature=None):
         """capture() as one graph per chain on real streams (functional.SegmentSched / grl_train_step_segmented)."""
         if self.steps < 1:
             raise RuntimeError("capture() needs at least one eager warm-up step (first-use setup, active-set discovery)")
@@ -385,7 +399,8 @@ class GrlTrainer(_TrainerBase):
         fn = features if callable(features) else None
         out = SF.grl_train_step_segmented(sched, self.model, None if fn else features, labels_emo, labels_gen, weights,
                                           self.gender_lambda, self.scale_lamda, use_scale_term=not self.suppression,
-                                          mask=mask, pooling=pooling, before_cloak=fn, tail=tail)
+                                          mask=mask, pooling=pooling, global_feature=global_feature, before_cloak=fn,
+                                          tail=tail)
         if in_graph_update:
             self.steps -= 1            # the capture enqueued nothing
         SF.invalidate_weight_cache()

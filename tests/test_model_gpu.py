@@ -5,14 +5,15 @@ oracle with the same closed-form weights.
 Tolerances: the conv stack computes on bf16 MFMA (fp32 accumulate) and keeps bf16
 activations, as BASELINE.json config 3 prescribes; the north-star criterion is "identical
 emotion/gender argmax on fixed seeds".  Two references, two bounds:
-  * the REFERENCE goldens / the fp32 oracle: logits within LOGIT_RTOL (1 %) of the largest golden
+  * the REFERENCE goldens / the fp32 oracle: logits within LOGIT_RTOL (2 %) of the largest golden
     |logit| (the closed-form weights give logits of scale 1-4 that depend on the input, see
     tests/closed_form.py), identical arg-max on every row whose reference margin exceeds 0.1 -- and at
     least 3/4 of the rows of every golden must be such rows, so the check cannot pass vacuously;
   * the oracle with the HIP path's bf16 storage points simulated (oracle.model_oracle.simulate_bf16):
     both sides then take the same max-pool decisions, so logits are held to SIM_RTOL (1 % of the largest
-    |logit|), arg-max on all decided rows, and EVERY gradient -- also those behind the conv stack -- to
-    cosine > 0.995 and 10 % of its norm (CONV_COS, CONV_REL; measured values beside them)."""
+    |logit|), arg-max on all decided rows, and EVERY gradient: those inside / behind the conv stack to
+    cosine > 0.995 and 10 % of its norm (CONV_COS, CONV_REL), those outside it to the per-group bounds of
+    _fp32_part_bounds (cosine > 0.997-0.998, 6-9 %); measured values beside the constants."""
 import os
 
 import numpy as np
@@ -157,7 +158,7 @@ def _grad_report(grl, ref):
         if name.endswith(("conv.1.0.bias", "conv.1.5.bias", "conv.1.10.bias")):
             # a conv bias in front of a train-mode BatchNorm has zero gradient up to rounding: the oracle's is fp32
             # summation noise, the HIP path's is exactly 0 (5x5 layers) or the sum of bf16-rounded gradients
-            # (conv1) -- held to 1e-3 of the same conv's weight gradient
+            # (conv1) -- both held to 5 % of the largest entry of the same conv's weight gradient
             wg = float(got[name[:-4] + "weight"].grad.abs().max())
             assert float(p.grad.abs().max()) <= 5e-2 * wg and float(g.abs().max()) <= 5e-2 * wg, \
                 (name, float(p.grad.abs().max()), float(g.abs().max()), wg)
@@ -178,7 +179,7 @@ CONV_COS, CONV_REL = 0.995, 0.10   # gradients inside / behind the bf16 conv sta
 #   cloak parameters, 9.6 % for the first BatchNorm's bias of the 4-block LSTM model -- noise orthogonal to the
 #   gradient (sqrt(2 (1 - cos)) matches), from pre-activations that round the other way and cascade.  Round 1 only
 #   asked for cosine > 0.8 here (an fp32 oracle takes different max-pool decisions); everything outside the conv stack
-#   is held to cosine > 0.999 and 3 %.
+#   is held to the tighter per-group bounds of _fp32_part_bounds.
 
 
 def _fp32_part_bounds(name):
@@ -186,9 +187,14 @@ def _fp32_part_bounds(name):
     GEMMs, fp32 recurrences), but their INPUT is the conv stack's bf16 output, so they inherit its noise: measured
     1-4 % for dense1 / the heads, 3-4.5 % for the recurrent layers, 6 % for the attention matrices, cosine
     0.9981-0.9996 -- and the figures move by a percent whenever a kernel changes its summation order upstream (a
-    pre-activation that rounds the other way is one bf16 ulp and cascades).  The fp32 kernels themselves are held to
-    1e-3-1e-5 against torch in tests/test_small_ops_gpu.py on identical inputs; here one robust bound serves all."""
-    return CONV_COS, CONV_REL
+    pre-activation that rounds the other way is one bf16 ulp and cascades), hence bounds 1.5-2 x the measurements rather
+    than at them.  The fp32 kernels themselves are held to 1e-3-1e-5 against torch in tests/test_small_ops_gpu.py on
+    identical inputs."""
+    if "att_" in name:
+        return 0.997, 0.09     # attention matrices: measured 6 %
+    if "rnn." in name:
+        return 0.998, 0.07     # second recurrent layer: measured 3-4.5 %
+    return 0.998, 0.06         # dense1 / prediction heads: measured 1-4 %
 
 
 def _sim_step_check(grl, x, le, lg, wts, state=None, F=80, logits=None, min_decided=0.75):

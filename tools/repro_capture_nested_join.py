@@ -2,7 +2,7 @@
 """DOCUMENTATION, not a test: the HIP-graph capture topology that aborts the process on ROCm 7.2 (gfx950)
 and the ones that do not.  Pure torch, no libsept.  Run one mode per process on a GPU box:
 
-    python tools/repro_capture_nested_join.py nested     # origin -> s1 -> wg, s1 joins wg    : core dump in
+    python tools/repro_capture_nested_join.py nested --i-know-this-dumps-core   # origin -> s1 -> wg, s1 joins wg    : core dump in
                                                          #   hipStreamEndCapture (round-1 logs cap_nested / cap_both
                                                          #   / cap_n4 / cap_n5: "the monitored command dumped core")
     python tools/repro_capture_nested_join.py origin     # origin -> s1 -> wg, ORIGIN joins wg : works (cap_n1)
@@ -72,4 +72,8 @@ def main(mode):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "origin")
+    mode = sys.argv[1] if len(sys.argv) > 1 else "origin"
+    if mode == "nested" and "--i-know-this-dumps-core" not in sys.argv[2:]:
+        sys.exit("the 'nested' mode aborts the process inside hipStreamEndCapture (core dump on the GPU box); "
+                 "pass --i-know-this-dumps-core to run it anyway")
+    main(mode)
