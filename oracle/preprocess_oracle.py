@@ -17,8 +17,11 @@ What the reference does (win_len W = 200, shift_len = W / 4 = 50, `--shift 1`):
   statistics (:356-367)         np.nanmean / nanstd (population, ddof 0) / nanmin / nanmax over that row list, per mel bin.
   normalisation (:371-381)      znorm: (x - mean) / (std + 1e-5);  min_max: (x - min) / (max - min) * 2 - 1.
 
-Parity status: pinned by construction only -- the reference script cannot run here (it reads pickles under a
-hard-coded root and IEMOCAP label files); this file restates its arithmetic with the reference's own numpy calls.
+Parity status: PINNED to the reference's own code.  The script as a whole cannot run here (hard-coded corpus root,
+IEMOCAP label files, pickles), but tools/make_goldens_preprocess.py executes its write_data_dict / save_data_dict
+(:20-83) and its statistics + normalisation block (:357-390), read from the reference file in the build container, on
+the synthetic clips of tests/preprocess_synth.py and records the results in tests/golden/preprocess_golden.npz;
+tests/test_oracle_preprocess.py holds this restatement to them at 1e-10 (statistics 1e-12).
 """
 import numpy as np
 

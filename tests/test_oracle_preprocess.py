@@ -1,7 +1,54 @@
-"""oracle/preprocess_oracle.py against hand-computable cases of preprocess_adversary_data.py:20-83, 356-381."""
+"""oracle/preprocess_oracle.py against (a) the vectors the REFERENCE's own code produced on synthetic clips
+(tests/golden/preprocess_golden.npz, written by tools/make_goldens_preprocess.py, which executes
+preprocess_adversary_data.py:20-83 and :357-390) and (b) hand-computable cases."""
+import os
+
 import numpy as np
 
 from oracle import preprocess_oracle as po
+from tests.preprocess_synth import CLIPS, F, WIN, synthetic_clips
+
+
+def reference_items(G, norm):
+    """{key: (split, length, checksums, edge rows)} of one normalisation mode of the golden file"""
+    return {str(k): (str(s), int(n), c, e) for k, s, n, c, e in
+            zip(G[f"{norm}_keys"], G[f"{norm}_splits"], G[f"{norm}_len"], G[f"{norm}_sums"], G[f"{norm}_edges"])}
+
+
+def oracle_items(clips, stats, norm):
+    """the oracle's stored + normalised items, keyed like the reference's dictionaries (sentence_file + '_' + i)"""
+    out = {}
+    for k, (clip, (L, spk, split)) in enumerate(zip(clips, CLIPS)):
+        for i, (_, stored) in enumerate(po.saved_items(clip, WIN, WIN // 4, split == "test")):
+            out[f"clip{k:02d}_{i}"] = (split, po.normalise(stored, stats[spk], norm))
+    return out
+
+
+def test_oracle_reproduces_the_reference_run(golden_dir):
+    """The restatement against the reference's own functions: same stored items (count, keys, lengths -- short clips
+    padded to 200 rows, test-split clips whole and once), same per-speaker statistics population, same normalised data."""
+    G = np.load(os.path.join(golden_dir, "preprocess_golden.npz"))
+    clips = synthetic_clips()
+    np.testing.assert_allclose([c.sum() for c in clips], G["clip_sums"], rtol=1e-12)       # same synthetic inputs
+    assert int(G["F"]) == F and int(G["win_len"]) == WIN
+    speakers = [c[1] for c in CLIPS]
+    test_speakers = {c[1] for c in CLIPS if c[2] == "test"}
+    stats = po.speaker_statistics(clips, speakers, test_speakers, WIN, WIN // 4)
+    assert sorted(stats) == [str(s) for s in G["stat_speakers"]]
+    for j, spk in enumerate(G["stat_speakers"]):
+        for w, which in enumerate(("mean", "std", "min", "max")):
+            np.testing.assert_allclose(stats[str(spk)][which], G["stats"][j, w], rtol=1e-12, atol=1e-12)
+    for norm in ("znorm", "min_max"):
+        want = reference_items(G, norm)
+        got = oracle_items(clips, stats, norm)
+        assert sorted(got) == sorted(want)
+        for key, (split, d) in got.items():
+            w_split, w_len, w_sums, w_edges = want[key]
+            assert split == w_split and d.shape == (w_len, F), key
+            np.testing.assert_allclose([d.sum(), np.abs(d).sum(), (d * d).sum()], w_sums, rtol=1e-10)
+            np.testing.assert_allclose(np.concatenate([d[:4], d[-4:]]), w_edges, rtol=1e-10, atol=1e-12)
+            if f"{norm}_{key}" in G.files:
+                np.testing.assert_allclose(d, G[f"{norm}_{key}"][0], rtol=1e-5, atol=1e-5)       # stored as float32
 
 
 def test_saved_items_counts_and_padding():

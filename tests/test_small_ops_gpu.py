@@ -359,6 +359,55 @@ def test_speaker_stats_follow_the_reference_population():
                 np.testing.assert_allclose(w[i], po.normalise(stored, want[spk[b]], norm), rtol=3e-4, atol=3e-4)
 
 
+def test_preprocess_kernels_reproduce_the_reference_run(golden_dir):
+    """sept_speaker_stats_windows + sept_window_norm_spk against what the REFERENCE's own write_data_dict /
+    save_data_dict / normalisation block produced on the synthetic clips of tests/preprocess_synth.py
+    (tests/golden/preprocess_golden.npz, tools/make_goldens_preprocess.py): statistics of every speaker and every stored
+    item of the train / validation / adversary splits (windows; short clips zero padded) in both normalisation modes.
+    Test-split clips are stored whole by the reference (no windows): their frames enter the statistics once each."""
+    import os
+    import numpy as np
+    from sept_amd import preprocess as pp
+    from tests.preprocess_synth import CLIPS, F, WIN, synthetic_clips
+    G = np.load(os.path.join(golden_dir, "preprocess_golden.npz"))
+    clips = synthetic_clips()
+    names = [str(s) for s in G["stat_speakers"]]
+    T = max(c[0] for c in CLIPS)
+    mel = torch.zeros(len(CLIPS), T, F)
+    for b, c in enumerate(clips):
+        mel[b, :len(c)] = torch.from_numpy(c).float()
+    spk = torch.tensor([names.index(c[1]) for c in CLIPS])
+    lens = torch.tensor([c[0] for c in CLIPS])
+    whole = torch.tensor([c[2] == "test" for c in CLIPS])
+    stats = pp.speaker_stats(mel.cuda(), spk, len(names), lengths=lens, whole_clip=whole)
+    got = stats.cpu().numpy()
+    np.testing.assert_allclose(got[:, 0], G["stats"][:, 0], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(got[:, 1], G["stats"][:, 1], rtol=1e-5)
+    np.testing.assert_allclose(got[:, 2], G["stats"][:, 2], rtol=1e-6)
+    np.testing.assert_allclose(got[:, 3], G["stats"][:, 3], rtol=1e-6)
+    st = torch.from_numpy(G["stats"].astype(np.float32)).cuda()     # the reference's own statistics from here on
+    for norm in ("znorm", "min_max"):
+        ref = {str(k): (int(n), c, e) for k, n, c, e in zip(G[f"{norm}_keys"], G[f"{norm}_len"], G[f"{norm}_sums"],
+                                                            G[f"{norm}_edges"])}
+        checked = 0
+        for b, (L, name, split) in enumerate(CLIPS):
+            if split == "test":
+                continue
+            w = pp.window_normalize(mel[b:b + 1, :L].contiguous().cuda(), st, spk[b:b + 1], norm).double().cpu().numpy()
+            n_items = sum(1 for k in ref if k.startswith(f"clip{b:02d}_"))
+            assert w.shape == (n_items, WIN, F), (b, w.shape, n_items)
+            for i in range(n_items):
+                n, sums, edges = ref[f"clip{b:02d}_{i}"]
+                assert n == WIN
+                scale = max(1.0, float(np.abs(w[i]).max()))
+                np.testing.assert_allclose(np.concatenate([w[i, :4], w[i, -4:]]), edges, rtol=2e-4, atol=2e-4 * scale)
+                assert abs(w[i].sum() - sums[0]) < 1e-4 * sums[1] + 1e-3 and abs(np.abs(w[i]).sum() - sums[1]) < 1e-4 * sums[1]
+                if f"{norm}_clip{b:02d}_{i}" in G.files:
+                    np.testing.assert_allclose(w[i], G[f"{norm}_clip{b:02d}_{i}"][0], rtol=2e-4, atol=2e-4 * scale)
+                checked += 1
+        assert checked == 27
+
+
 @pytest.mark.parametrize("B,T,H", [(7, 25, 64), (3, 2, 64), (1, 1, 64), (5, 25, 128), (2, 3, 128)])
 def test_lstm_layer_forward_backward(B, T, H):
     """One bidirectional LSTM layer (input projections by sept_gemm + sept_lstm_forward / backward) vs nn.LSTM
