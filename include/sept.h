@@ -338,6 +338,35 @@ int sept_conv1_bn_relu_pool_backward_apply(const float* x, const float* w, const
                                            const float* sums, double n_total, void* dpre, int B, int H, int W,
                                            void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Block 1 in POOL-FIRST form (round 3; baseline_models.py:172-176 forward + autograd backward, no 64-byte-per-pixel
+ * tensor in either direction).  maxpool(relu(bn(v))) over a 2x2 window = relu(bn(max v)) where gamma >= 0 and
+ * relu(bn(min v)) where gamma < 0, and the sign of gamma is known when conv1 runs, so ONE pass over the input leaves
+ *   stats [64][sept_conv1_stats_parts(B, H)]  the BatchNorm statistics partials of the (bf16-rounded) conv output of
+ *                                             every pixel (finish with sept_bn_stats_from_partials),
+ *   ext (B, H/2, W/2, 32) bf16                the window's extremum of the rounded conv output,
+ *   idx (B, H/2, W/2, 32) u8                  its window position (scan order 0..3, first one wins).
+ * sept_bn_relu_ext_forward then forms y = dropscale * relu(sc * ext + sh) (bit-identical to sept_bn_relu_pool_forward
+ * on the stored pre-activations) and re-marks idx = 4 where the ReLU is inactive (the convention of
+ * sept_bn_relu_pool_forward_argmax); px_per_item = pooled pixels per batch item (the Dropout2d scale is per item).
+ * Backward: (sum g, sum g * xhat) from (dy, ext, idx) -- xhat = (ext - mean) * invstd exactly, for any gamma -- either
+ * in the epilogue of the data-gradient conv that produces dy (sept_conv5x5_dgrad_bnsums_ext, partials finished by
+ * sept_bn_bwd_sums_from_partials) or by sept_bn_backward_sums_ext; then sept_conv1_backward_data_sparse (data gradient)
+ * and sept_conv1_backward_weight_sparse (weight gradient) work from (dy, idx, x).  H even, W % 16 == 0
+ * (sept_conv1_pool_supported); gamma NULL = all maxima. */
+int sept_conv1_pool_supported(int H, int W);
+int sept_conv1_forward_pool(const float* x, const float* w, const float* bias, float* wprep, const float* gamma,
+                            void* ext_bf16, void* idx_u8, float* stats, int B, int H, int W, void* stream);
+int sept_bn_relu_ext_forward(const void* ext, void* idx_u8 /*nullable, in/out*/, const float* mean, const float* invstd,
+                             const float* gamma, const float* beta, const float* dropscale, void* y, int B,
+                             long px_per_item, int C, void* stream);
+int sept_bn_backward_sums_ext(const void* dy, const void* ext, const void* idx_u8, const float* mean, const float* invstd,
+                              const float* dropscale, float* ws, float* sums_out, float* dgamma, float* dbeta, int B,
+                              long px_per_item, int C, void* stream);
+int sept_conv5x5_dgrad_bnsums_ext(const void* dy_out, const void* wt, void* dx_out, const void* ext, const void* idx_u8,
+                                  const float* bn_mean, const float* bn_invstd, const float* dropscale, float* partials,
+                                  int B, int H, int W, int cin, int cout, void* stream);
+
 /* y = a * x  (GradientReversalFunction.backward with a = -lambda, reversal_gradient.py:18-23) */
 int sept_scale(const float* x, float a, float* y, long n, void* stream);
 /* y[i] = value (zero gradients of conv biases in front of a train-mode BatchNorm; flat-buffer housekeeping) */

@@ -454,6 +454,79 @@ __global__ __launch_bounds__(256) void sept_bn_bwd_apply_kernel(BnBwdArgs a) {
   }
 }
 
+
+// ---- blocks whose pooling window was resolved before the BatchNorm (sept_conv1_forward_pool) ------------------------
+// ext [n_px][C] bf16 = the window's extremum of the conv output (maximum where gamma >= 0, minimum where gamma < 0),
+// idx [n_px][C] u8 = its position in the window.  Forward: y = dropscale * relu(sc * ext + sh), the same arithmetic
+// sept_bn_relu_pool_fwd_kernel applies to the winning element (bn is monotone per channel, so the window maximum of the
+// activations is the activation of the extremum: bit-identical); positions whose ReLU is inactive are re-marked P * P = 4
+// ("no gradient"), the convention sept_bn_relu_pool_forward_argmax established for the consumers of idx.
+struct BnExtArgs {
+  const bf16* ext;
+  unsigned char* idx;       // in / out (nullable in the forward pass)
+  const bf16* dy;           // backward: gradient of the pooled activation
+  const float *mean, *invstd, *gamma, *beta, *drop;
+  bf16* y;
+  float* ws;                // backward: transposed partials [2C][blocks]
+  long n_px, per_b;         // pooled pixels in all, per batch item
+};
+
+template <int CPP>
+__global__ __launch_bounds__(256) void sept_bn_relu_ext_fwd_kernel(BnExtArgs a) {
+  constexpr int C = CPP * 8;
+  const long n_items = a.n_px * CPP;
+  const int chunk = threadIdx.x % CPP;
+  const f32x8 mu = loadf8(a.mean + chunk * 8), is = loadf8(a.invstd + chunk * 8);
+  const f32x8 ga = loadf8(a.gamma + chunk * 8), be = loadf8(a.beta + chunk * 8);
+  const f32x8 sc = ga * is, sh = be - mu * ga * is;
+  for (long i = long(blockIdx.x) * 256 + threadIdx.x; i < n_items; i += long(gridDim.x) * 256) {
+    const long px = i / CPP;
+    const f32x8 v = load8(a.ext + px * C + chunk * 8) * sc + sh;
+    f32x8 m;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = fmaxf(v[e], 0.f);
+    if (a.idx) {
+      uint2* ip = reinterpret_cast<uint2*>(a.idx + px * C + chunk * 8);
+      uint2 pk = *ip;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        unsigned& wd = e < 4 ? pk.x : pk.y;
+        if (!(v[e] > 0.f)) wd = (wd & ~(0xFFu << (8 * (e & 3)))) | (4u << (8 * (e & 3)));
+      }
+      *ip = pk;
+    }
+    if (a.drop) m *= loadf8(a.drop + (px / a.per_b) * C + chunk * 8);
+    store8(a.y + px * C + chunk * 8, m);
+  }
+}
+
+// backward sums of such a block from the pooled tensors alone: ge = dy * dropscale where idx != 4, xhat = (ext - mean) *
+// invstd EXACTLY (the extremum is the pre-activation the gradient lands on: no division by gamma, no tiny-|gamma| path)
+template <int CPP>
+__global__ __launch_bounds__(256) void sept_bn_bwd_reduce_ext_kernel(BnExtArgs a) {
+  constexpr int C = CPP * 8;
+  __shared__ float lds[256 * 16];
+  const long n_items = a.n_px * CPP;
+  const int chunk = threadIdx.x % CPP;
+  const f32x8 mu = loadf8(a.mean + chunk * 8), is = loadf8(a.invstd + chunk * 8);
+  f32x8 s1 = {0, 0, 0, 0, 0, 0, 0, 0}, s2 = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (long i = long(blockIdx.x) * 256 + threadIdx.x; i < n_items; i += long(gridDim.x) * 256) {
+    const long px = i / CPP;
+    f32x8 g = load8(a.dy + px * C + chunk * 8);
+    const f32x8 xh = (load8(a.ext + px * C + chunk * 8) - mu) * is;
+    const uint2 pk = *reinterpret_cast<const uint2*>(a.idx + px * C + chunk * 8);
+    if (a.drop) g *= loadf8(a.drop + (px / a.per_b) * C + chunk * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const unsigned k = ((e < 4 ? pk.x : pk.y) >> (8 * (e & 3))) & 0xFFu;
+      const float ge = k < 4u ? g[e] : 0.f;
+      s1[e] += ge;
+      s2[e] += ge * xh[e];
+    }
+  }
+  block_reduce_2c<CPP>(s1, s2, a.ws, gridDim.x, lds);
+}
+
 int grid_for(long items, int cap = kParts) { return int(std::min<long>((items + 255) / 256, cap)); }
 
 }  // namespace
@@ -704,4 +777,37 @@ extern "C" int sept_bn_relu_pool_backward_apply(const void* dy, const void* x, c
               nullptr, static_cast<bf16*>(dx), B, H, W, C, pool, sums, float(1.0 / n_total)};
   if (int e = bn_bwd_launch_apply(a, static_cast<hipStream_t>(stream))) return e;
   return sept::launch_check("sept_bn_relu_pool_backward_apply");
+}
+
+// ---- pool-first blocks (sept_conv1_forward_pool): forward activation pass and backward channel sums ----
+extern "C" int sept_bn_relu_ext_forward(const void* ext, void* idx_u8, const float* mean, const float* invstd,
+                                        const float* gamma, const float* beta, const float* dropscale, void* y, int B,
+                                        long px_per_item, int C, void* stream) {
+  SEPT_REQUIRE(B >= 0 && px_per_item > 0, SEPT_ERR_INVALID, "sept_bn_relu_ext_forward: B=%d px=%ld", B, px_per_item);
+  if (B == 0) return SEPT_OK;
+  SEPT_REQUIRE(ext && mean && invstd && gamma && beta && y, SEPT_ERR_INVALID, "sept_bn_relu_ext_forward: null argument");
+  BnExtArgs a{static_cast<const bf16*>(ext), static_cast<unsigned char*>(idx_u8), nullptr, mean, invstd, gamma, beta, dropscale,
+              static_cast<bf16*>(y), nullptr, long(B) * px_per_item, px_per_item};
+  const long items = a.n_px * (C / 8);
+  const int grid = int(std::min<long>((items + 255) / 256, 4096));
+  SEPT_CPP_DISPATCH(C, hipLaunchKernelGGL(sept_bn_relu_ext_fwd_kernel<CPP>, dim3(grid), dim3(256), 0,
+                                          static_cast<hipStream_t>(stream), a));
+  return sept::launch_check("sept_bn_relu_ext_fwd_kernel");
+}
+
+// sums_out[2C] = (sum g, sum g * xhat) (+ dgamma / dbeta) from (dy, ext, idx): the reduce pass for callers whose
+// producer did not leave partials (sept_conv5x5_dgrad_bnsums_ext does).  ws: sept_bn_workspace_floats(C) floats.
+extern "C" int sept_bn_backward_sums_ext(const void* dy, const void* ext, const void* idx_u8, const float* mean,
+                                         const float* invstd, const float* dropscale, float* ws, float* sums_out,
+                                         float* dgamma, float* dbeta, int B, long px_per_item, int C, void* stream) {
+  SEPT_REQUIRE(B > 0 && px_per_item > 0, SEPT_ERR_INVALID, "sept_bn_backward_sums_ext: B=%d px=%ld", B, px_per_item);
+  SEPT_REQUIRE(dy && ext && idx_u8 && mean && invstd && ws && sums_out, SEPT_ERR_INVALID, "sept_bn_backward_sums_ext: null argument");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  BnExtArgs a{static_cast<const bf16*>(ext), const_cast<unsigned char*>(static_cast<const unsigned char*>(idx_u8)),
+              static_cast<const bf16*>(dy), mean, invstd, nullptr, nullptr, dropscale, nullptr, ws, long(B) * px_per_item,
+              px_per_item};
+  const int grid = grid_for(a.n_px * (C / 8));
+  SEPT_CPP_DISPATCH(C, hipLaunchKernelGGL(sept_bn_bwd_reduce_ext_kernel<CPP>, dim3(grid), dim3(256), 0, st, a));
+  hipLaunchKernelGGL(sept_bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, ws, grid, C, dgamma, dbeta, sums_out, false);
+  return sept::launch_check("sept_bn_backward_sums_ext");
 }

@@ -51,6 +51,11 @@ struct ConvArgs {
   // exactly as sept_bn_bwd_reduce_pooled_kernel forms them (xhat = (y / drop - beta) / gamma where y > 0).
   const bf16* ypool;
   const float *bn_gamma, *bn_beta, *drop;
+  // ... or, for a block whose pooling window was resolved before its BatchNorm (sept_conv1_forward_pool): ypool = ext
+  // (the window's extremum of the pre-activation), bn_idx = its position bytes (4 = ReLU inactive), bn_mean / bn_invstd:
+  // xhat = (ext - mean) * invstd exactly, ge = g * drop where idx != 4 (no division by gamma)
+  const unsigned char* bn_idx;
+  const float *bn_mean, *bn_invstd;
 };
 
 __host__ __device__ constexpr int conv_nr_max(int mt, int w) { return (mt + w - 2) / w + 5; }
@@ -300,6 +305,20 @@ void sept_conv5x5_mfma_kernel(ConvArgs a) {
           t1 += v;
           t2 += v * v;
         }
+      } else if (a.bn_idx) {
+        const float d = a.drop ? a.drop[size_t(b) * COUT + c] : 1.0f;
+        const float mu = a.bn_mean[c], is = a.bn_invstd[c];
+        const bf16* ep = a.ypool + (size_t(b) * HW + q0) * COUT + c;
+        const unsigned char* ip = a.bn_idx + (size_t(b) * HW + q0) * COUT + c;
+        const int np = min(MT, HW - q0);
+#pragma unroll 8
+        for (int p = grp; p < np; p += NGRP) {
+          const float g = float(*reinterpret_cast<const bf16*>(smem + size_t(p) * SP + c * 2)) * d;
+          const float xh = (float(ep[size_t(p) * COUT]) - mu) * is;
+          const float ge = ip[size_t(p) * COUT] < 4 ? g : 0.f;
+          t1 += ge;
+          t2 += ge * xh;
+        }
       } else {
         const float d = a.drop ? a.drop[size_t(b) * COUT + c] : 1.0f;
         const float rd = d > 0.f ? 1.0f / d : 0.f, be = a.bn_beta[c], rg = 1.0f / a.bn_gamma[c];
@@ -472,7 +491,8 @@ const ConvVariant* conv_pick(int W, int cin, int cout, bool want_stats, size_t* 
 
 int conv_launch(const char* who, const void* x, const void* wt, const float* bias, void* y, float* stats, int B, int H,
                 int W, int cin, int cout, void* stream, const void* ypool = nullptr, const float* bn_gamma = nullptr,
-                const float* bn_beta = nullptr, const float* drop = nullptr) {
+                const float* bn_beta = nullptr, const float* drop = nullptr, const void* bn_idx = nullptr,
+                const float* bn_mean = nullptr, const float* bn_invstd = nullptr) {
   SEPT_REQUIRE(B >= 0 && H > 0 && W > 0, SEPT_ERR_INVALID, "%s: B=%d H=%d W=%d", who, B, H, W);
   if (B == 0) return SEPT_OK;
   SEPT_REQUIRE(x && wt && y, SEPT_ERR_INVALID, "%s: null argument", who);
@@ -492,6 +512,9 @@ int conv_launch(const char* who, const void* x, const void* wt, const float* bia
   a.bn_gamma = bn_gamma;
   a.bn_beta = bn_beta;
   a.drop = drop;
+  a.bn_idx = static_cast<const unsigned char*>(bn_idx);
+  a.bn_mean = bn_mean;
+  a.bn_invstd = bn_invstd;
   a.y = static_cast<bf16*>(y);
   a.B = B;
   a.H = H;
@@ -555,4 +578,17 @@ extern "C" int sept_conv5x5_dgrad_bnsums(const void* dy_out, const void* wt, voi
                "sept_conv5x5_dgrad_bnsums: null argument / empty batch / not a data-gradient shape (cin=%d cout=%d)", cin, cout);
   return conv_launch("sept_conv5x5_dgrad_bnsums", dy_out, wt, nullptr, dx_out, partials, B, H, W, cin, cout, stream, ypool,
                      bn_gamma, bn_beta, dropscale);
+}
+
+// The same for a block in pool-first form (sept_conv1_forward_pool): ext / idx_u8 (B, H, W, cout) are that block's
+// extremum values and position bytes (after sept_bn_relu_ext_forward: 4 = ReLU inactive), mean / invstd its batch
+// statistics.  The partials are exact for every gamma: sept_bn_bwd_sums_from_partials finishes them.
+extern "C" int sept_conv5x5_dgrad_bnsums_ext(const void* dy_out, const void* wt, void* dx_out, const void* ext,
+                                             const void* idx_u8, const float* bn_mean, const float* bn_invstd,
+                                             const float* dropscale, float* partials, int B, int H, int W, int cin, int cout,
+                                             void* stream) {
+  SEPT_REQUIRE(partials && ext && idx_u8 && bn_mean && bn_invstd && B > 0 && cin > cout, SEPT_ERR_INVALID,
+               "sept_conv5x5_dgrad_bnsums_ext: null argument / empty batch / not a data-gradient shape (cin=%d cout=%d)", cin, cout);
+  return conv_launch("sept_conv5x5_dgrad_bnsums_ext", dy_out, wt, nullptr, dx_out, partials, B, H, W, cin, cout, stream, ext,
+                     nullptr, nullptr, dropscale, idx_u8, bn_mean, bn_invstd);
 }

@@ -1188,6 +1188,185 @@ __global__ __launch_bounds__(256) void sept_conv1_l1_kernel(L1Args a) {
   }
 }
 
+
+// ---- conv1 with the 2x2 pooling window resolved BEFORE the BatchNorm (round 3) ------------------------------------
+// maxpool(relu(bn(v))) = relu(bn(max v)) over a window when gamma >= 0 and relu(bn(min v)) when gamma < 0 (bn is a
+// monotone map per channel, ReLU and the Dropout2d scale are monotone too), and the sign of gamma is known when conv1 is
+// launched.  So ONE pass over the input leaves everything the block needs, with no 64-byte-per-pixel tensor at all:
+//   stats [64][workgroups]       sums / sums of squares of the bf16-rounded conv outputs of EVERY pixel (the BatchNorm
+//                                statistics: sept_bn_stats_from_partials finishes them, as for sept_conv1_forward_stats)
+//   ext   [B][H/2][W/2][32] bf16 the window's extremum of the rounded conv output (maximum where gamma >= 0, minimum
+//                                where gamma < 0): the value the pooled activation is a function of
+//   idx   [B][H/2][W/2][32] u8   where it sits in the window (scan order 0..3, first one wins: ATen's rule)
+// A tiny elementwise pass (sept_bn_relu_ext_forward) then forms y = dropscale * relu(sc * ext + sh) -- bit-identical to
+// sept_bn_relu_pool_forward on the stored tensor -- and the backward pass works from (ext, idx, pooled gradient, input).
+// A 32-pixel MFMA block is a 2-row x 16-column patch (as sept_conv1_l1_kernel); the window logic runs on PACKED bf16
+// pairs through the LDS: each lane stores its 16 channels (4 x 8 bytes), then lane (window w = l >> 3, channel group
+// g = l & 7) reads the four pixels' 8 bytes of channels 4g..4g+3 and works on two dwords = four channels at a time with
+// 16-bit integer keys (bf16 bits mapped to an order-preserving int16: flip the magnitude bits of negatives; complement
+// where the minimum is wanted): v_pk_max_i16, v_pk_sub / v_pk_min_u16 for the "differs from the extremum" flags,
+// v_pk_mad_u16 for the first position whose flag is clear -- about 60 VALU instructions per block where the
+// lane-exchange form of the round-2 fused kernel needed ~190.  (-0 orders below +0 here; both give the same activation.)
+constexpr int kPoolPS = 72;   // bytes per pixel in the wave's pooling buffer: conflict-free 8-byte writes (18-dword stride)
+typedef short __attribute__((ext_vector_type(2))) s16x2;
+typedef unsigned short __attribute__((ext_vector_type(2))) u16x2;
+
+struct C1PoolArgs {
+  const float* x;       // [B][H][W]
+  const float* wprep;   // sept_conv1_prep_kernel output
+  const float* gamma;   // [32] BatchNorm weight (its sign picks maximum / minimum), null = all maxima
+  bf16* ext;            // [B][H/2][W/2][32]
+  unsigned char* idx;   // [B][H/2][W/2][32]
+  float* stats;         // [64][workgroups]
+  int B, H, W;
+};
+
+__device__ __forceinline__ unsigned pool_key(unsigned u, unsigned sm) {   // bf16 pair -> order-preserving int16 pair
+  const s16x2 s = __builtin_bit_cast(s16x2, u);
+  const unsigned m = __builtin_bit_cast(unsigned, s16x2(s >> 15));       // all ones where negative
+  return u ^ (m & 0x7FFF7FFFu) ^ sm;
+}
+
+__global__ __launch_bounds__(256) void sept_conv1_fwd_pool_kernel(C1PoolArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned* tile = reinterpret_cast<unsigned*>(smem);   // packed (hi << 16 | lo) bf16 halves of every staged sample
+  const int H = a.H, W = a.W, W4 = W + 4, PW = W / 16;
+  const int b = blockIdx.y, h0 = blockIdx.x * kFwdRows;
+  const int nrows = min(kFwdRows, H - h0);   // even: H is
+  stage_x_split(a.x + size_t(b) * H * W, tile, h0, nrows + 4, H, W);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, c = lane & 31;
+  unsigned char* pool = smem + ((size_t(kFwdRows + 4) * W4 * 4 + 15) & ~size_t(15)) + size_t(wave) * 32 * kPoolPS;
+  const float* wprep = a.wprep;
+  bf16x8 whi[2], wlo[2];
+  int tapoff[2][8];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int t = 16 * ks + 8 * half + j;
+      const float wv = t < kTaps ? wprep[t * kC + c] : (t == kTaps ? wprep[kTaps * kC + c] : 0.f);
+      whi[ks][j] = (bf16)wv;
+      wlo[ks][j] = (bf16)(wv - float(whi[ks][j]));
+      tapoff[ks][j] = t < kTaps ? (t / 5) * W4 + t % 5 : 0;
+    }
+  // pooling role of this lane: window pw (columns 2 pw, 2 pw + 1 of both rows), channels 4 pg .. 4 pg + 3
+  const int pg = lane & 7, pw = lane >> 3;
+  unsigned sm[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    const float g0 = a.gamma ? a.gamma[4 * pg + 2 * d] : 1.f, g1 = a.gamma ? a.gamma[4 * pg + 2 * d + 1] : 1.f;
+    sm[d] = (g0 < 0.f ? 0x0000FFFFu : 0u) | (g1 < 0.f ? 0xFFFF0000u : 0u);
+  }
+  const unsigned char* prd = pool + size_t(2 * pw) * kPoolPS + pg * 8;
+  float rs[16], rss[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) rs[r] = rss[r] = 0.f;
+  __syncthreads();
+  const int Ho = H / 2, Wo = W / 2;
+  const int nblk = (nrows / 2) * PW;
+  for (int blk = wave; blk < nblk; blk += 4) {
+    const int rp = blk / PW, pc = blk - rp * PW;
+    const int hh = 2 * rp + ((c >> 4) & 1), ww = 16 * pc + (c & 15);
+    const unsigned* tp = tile + hh * W4 + ww;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      unsigned wv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        wv[j] = tp[tapoff[ks][j]];
+        if (ks == 1) wv[j] = (half && j == 1) ? 0x3F800000u : ((half && j > 1) ? 0u : wv[j]);
+      }
+      unsigned ph[4], pl[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        ph[j] = __builtin_amdgcn_perm(wv[2 * j + 1], wv[2 * j], 0x07060302u);
+        pl[j] = __builtin_amdgcn_perm(wv[2 * j + 1], wv[2 * j], 0x05040100u);
+      }
+      const bf16x8 xhi = __builtin_bit_cast(bf16x8, make_uint4(ph[0], ph[1], ph[2], ph[3]));
+      const bf16x8 xlo = __builtin_bit_cast(bf16x8, make_uint4(pl[0], pl[1], pl[2], pl[3]));
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo[ks], xhi, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[ks], xlo, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[ks], xhi, acc, 0, 0, 0);
+    }
+    // acc[4j + i] = channel 8j + 4*half + i of pixel c: round, add to the statistics, hand the pixel to the pooling lanes
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      unsigned pk[2];
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        bf16x2 t;
+        t[0] = (bf16)acc[4 * j + 2 * d];
+        t[1] = (bf16)acc[4 * j + 2 * d + 1];
+        pk[d] = __builtin_bit_cast(unsigned, t);
+        const float v0 = float(t[0]), v1 = float(t[1]);
+        rs[4 * j + 2 * d] += v0;
+        rss[4 * j + 2 * d] = fmaf(v0, v0, rss[4 * j + 2 * d]);
+        rs[4 * j + 2 * d + 1] += v1;
+        rss[4 * j + 2 * d + 1] = fmaf(v1, v1, rss[4 * j + 2 * d + 1]);
+      }
+      *reinterpret_cast<uint2*>(pool + size_t(c) * kPoolPS + 16 * j + 8 * half) = make_uint2(pk[0], pk[1]);
+    }
+    sept::wave_lds_sync();
+    const uint2 q0 = *reinterpret_cast<const uint2*>(prd), q1 = *reinterpret_cast<const uint2*>(prd + kPoolPS);
+    const uint2 q2 = *reinterpret_cast<const uint2*>(prd + 16 * kPoolPS), q3 = *reinterpret_cast<const uint2*>(prd + 17 * kPoolPS);
+    sept::wave_lds_sync();   // the next block's stores stay behind these reads
+    unsigned eo[2], po[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const unsigned u0 = d ? q0.y : q0.x, u1 = d ? q1.y : q1.x, u2 = d ? q2.y : q2.x, u3 = d ? q3.y : q3.x;
+      const s16x2 k0 = __builtin_bit_cast(s16x2, pool_key(u0, sm[d])), k1 = __builtin_bit_cast(s16x2, pool_key(u1, sm[d]));
+      const s16x2 k2 = __builtin_bit_cast(s16x2, pool_key(u2, sm[d])), k3 = __builtin_bit_cast(s16x2, pool_key(u3, sm[d]));
+      const s16x2 M = __builtin_elementwise_max(__builtin_elementwise_max(k0, k1), __builtin_elementwise_max(k2, k3));
+      const u16x2 one = {1, 1};
+      const u16x2 n0 = __builtin_elementwise_min(__builtin_bit_cast(u16x2, s16x2(M - k0)), one);   // 1 = differs from the extremum
+      const u16x2 n1 = __builtin_elementwise_min(__builtin_bit_cast(u16x2, s16x2(M - k1)), one);
+      const u16x2 n2 = __builtin_elementwise_min(__builtin_bit_cast(u16x2, s16x2(M - k2)), one);
+      const u16x2 pos = n0 * (n1 * n2 + n1) + n0;      // first position whose flag is clear: n0 + n0 n1 + n0 n1 n2
+      po[d] = __builtin_bit_cast(unsigned, pos);
+      const unsigned v = __builtin_bit_cast(unsigned, M) ^ sm[d];
+      const unsigned vm = __builtin_bit_cast(unsigned, s16x2(__builtin_bit_cast(s16x2, v) >> 15));
+      eo[d] = v ^ (vm & 0x7FFF7FFFu);                  // back to bf16 bits
+    }
+    const int ho = (h0 >> 1) + rp, wo = 8 * pc + pw;
+    const size_t o = ((size_t(b) * Ho + ho) * Wo + wo) * kC + 4 * pg;
+    *reinterpret_cast<uint2*>(a.ext + o) = make_uint2(eo[0], eo[1]);
+    *reinterpret_cast<unsigned*>(a.idx + o) = __builtin_amdgcn_perm(po[1], po[0], 0x06040200u);
+  }
+  {
+    __syncthreads();   // the staged rows and the pooling buffers are no longer needed: the exchange reuses their LDS
+    float* ex = reinterpret_cast<float*>(smem);
+    float* ex2 = ex + 32 * 256;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      ex[r * 256 + threadIdx.x] = rs[r];
+      ex[(16 + r) * 256 + threadIdx.x] = rss[r];
+    }
+    __syncthreads();
+    {
+      const int o = threadIdx.x & 63, p = threadIdx.x >> 6;
+      const int which = o / kC, ch = o % kC;
+      const int j = ch >> 3, hf = (ch >> 2) & 1, i = ch & 3;
+      const float4* run = reinterpret_cast<const float4*>(ex + (which * 16 + 4 * j + i) * 256 + p * 64 + hf * 32);
+      float t = 0.f;
+#pragma unroll
+      for (int l = 0; l < 8; ++l) {
+        const float4 v = run[l];
+        t += (v.x + v.y) + (v.z + v.w);
+      }
+      ex2[o * 4 + p] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * kC) {
+      const float4 v = reinterpret_cast<const float4*>(ex2)[threadIdx.x];
+      a.stats[size_t(threadIdx.x) * (size_t(gridDim.x) * gridDim.y) + size_t(blockIdx.y) * gridDim.x + blockIdx.x] =
+          (v.x + v.y) + (v.z + v.w);
+    }
+  }
+}
+
 }  // namespace
 
 // the MFMA path writes one raw [16][64] accumulator slab (1024 floats) per workgroup
@@ -1396,6 +1575,30 @@ extern "C" int sept_conv1_bn_relu_pool_backward_apply(const float* x, const floa
   a.inv_n = float(1.0 / n_total); a.B = B; a.H = H; a.W = W;
   hipLaunchKernelGGL(sept_conv1_l1_kernel<kL1BwdApply>, dim3((H + kFwdRows - 1) / kFwdRows, B), dim3(256), l1_smem(W), st, a);
   return sept::launch_check("sept_conv1_l1_kernel<backward apply>");
+}
+
+
+// conv1 forward with the pooling window resolved before the BatchNorm: see sept_conv1_fwd_pool_kernel.
+extern "C" int sept_conv1_pool_supported(int H, int W) {
+  return H > 0 && W > 0 && H % 2 == 0 && W % 16 == 0 &&
+         std::max(((size_t(kFwdRows + 4) * (W + 4) * 4 + 15) & ~size_t(15)) + size_t(4) * 32 * kPoolPS,
+                  sizeof(float) * (32 * 256 + 256)) <= 64 * 1024;
+}
+
+extern "C" int sept_conv1_forward_pool(const float* x, const float* w, const float* bias, float* wprep, const float* gamma,
+                                       void* ext_bf16, void* idx_u8, float* stats, int B, int H, int W, void* stream) {
+  if (int e = conv1_check("sept_conv1_forward_pool", B, H, W)) return e;
+  SEPT_REQUIRE(B > 0 && x && wprep && ext_bf16 && idx_u8 && stats, SEPT_ERR_INVALID,
+               "sept_conv1_forward_pool: null argument / empty batch");
+  SEPT_REQUIRE(sept_conv1_pool_supported(H, W), SEPT_ERR_UNSUPPORTED,
+               "sept_conv1_forward_pool: H=%d W=%d (needs an even H and W %% 16 == 0)", H, W);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (w) hipLaunchKernelGGL(sept_conv1_prep_kernel, dim3((kTaps * kC + 255) / 256), dim3(256), 0, st, w, bias, wprep);
+  const size_t smem = std::max(((size_t(kFwdRows + 4) * (W + 4) * 4 + 15) & ~size_t(15)) + size_t(4) * 32 * kPoolPS,
+                               sizeof(float) * (32 * 256 + 256));
+  C1PoolArgs a{x, wprep, gamma, static_cast<bf16*>(ext_bf16), static_cast<unsigned char*>(idx_u8), stats, B, H, W};
+  hipLaunchKernelGGL(sept_conv1_fwd_pool_kernel, dim3((H + kFwdRows - 1) / kFwdRows, B), dim3(256), smem, st, a);
+  return sept::launch_check("sept_conv1_fwd_pool_kernel");
 }
 
 // The operand form of conv1's weights (sept_conv1_prep_floats() floats): built by every entry point above from

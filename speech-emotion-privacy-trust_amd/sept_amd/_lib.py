@@ -147,6 +147,11 @@ SIGNATURES = {
     "sept_conv1_bn_relu_pool_backward_reduce": (c_int, [c_void_p] * 11 + [c_int] * 3 + [c_void_p]),
     "sept_bn_bwd_sums_from_partials": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sept_conv1_bn_relu_pool_backward_apply": (c_int, [c_void_p] * 11 + [c_double, c_void_p] + [c_int] * 3 + [c_void_p]),
+    "sept_conv1_pool_supported": (c_int, [c_int, c_int]),
+    "sept_conv1_forward_pool": (c_int, [c_void_p] * 8 + [c_int] * 3 + [c_void_p]),
+    "sept_bn_relu_ext_forward": (c_int, [c_void_p] * 8 + [c_int, c_long, c_int, c_void_p]),
+    "sept_bn_backward_sums_ext": (c_int, [c_void_p] * 10 + [c_int, c_long, c_int, c_void_p]),
+    "sept_conv5x5_dgrad_bnsums_ext": (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_void_p]),
     "sept_sgd_step_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_float, c_float, c_float, c_void_p]),
     "sept_adam_step_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_float, c_float, c_float,
                                    c_float, c_void_p, c_float, c_void_p]),

@@ -243,8 +243,27 @@ def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None, gfeat=Non
                 d2 = inj.get("drop2d")
                 drop = d2[li] if d2 is not None else masks[("c", li)]
             out = ops.conv1_bn_relu_pool_forward(x, cv.weight, cv.bias, mean, invstd, bn.weight, bn.bias, drop, prep=c1p)
-            S.blocks.append(SimpleNamespace(inp=None, pre=None, out=out, mean=mean, invstd=invstd, drop=drop, pool=pool, h=h,
-                                            w=w, bn_train=bn.training, sync=False, l1_fused=True, idx=None))
+            S.blocks.append(SimpleNamespace(inp=None, pre=None, ext=None, out=out, mean=mean, invstd=invstd, drop=drop, pool=pool,
+                                            h=h, w=w, bn_train=bn.training, sync=False, l1_fused=True, idx=None))
+            act = out
+            h, w = h // pool, w // pool
+            continue
+        if (li == 0 and pool == 2 and bn.training and not _SYNC_BN["on"] and L1_POOL_FIRST and ops.conv1_pool_supported(H, W)
+                and _pool_first_backward_ok(cv, need_grad)):
+            # block 1 in pool-first form: conv1 leaves the statistics partials, the 2x2 window's extremum (by the sign of
+            # gamma) and its position; a quarter-size elementwise pass forms the pooled activation.  Nothing of
+            # (B, H, W, 32) is written or read, forward or backward (include/sept.h, "POOL-FIRST")
+            ext, idx, mean, invstd = ops.conv1_forward_pool(x, cv.weight, cv.bias, bn.weight, bn.running_mean, bn.running_var,
+                                                            bn.num_batches_tracked,
+                                                            bn.momentum if bn.momentum is not None else 0.1, bn.eps,
+                                                            prep=_conv1_operand(cv))
+            drop = None
+            if train and (P.drop_ps[li] > 0 or "drop2d" in inj):
+                d2 = inj.get("drop2d")
+                drop = d2[li] if d2 is not None else masks[("c", li)]
+            out = ops.bn_relu_ext_forward(ext, idx if need_grad else None, mean, invstd, bn.weight, bn.bias, drop)
+            S.blocks.append(SimpleNamespace(inp=None, pre=None, ext=ext, out=out, mean=mean, invstd=invstd, drop=drop, pool=pool,
+                                            h=h, w=w, bn_train=True, sync=False, l1_fused=False, idx=idx))
             act = out
             h, w = h // pool, w // pool
             continue
@@ -287,8 +306,8 @@ def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None, gfeat=Non
             out, idx = ops.bn_relu_pool_forward(pre, mean, invstd, bn.weight, bn.bias, drop, pool, want_argmax=True)
         else:
             out = ops.bn_relu_pool_forward(pre, mean, invstd, bn.weight, bn.bias, drop, pool)
-        S.blocks.append(SimpleNamespace(inp=act, pre=pre, out=out, mean=mean, invstd=invstd, drop=drop, pool=pool, h=h, w=w,
-                                        bn_train=bn.training, sync=_SYNC_BN["on"] and bn.training, l1_fused=False, idx=idx))
+        S.blocks.append(SimpleNamespace(inp=act, pre=pre, ext=None, out=out, mean=mean, invstd=invstd, drop=drop, pool=pool, h=h,
+                                        w=w, bn_train=bn.training, sync=_SYNC_BN["on"] and bn.training, l1_fused=False, idx=idx))
         act = out
         h, w = h // pool, w // pool
     # ---- GRU: (B, T=h, D = w*C) with NHWC feature order (w, c) ----
@@ -509,6 +528,18 @@ BN_APPLY_IN_DGRAD = os.environ.get("SEPT_BN_APPLY_DGRAD", "0") == "1"
 # recorded arg-max positions + the input, no pre-activation-sized tensor (ops.conv1_backward_data_sparse; -1.7 % step
 # time).  SEPT_L1_SPARSE=0: BatchNorm backward apply pass + dense data gradient as for the trainable one
 L1_SPARSE = os.environ.get("SEPT_L1_SPARSE", "1") != "0"
+# block 1 in pool-first form (round 3): conv1's epilogue resolves the 2x2 pooling window BEFORE the BatchNorm (maximum or
+# minimum by the sign of gamma) and leaves the statistics partials, so no (B, H, W, 32) tensor exists in either direction.
+# SEPT_L1_POOL_FIRST=0: conv1 stores its output and the BatchNorm passes stream it (round 2's form)
+L1_POOL_FIRST = os.environ.get("SEPT_L1_POOL_FIRST", "1") != "0"
+
+
+def _pool_first_backward_ok(cv, need_grad):
+    """the pool-first form has a backward pass for a conv1 without weight gradient (the frozen emotion network: sparse data
+    gradient from the pooled gradient + position bytes + input); a trainable conv1 still needs its stored output"""
+    return not need_grad or not cv.weight.requires_grad
+
+
 # BatchNorm statistics of the 5x5 conv layers from the conv kernel's epilogue (SEPT_CONV_STATS=0: a separate pass)
 CONV_FUSED_STATS = os.environ.get("SEPT_CONV_STATS", "1") != "0"
 NO_WGRAD_FORK = set()
@@ -702,6 +733,20 @@ def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq, go
         if li == 0 and not need_wgrad:
             _run_tail_wgrads(dact.device)   # the other branch's deferred weight gradients, in front of this branch's block 1
         want_bn = need_wgrad and bn.weight.requires_grad
+        if li == 0 and blk.ext is not None:
+            # pool-first block 1: channel sums from (dy, ext, idx) -- formed by the data-gradient conv above when it could --
+            # then the data gradient from the pooled gradient, the position bytes and the input
+            sums, dgamma, dbeta = ops.bn_backward_sums_ext(dact, blk.ext, blk.idx, blk.mean, blk.invstd, blk.drop, presums,
+                                                           need_param_grads=want_bn,
+                                                           out_gamma=gout(bn.weight) if want_bn else None,
+                                                           out_beta=gout(bn.bias) if want_bn else None)
+            if want_bn:
+                put(bn.weight, dgamma)
+                put(bn.bias, dbeta)
+            if need_dx:
+                dx = ops.conv1_backward_data_from_sums(S.x, dact, blk.idx, sums, blk.mean, blk.invstd, bn.weight, blk.drop,
+                                                       cv.weight, cv.bias, prep=_conv1_operand(cv))
+            continue
         if (li == 0 and getattr(blk, "idx", None) is not None and need_dx and not blk.sync
                 and not (need_wgrad and cv.weight.requires_grad)):
             # block 1 of a network without conv1 weight gradient (the frozen emotion model): no pre-activation-sized tensor
@@ -787,7 +832,9 @@ def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq, go
                 put(cv.bias, ops.fill(ob if ob is not None else torch.empty_like(cv.bias), 0.0))
             wtd = _cached("convdgrad", cv.weight, lambda: ops.conv5x5_prep_weights(cv.weight, 1))
             prev = S.blocks[li - 1]
-            if (BN_SUMS_IN_DGRAD and BN_POOLED_SUMS and prev.bn_train and not prev.sync and not prev.l1_fused
+            if prev.ext is not None:
+                dact, presums = ops.conv5x5_dgrad_bnsums_ext(dpre, wtd, prev.ext, prev.idx, prev.mean, prev.invstd, prev.drop)
+            elif (BN_SUMS_IN_DGRAD and BN_POOLED_SUMS and prev.bn_train and not prev.sync and not prev.l1_fused
                     and prev.pool == 2):
                 # the data-gradient conv's epilogue also forms the backward sums of the BatchNorm in front (from its
                 # output tile and that block's pooled activation): that block's reduce pass over y / dy disappears

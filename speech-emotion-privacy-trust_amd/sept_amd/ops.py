@@ -457,6 +457,105 @@ def conv1_backward_data_sparse(x, pre, dy, idx, mean, invstd, gamma, beta, drops
     return dx, dgamma, dbeta
 
 
+def conv1_pool_supported(H, W):
+    return bool(lib.sept_conv1_pool_supported(int(H), int(W)))
+
+
+def conv1_forward_pool(x, w, bias, gamma, bn_running_mean=None, bn_running_var=None, bn_num_batches_tracked=None,
+                       momentum=0.1, eps=1e-5, prep=None):
+    """conv1 with the 2x2 pooling window resolved BEFORE the BatchNorm (include/sept.h, "pool-first"): x (B,H,W) fp32 ->
+    (ext (B,H/2,W/2,32) bf16 = the window's extremum of the conv output by the sign of gamma, idx u8 = its position,
+    mean, invstd = the batch statistics over EVERY pixel).  No (B,H,W,32) tensor is written; the running buffers of the
+    BatchNorm are updated here."""
+    require_cuda(x, w, gamma)
+    B, H, W = x.shape
+    dev = x.device
+    ext = torch.empty((B, H // 2, W // 2, 32), dtype=torch.bfloat16, device=dev)
+    idx = torch.empty((B, H // 2, W // 2, 32), dtype=torch.uint8, device=dev)
+    wptr, wp = _c1w(x, w, prep)
+    nparts = lib.sept_conv1_stats_parts(B, H)
+    parts = workspace("conv1_stats", nparts * 64, dev)
+    check(lib.sept_conv1_forward_pool(x.data_ptr(), wptr, _p(bias), wp.data_ptr(), gamma.data_ptr(), ext.data_ptr(),
+                                      idx.data_ptr(), parts.data_ptr(), B, H, W, _s(x)), "sept_conv1_forward_pool")
+    mean = torch.empty(32, dtype=torch.float32, device=dev)
+    invstd = torch.empty_like(mean)
+    check(lib.sept_bn_stats_from_partials(parts.data_ptr(), nparts, B * H * W, 32, mean.data_ptr(), invstd.data_ptr(),
+                                          _p(bn_running_mean), _p(bn_running_var), _p(bn_num_batches_tracked),
+                                          float(momentum), float(eps), _s(x)), "sept_bn_stats_from_partials")
+    return ext, idx, mean, invstd
+
+
+def bn_relu_ext_forward(ext, idx, mean, invstd, gamma, beta, dropscale=None):
+    """y = dropscale * relu(bn(ext)) for a pool-first block; idx (nullable) is re-marked 4 where the ReLU is inactive."""
+    require_cuda(ext, mean, invstd, gamma, beta)
+    B, Ho, Wo, C = ext.shape
+    y = torch.empty_like(ext)
+    check(lib.sept_bn_relu_ext_forward(ext.data_ptr(), _p(idx), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+                                       beta.data_ptr(), _p(dropscale), y.data_ptr(), B, Ho * Wo, C, _s(ext)),
+          "sept_bn_relu_ext_forward")
+    return y
+
+
+def conv5x5_dgrad_bnsums_ext(dy_out, wtd, ext, idx, mean, invstd, dropscale=None):
+    """conv5x5_dgrad_bnsums for a block in pool-first form: the partials come from (dx, ext, idx) and are exact for any
+    gamma.  -> (dx, (partials, nparts)) or (dx, None) when the shape has no such kernel form."""
+    require_cuda(dy_out, wtd, ext, idx)
+    B, H, W, cin = dy_out.shape
+    cout = wtd.shape[1]
+    nparts = lib.sept_conv5x5_bwsums_parts(B, H, W, cin, cout)
+    if nparts <= 0 or tuple(ext.shape) != (B, H, W, cout) or tuple(idx.shape) != (B, H, W, cout):
+        return conv5x5(dy_out, wtd), None
+    dx = torch.empty((B, H, W, cout), dtype=torch.bfloat16, device=dy_out.device)
+    parts = workspace(f"conv5x5_bwsums{cout}", nparts * 2 * cout, dy_out.device)
+    h = TIMER.start(f"conv5x5_mfma<{cin},{cout}>") if TIMER is not None else None
+    check(lib.sept_conv5x5_dgrad_bnsums_ext(dy_out.data_ptr(), wtd.data_ptr(), dx.data_ptr(), ext.data_ptr(), idx.data_ptr(),
+                                            mean.data_ptr(), invstd.data_ptr(), _p(dropscale), parts.data_ptr(), B, H, W, cin,
+                                            cout, _s(dx)), "sept_conv5x5_dgrad_bnsums_ext")
+    if h is not None:
+        TIMER.stop(h)
+    return dx, (parts, nparts)
+
+
+def bn_backward_sums_ext(dy, ext, idx, mean, invstd, dropscale, presums=None, need_param_grads=True, out_gamma=None,
+                         out_beta=None):
+    """(sum g, sum g * xhat) [2C] of a pool-first block (+ dgamma, dbeta): from a producer's partials, else by a reduce
+    pass over (dy, ext, idx)."""
+    C = ext.shape[-1]
+    dev = ext.device
+    sums = torch.empty(2 * C, dtype=torch.float32, device=dev)
+    dgamma = dbeta = None
+    if need_param_grads:
+        dgamma = torch.empty(C, dtype=torch.float32, device=dev) if out_gamma is None else out_gamma
+        dbeta = torch.empty(C, dtype=torch.float32, device=dev) if out_beta is None else out_beta
+    if presums is not None:
+        parts, nparts = presums
+        check(lib.sept_bn_bwd_sums_from_partials(parts.data_ptr(), nparts, C, sums.data_ptr(), _p(dgamma), _p(dbeta), _s(ext)),
+              "sept_bn_bwd_sums_from_partials")
+    else:
+        B, Ho, Wo, _ = ext.shape
+        ws = workspace("bn", lib.sept_bn_workspace_floats(C), dev)
+        check(lib.sept_bn_backward_sums_ext(dy.data_ptr(), ext.data_ptr(), idx.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                            _p(dropscale), ws.data_ptr(), sums.data_ptr(), _p(dgamma), _p(dbeta), B, Ho * Wo, C,
+                                            _s(ext)), "sept_bn_backward_sums_ext")
+    return sums, dgamma, dbeta
+
+
+def conv1_backward_data_from_sums(x, dy, idx, sums, mean, invstd, gamma, dropscale, w, bias, prep=None):
+    """Block 1's data gradient from the pooled gradient dy, the position bytes idx, the input x and the two channel sums
+    (sept_conv1_backward_data_sparse): no pre-activation-sized tensor."""
+    require_cuda(x, dy, idx, w)
+    B, H, W = x.shape
+    dx = torch.empty((B, H, W), dtype=torch.float32, device=x.device)
+    coef = torch.empty(2800, dtype=torch.float32, device=x.device)
+    wptr, wp = _c1w(x, w, prep, "conv1_prep_bwd")
+    wf = w.detach().contiguous()
+    check(lib.sept_conv1_backward_data_sparse(dy.data_ptr(), idx.data_ptr(), x.data_ptr(), wf.data_ptr(), _p(bias),
+                                              mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), _p(dropscale),
+                                              sums.data_ptr(), float(B) * H * W, wptr, wp.data_ptr(), coef.data_ptr(),
+                                              dx.data_ptr(), B, H, W, _s(x)), "sept_conv1_backward_data_sparse")
+    return dx
+
+
 def conv5x5_backward_weight(x, dy, out=None):
     """x (B,H,W,cin) bf16, dy (B,H,W,cout) bf16 -> dW (cout,cin,5,5) fp32."""
     require_cuda(x, dy)

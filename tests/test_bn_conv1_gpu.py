@@ -320,3 +320,82 @@ def test_block1_data_gradient_from_pooled_gradient_and_argmax_positions(B, H, W,
     assert err_new < 6e-3, (err_new, err_old)
     assert torch.allclose(dx, ref_dx, rtol=2e-2, atol=4e-3 * scale), float((dx - ref_dx).abs().max()) / scale
     assert float((dx - hip_dx).norm() / hip_dx.norm()) < 8e-3
+
+
+@pytest.mark.parametrize("B,H,W", [(3, 200, 80), (2, 200, 128), (5, 38, 16)])
+@pytest.mark.parametrize("drop", [False, True])
+def test_block1_pool_first_equals_the_stored_tensor_path(B, H, W, drop):
+    """sept_conv1_forward_pool + sept_bn_relu_ext_forward (round 3: the 2x2 window resolved BEFORE the BatchNorm, maximum
+    or minimum by the sign of gamma; baseline_models.py:172-176) against the stored-tensor path (conv1 with statistics,
+    BatchNorm + ReLU + MaxPool + Dropout2d with arg-max): identical statistics, bit-identical pooled activation, identical
+    position bytes, ext = the window extremum of the stored pre-activations.  gamma has negative, tiny and zero entries;
+    then the backward sums from (dy, ext, idx) -- by the reduce kernel and by the data-gradient conv's epilogue -- against
+    the window-path sums of the stored tensor, and the data gradient against the pre-activation form."""
+    from sept_amd import ops
+    g = torch.Generator().manual_seed(3 * H + W + B)
+    x = torch.randn(B, H, W, generator=g).cuda()
+    w = (torch.randn(32, 1, 5, 5, generator=g) * 0.25).cuda()
+    bias = (0.1 * torch.randn(32, generator=g)).cuda()
+    gamma = 1 + 0.3 * torch.randn(32, generator=g)
+    gamma[2], gamma[7], gamma[11], gamma[30] = -0.8, 1e-5, -2e-4, 0.0
+    gamma = gamma.cuda()
+    beta = (0.2 * torch.randn(32, generator=g)).cuda()
+    dmask = ((torch.rand(B, 32, generator=g) > 0.2).float() * 1.25).cuda() if drop else None
+    pre, mean, invstd = ops.conv1_forward_stats(x, w, bias)
+    y_old, idx_old = ops.bn_relu_pool_forward(pre, mean, invstd, gamma, beta, dmask, 2, want_argmax=True)
+    rm, rv, nbt = torch.zeros(32).cuda(), torch.ones(32).cuda(), torch.zeros((), dtype=torch.int64).cuda()
+    ext, idx, mean2, invstd2 = ops.conv1_forward_pool(x, w, bias, gamma, rm, rv, nbt)
+    assert int(nbt) == 1 and float(rm.abs().max()) > 0
+    assert torch.allclose(mean2, mean, rtol=1e-5, atol=1e-6) and torch.allclose(invstd2, invstd, rtol=1e-5)
+    # the extremum of the stored pre-activations, window by window
+    p4 = pre.float().view(B, H // 2, 2, W // 2, 2, 32).permute(0, 1, 3, 2, 4, 5).reshape(B, H // 2, W // 2, 4, 32)
+    want_ext = torch.where(gamma >= 0, p4.max(3).values, p4.min(3).values)
+    assert torch.equal(ext.float(), want_ext)
+    # first position attaining it, in scan order
+    hit = p4 == want_ext[:, :, :, None, :]
+    order = torch.arange(4, device=hit.device).view(1, 1, 1, 4, 1)
+    want_pos = torch.where(hit, order, torch.full_like(order, 4)).min(3).values.to(torch.uint8)
+    assert torch.equal(idx, want_pos)
+    y_new = ops.bn_relu_ext_forward(ext, idx, mean, invstd, gamma, beta, dmask)   # same statistics as the old path: bit equality
+    assert torch.equal(y_new, y_old)
+    # idx after the activation pass: 4 where the ReLU is inactive, else the old path's arg-max (which is the first
+    # maximum of the ACTIVATIONS: where gamma == 0 every position ties and ATen's rule picks 0, here the extremum of v)
+    live = gamma != 0
+    assert torch.equal(idx[..., live] == 4, idx_old[..., live] == 4)
+    both = (idx != 4) & (idx_old != 4)
+    assert torch.equal(idx[both & live], idx_old[both & live])
+    # ---- backward sums: window path of the stored tensor vs (dy, ext, idx) ----
+    dy = torch.randn(B, H // 2, W // 2, 32, generator=g).bfloat16().cuda()
+    _, want_dg, want_db = ops.bn_relu_pool_backward(dy, pre, mean, invstd, gamma, beta, dmask, 2)      # y=None: every window
+    sums, dg, db = ops.bn_backward_sums_ext(dy, ext, idx, mean, invstd, dmask)
+    assert torch.allclose(db[live], want_db[live], rtol=1e-4, atol=1e-4) and torch.allclose(dg[live], want_dg[live], rtol=1e-4, atol=1e-4)
+    assert torch.equal(sums[:32], db) and torch.equal(sums[32:], dg)
+    # ---- data gradient: sparse + dense form from (dy, idx, x, sums) vs the stored-tensor passes ----
+    if W <= 128 and W >= 8 and H >= 4:
+        dx = ops.conv1_backward_data_from_sums(x, dy, idx, sums, mean, invstd, gamma, dmask, w, bias)
+        dpre_t, _, _ = ops.bn_relu_pool_backward(dy, pre, mean, invstd, gamma, beta, dmask, 2)
+        hip_dx = ops.conv1_backward_data(dpre_t, w)
+        assert float((dx - hip_dx).norm() / hip_dx.norm()) < 8e-3
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout", [(3, 100, 40, 64, 32), (2, 50, 20, 128, 64)])
+def test_dgrad_epilogue_sums_for_a_pool_first_block(B, H, W, cin, cout):
+    """sept_conv5x5_dgrad_bnsums_ext: the data-gradient conv whose epilogue leaves (sum g, sum g * xhat) of the pool-first
+    block in front of its output, from its output tile and that block's (ext, idx): same dx as the plain conv, same sums
+    as the reduce kernel over the stored dx."""
+    from sept_amd import ops
+    g = torch.Generator().manual_seed(cin + H)
+    dyo = torch.randn(B, H, W, cin, generator=g).bfloat16().cuda()
+    wt = ops.conv5x5_prep_weights((torch.randn(cin, cout, 5, 5, generator=g) * 0.05).cuda(), 1)
+    ext = (torch.randn(B, H, W, cout, generator=g) * 1.5).bfloat16().cuda()
+    idx = torch.randint(0, 5, (B, H, W, cout), generator=g).to(torch.uint8).cuda()
+    mean, invstd = (0.2 * torch.randn(cout, generator=g)).cuda(), (0.5 + torch.rand(cout, generator=g)).cuda()
+    dmask = ((torch.rand(B, cout, generator=g) > 0.2).float() * 1.25).cuda()
+    dx, presums = ops.conv5x5_dgrad_bnsums_ext(dyo, wt, ext, idx, mean, invstd, dmask)
+    assert presums is not None
+    assert torch.equal(dx, ops.conv5x5(dyo, wt))
+    sums, dg, db = ops.bn_backward_sums_ext(dx, ext, idx, mean, invstd, dmask, presums)
+    sums2, dg2, db2 = ops.bn_backward_sums_ext(dx, ext, idx, mean, invstd, dmask, None)
+    scale = float(sums2.abs().max())
+    assert torch.allclose(sums, sums2, rtol=1e-4, atol=1e-5 * scale)
+    assert torch.equal(dg, sums[cout:]) and torch.equal(db, sums[:cout])
