@@ -363,6 +363,21 @@ int sept_bn_relu_ext_forward(const void* ext, void* idx_u8 /*nullable, in/out*/,
 int sept_bn_backward_sums_ext(const void* dy, const void* ext, const void* idx_u8, const float* mean, const float* invstd,
                               const float* dropscale, float* ws, float* sums_out, float* dgamma, float* dbeta, int B,
                               long px_per_item, int C, void* stream);
+size_t sept_conv1_wgrad_sparse_workspace_floats(void);
+int sept_conv1_backward_weight_sparse(const void* dy_pooled, const void* idx_u8, const float* x, const float* w_f32,
+                                      const float* bias, const float* mean, const float* invstd, const float* gamma,
+                                      const float* dropscale, const float* sums, double n_total, float* ws, float* dw,
+                                      float* db /*nullable*/, int B, int H, int W, void* stream);
+/* sum over the batch of block 1's input gradient, (H, W) fp32 -- all the cloak's backward pass needs (its parameters are
+ * shared by every sample: dlocs = sum_b g_b, drhos = eps * dscales/drhos * sum_b g_b, cloak_models.py:45-58).  Every stage
+ * is linear in its per-sample input, so the pooled gradients are summed over the batch first (at their recorded positions),
+ * then ONE single-image transposed conv and ONE single-image 81-tap pass finish the job in fp32.
+ * ws: sept_conv1_dsum_workspace_floats(H, W) floats; coef: SEPT_CONV1_COEF_FLOATS floats of scratch. */
+size_t sept_conv1_dsum_workspace_floats(int H, int W);
+int sept_conv1_backward_data_sum(const void* dy_pooled, const void* idx_u8, const float* x, const float* w_f32,
+                                 const float* bias, const float* mean, const float* invstd, const float* gamma,
+                                 const float* dropscale, const float* sums, double n_total, float* ws, float* coef,
+                                 float* dxsum, int B, int H, int W, void* stream);
 int sept_conv5x5_dgrad_bnsums_ext(const void* dy_out, const void* wt, void* dx_out, const void* ext, const void* idx_u8,
                                   const float* bn_mean, const float* bn_invstd, const float* dropscale, float* partials,
                                   int B, int H, int W, int cin, int cout, void* stream);

@@ -977,6 +977,187 @@ __global__ void sept_conv1_wgrad_mfma_finalize_kernel(const float* ws, int npart
     db[c] = float(s);
 }
 
+// ---- weight gradient of a pool-first block 1: from the pooled gradient, the position bytes and the input -----------------
+// BatchNorm's input gradient is dpre[c,q] = sc_c * drop[b,c] * g[c,q] (at the window's recorded position, zero elsewhere)
+//                                        + c0_c + c1_c * v[c,q],     v = sum_s w[c,s] x~[q + s] + bias_c   (x~ = x, zero outside)
+// so conv1's weight gradient dW[c,t] = sum_q dpre[c,q] x~[q + t] splits into
+//   sparse : sc_c * S[c,t],            S[c,t] = sum_q (drop * g)[c,q] x~[q + t]       -- the MFMA product of the dense kernel
+//                                                 above, its dy rows EXPANDED in the loader from g (1/4 of the pixels)
+//                                                 and one position byte per pooled element;
+//   dense  : c0_c R[25,t] + c1_c sum_s w~[c,s] R[s,t],   R[s,t] = sum_q p_s[q] p_t[q],   p = (x~[q + tap 0..24], 1),
+//            w~[c,.] = (w[c,.], bias_c): conv1 has ONE input channel, so the dense part is a 26 x 26 Gram matrix of the input
+//            patches -- two more MFMAs per 16-pixel step on the im2col operand the sparse product builds anyway
+//            (A = that operand's bf16 value and, for the left factor only, its rounding residual: the products then match
+//            "v in fp32 times the bf16-rounded x" of the dense kernel).
+// Column 25 of every product is the constant 1, so t = 25 yields the bias gradient (zero up to rounding: the BatchNorm
+// behind the conv removes any per-channel constant).  No (B, H, W, 32) tensor is read: 229 MB of dpre + the 516 MB apply
+// pass that produced it at 224 windows of 200 x 80.
+struct C1WgSparseArgs {
+  const float* x;             // [B][H][W]
+  const bf16* dyp;            // [B][H/2][W/2][32] gradient of the pooled activation
+  const unsigned char* idx;   // [B][H/2][W/2][32] window position (>= 4: no gradient)
+  const float* drop;          // [B][32] Dropout2d scale or null
+  float* ws;                  // [workgroups][3][1024] accumulator slabs: S, HH, LH
+  int B, H, W;
+};
+
+__global__ __launch_bounds__(256, 3) void sept_conv1_wgrad_sparse_kernel(C1WgSparseArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int H = a.H, W = a.W, HW = H * W, W4 = W + 4, Ho = H / 2, Wo = W / 2;
+  float* xt = reinterpret_cast<float*>(smem);
+  unsigned char* yt = smem + ((sizeof(float) * nr_max(W) * W4 + 15) & ~size_t(15));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tap = lane & 31, k_hi = lane >> 5;
+  const int tapoff = tap < kTaps ? (tap / 5) * W4 + (tap % 5) : 0;
+  const int tr_q = (lane & 15) >> 2;
+  const int tr_ch = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  f32x16 acc, ghh, glh;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = ghh[r] = glh[r] = 0.f;
+  const int tiles_per_img = (HW + kMT - 1) / kMT;
+  const long n_tiles = long(a.B) * tiles_per_img;
+  const float inv_w = 1.0f / float(W);
+  // the pooled gradient / position bytes of the NEXT tile are fetched into registers while the current one is computed
+  // on (unconditional, clamped addresses); a thread's four chunks share its channel group cc = tid & 3
+  constexpr int NY = kMT * 4 / 256;
+  const int cc = tid & 3;
+  uint4 gr[NY];
+  uint2 ir[NY];
+  float dsc[8];
+  const long tile_end = n_tiles * (blockIdx.x + 1) / gridDim.x;
+  auto fetch = [&](long tile_id) {
+    const long tc = min(tile_id, n_tiles - 1);
+    const int b = int(tc / tiles_per_img), q0 = int(tc % tiles_per_img) * kMT;
+#pragma unroll
+    for (int j = 0; j < NY; ++j) {
+      const int q = min(q0 + ((tid + 256 * j) >> 2), HW - 1);
+      const int h = int((float(q) + 0.5f) * inv_w), w = q - h * W;
+      const size_t o = ((size_t(b) * Ho + (h >> 1)) * Wo + (w >> 1)) * kC + cc * 8;
+      gr[j] = *reinterpret_cast<const uint4*>(a.dyp + o);
+      ir[j] = *reinterpret_cast<const uint2*>(a.idx + o);
+    }
+    if (a.drop) {
+      const float4 d0 = *reinterpret_cast<const float4*>(a.drop + size_t(b) * kC + cc * 8);
+      const float4 d1 = *reinterpret_cast<const float4*>(a.drop + size_t(b) * kC + cc * 8 + 4);
+      dsc[0] = d0.x; dsc[1] = d0.y; dsc[2] = d0.z; dsc[3] = d0.w;
+      dsc[4] = d1.x; dsc[5] = d1.y; dsc[6] = d1.z; dsc[7] = d1.w;
+    }
+  };
+#pragma unroll
+  for (int e = 0; e < 8; ++e) dsc[e] = 1.0f;
+  long tile_id = n_tiles * blockIdx.x / gridDim.x;
+  if (tile_id < tile_end) fetch(tile_id);
+  for (; tile_id < tile_end; ++tile_id) {
+    const int b = tile_id / tiles_per_img, q0 = int(tile_id % tiles_per_img) * kMT;
+    const int h_first = q0 / W, h_last = min(q0 + kMT - 1, HW - 1) / W;
+    __syncthreads();
+    stage_x(a.x + size_t(b) * HW, xt, h_first, h_last - h_first + 5, H, W);
+#pragma unroll
+    for (int j = 0; j < NY; ++j) {
+      const int t = (tid + 256 * j) >> 2;
+      const int q = q0 + t;
+      const int qc = min(q, HW - 1);
+      const int h = int((float(qc) + 0.5f) * inv_w), w = qc - h * W;
+      const unsigned pos = unsigned(2 * (h & 1) + (w & 1));
+      const bf16x8 gq = __builtin_bit_cast(bf16x8, gr[j]);
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const unsigned k = ((e < 4 ? ir[j].x : ir[j].y) >> (8 * (e & 3))) & 0xFFu;
+        o[e] = (k == pos && q < HW) ? (bf16)(float(gq[e]) * dsc[e]) : (bf16)0.f;
+      }
+      *reinterpret_cast<uint4*>(yt + size_t(t) * kDyPSt + cc * 16) = __builtin_bit_cast(uint4, o);
+    }
+    fetch(tile_id + 1);      // past the range: re-reads a valid tile, never used
+    sept::lds_barrier();     // LDS-only wait: the loads just issued stay in flight across the barrier
+    const int last_q = HW - 8;
+    constexpr int NS = kMT / 64;
+    bf16x8 afrag[NS], bfrag[NS], lfrag[NS];
+#pragma unroll
+    for (int ks = 0; ks < NS; ++ks) {
+      const int kb = wave * (kMT / 4) + ks * 16;
+      const int ta = kb + 8 * k_hi + tr_q;
+      const bf16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+          (__attribute__((address_space(3))) bf16x4*)(reinterpret_cast<uintptr_t>(yt + size_t(ta) * kDyPSt + tr_ch * 2)));
+      const bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+          (__attribute__((address_space(3))) bf16x4*)(reinterpret_cast<uintptr_t>(yt + size_t(ta + 4) * kDyPSt + tr_ch * 2)));
+      afrag[ks] = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
+      const int qg = q0 + kb + 8 * k_hi;
+      const int q = min(qg, last_q);
+      const int gh = int((float(q) + 0.5f) * inv_w), gw = q - __mul24(gh, W);
+      const float* xp = xt + __mul24(gh - h_first, W4) + gw + tapoff;
+      f32x8 xv;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xv[e] = xp[e];
+      // pixel groups past the image contribute nothing to the Gram products either (the sparse product is safe through
+      // dy = 0 there, the Gram products have no such factor): zero the whole column
+      const bool live = qg < HW;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xv[e] = !live ? 0.f : (tap < kTaps ? xv[e] : (tap == kTaps ? 1.0f : 0.0f));
+      bfrag[ks] = __builtin_convertvector(xv, bf16x8);
+      f32x8 res = xv - __builtin_convertvector(bfrag[ks], f32x8);
+      lfrag[ks] = __builtin_convertvector(res, bf16x8);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < NS; ++ks) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[ks], bfrag[ks], acc, 0, 0, 0);
+      ghh = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfrag[ks], bfrag[ks], ghh, 0, 0, 0);
+      glh = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lfrag[ks], bfrag[ks], glh, 0, 0, 0);
+    }
+  }
+  // fixed-order sum of the four waves, three [16][64] slabs per workgroup
+  float* red = reinterpret_cast<float*>(smem);
+  for (int wv = 0; wv < 4; ++wv) {
+    __syncthreads();
+    if (wave == wv) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        red[r * 64 + lane] = (wv == 0 ? 0.f : red[r * 64 + lane]) + acc[r];
+        red[1024 + r * 64 + lane] = (wv == 0 ? 0.f : red[1024 + r * 64 + lane]) + ghh[r];
+        red[2048 + r * 64 + lane] = (wv == 0 ? 0.f : red[2048 + r * 64 + lane]) + glh[r];
+      }
+    }
+  }
+  __syncthreads();
+  float* slab = a.ws + size_t(blockIdx.x) * 3072;
+  for (int i = tid; i < 3072; i += 256) slab[i] = red[i];
+}
+
+// slab element e = r * 64 + lane of a 32 x 32 accumulator is (row (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), column lane & 31)
+__global__ void sept_conv1_wgrad_sparse_reduce_kernel(const float* ws, int nparts, double* tot) {
+  const int e = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;  // one wave per slab element
+  if (e >= 3072) return;
+  const double s = sept::wave_sum_partials(ws, nparts, size_t(3072), e);
+  if (threadIdx.x & 63) return;
+  const int which = e >> 10, lane = e & 63, r = (e & 1023) >> 6;
+  const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = lane & 31;
+  tot[which * 1024 + row * 32 + col] = s;     // row-major [3][32][32]: S[c][t], HH[s][t], LH[s][t]
+}
+
+// dW[c][t] = sc_c S[c][t] + c0_c R[25][t] + c1_c sum_{s <= 25} w~[c][s] R[s][t],  R = HH + LH;   t = 25: the bias gradient
+__global__ __launch_bounds__(1024) void sept_conv1_wgrad_sparse_combine_kernel(const double* tot, const float* w, const float* bias,
+                                                                              const float* mean, const float* invstd,
+                                                                              const float* gamma, const float* sums, float inv_n,
+                                                                              float* dw, float* db) {
+  __shared__ double R[32 * 32];
+  const int c = threadIdx.x >> 5, t = threadIdx.x & 31;
+  R[threadIdx.x] = tot[1024 + threadIdx.x] + tot[2048 + threadIdx.x];
+  __syncthreads();
+  if (t > kTaps) return;
+  const double is = invstd[c], sc = double(gamma[c]) * is;
+  const double c1 = -sc * (double(sums[kC + c]) * inv_n) * is;
+  const double c0 = -sc * (double(sums[c]) * inv_n) - c1 * double(mean[c]);
+  double dot = (bias ? double(bias[c]) : 0.0) * R[kTaps * 32 + t];
+  for (int s2 = 0; s2 < kTaps; ++s2) dot += double(w[c * kTaps + s2]) * R[s2 * 32 + t];
+  const double v = sc * tot[c * 32 + t] + c0 * R[kTaps * 32 + t] + c1 * dot;
+  if (t < kTaps)
+    dw[c * kTaps + t] = float(v);
+  else if (db)
+    db[c] = float(v);   // analytically zero (the BatchNorm removes any per-channel constant): what is left is the rounding
+                        // of the large terms that cancel -- callers that know the BatchNorm is in train mode store 0 instead
+}
+
 // ---- layer 1 without its pre-activation tensor ----------------------------------------------------
 // conv1's output is 16x larger than its input (32 bf16 channels per fp32 pixel): at 224 windows of 200 x 80 the
 // pre-BatchNorm tensor is 229 MB, and storing it made every pass around it an HBM stream (conv1 write, BatchNorm
@@ -1601,6 +1782,37 @@ extern "C" int sept_conv1_forward_pool(const float* x, const float* w, const flo
   return sept::launch_check("sept_conv1_fwd_pool_kernel");
 }
 
+
+// Weight (and bias) gradient of conv1 for a pool-first block 1: see sept_conv1_wgrad_sparse_kernel.
+// ws: sept_conv1_wgrad_sparse_workspace_floats() floats.
+extern "C" size_t sept_conv1_wgrad_sparse_workspace_floats(void) { return size_t(kWgParts) * 3072 + 2 * 3072; }
+
+extern "C" int sept_conv1_backward_weight_sparse(const void* dy_pooled, const void* idx_u8, const float* x, const float* w_f32,
+                                                 const float* bias, const float* mean, const float* invstd, const float* gamma,
+                                                 const float* dropscale, const float* sums, double n_total, float* ws, float* dw,
+                                                 float* db, int B, int H, int W, void* stream) {
+  if (int e = conv1_check("sept_conv1_backward_weight_sparse", B, H, W)) return e;
+  SEPT_REQUIRE(B > 0 && dy_pooled && idx_u8 && x && w_f32 && mean && invstd && gamma && sums && ws && dw && n_total > 0,
+               SEPT_ERR_INVALID, "sept_conv1_backward_weight_sparse: null argument / empty batch");
+  SEPT_REQUIRE(H % 2 == 0 && W % 8 == 0 && H * W >= 8, SEPT_ERR_UNSUPPORTED,
+               "sept_conv1_backward_weight_sparse: H=%d W=%d (needs an even H and W %% 8 == 0)", H, W);
+  const size_t smem = std::max(((sizeof(float) * size_t(nr_max(W)) * (W + 4) + 15) & ~size_t(15)) + size_t(kMT) * kDyPS,
+                               sizeof(float) * 3072);
+  SEPT_REQUIRE(smem <= 160 * 1024, SEPT_ERR_UNSUPPORTED, "sept_conv1_backward_weight_sparse: W=%d needs %zu B of LDS", W, smem);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const long n_tiles = long(B) * ((H * W + kMT - 1) / kMT);
+  const int grid = int(std::min<long>(n_tiles, 768));   // three workgroups per CU (167 VGPRs): one resident round
+  C1WgSparseArgs a{x, static_cast<const bf16*>(dy_pooled), static_cast<const unsigned char*>(idx_u8), dropscale, ws, B, H, W};
+  SEPT_HIP(sept::allow_max_lds(reinterpret_cast<const void*>(&sept_conv1_wgrad_sparse_kernel)));
+  hipLaunchKernelGGL(sept_conv1_wgrad_sparse_kernel, dim3(grid), dim3(256), smem, st, a);
+  double* tot = reinterpret_cast<double*>(ws + size_t(kWgParts) * 3072);   // 3072 doubles = 2 * 3072 floats, 8-byte aligned
+  hipLaunchKernelGGL(sept_conv1_wgrad_sparse_reduce_kernel, dim3(3072 / 4), dim3(256), 0, st, ws, grid, tot);
+  hipLaunchKernelGGL(sept_conv1_wgrad_sparse_combine_kernel, dim3(1), dim3(1024), 0, st, tot, w_f32, bias, mean, invstd, gamma,
+                     sums, float(1.0 / n_total), dw, db);
+  return sept::launch_check("sept_conv1_backward_weight_sparse");
+}
+
+
 // The operand form of conv1's weights (sept_conv1_prep_floats() floats): built by every entry point above from
 // (w, bias) unless it is called with w == NULL, which means "wprep already holds it" -- a caller that keeps the
 // operands of unchanged weights (a frozen model: for good; a trainable one: per optimiser step) builds them once here.
@@ -1816,6 +2028,162 @@ __global__ __launch_bounds__(256) void sept_conv1_dense_dgrad_kernel(const float
   }
 }
 
+// ---- block 1's data gradient SUMMED OVER THE BATCH ---------------------------------------------------------------------
+// The only consumer of the gradient with respect to the network input in the cloak step is the cloak's backward pass, and
+// the cloak's parameters are shared by every sample: dlocs = sum_b g_b, drhos = eps * dscales * sum_b g_b (one epsilon per
+// step, cloak_models.py:45-58) -- only G = sum_b dL/dx_b is ever used.  Every stage of block 1's data gradient is linear in
+// its per-sample input, so the batch sum can be taken FIRST:
+//   sparse part : D[p,c] = sum_b drop[b,c] g[b,win(p),c] [idx[b,win(p),c] == pos(p)]   (one pass over the pooled gradient and
+//                 the position bytes: sept_conv1_dsum_partial_kernel, deterministic partial sums over NG batch groups),
+//                 then ONE single-image transposed conv  G_sparse[p] = sum_{t,c} sc_c w[c,t] D[p - off(t), c]  in fp32;
+//   dense part  : B * Vc[class(p)] + sum_u K9[class(p)][u] Xbar[p + u],  Xbar = sum_b x~_b  (same kernel tables as
+//                 sept_conv1_dense_dgrad_kernel, applied to ONE image).
+// At 224 windows this replaces the per-sample MFMA data gradient (60-75 us) and the per-sample 81-tap pass (39-50 us) by a
+// 100 MB streaming reduction and a one-image kernel -- and it is more exact (fp32 weights, no bf16 rounding of scd * g).
+constexpr int kDsumGroups = 8;     // most batch groups of the partial sums
+constexpr int kDsumPS = 36;        // floats per staged pixel of D (32 + 4: conflict-free 16-byte reads at a 36-dword stride)
+
+struct C1DsumArgs {
+  const bf16* dyp;            // [B][H/2][W/2][32]
+  const unsigned char* idx;   // [B][H/2][W/2][32]
+  const float* x;             // [B][H][W]
+  const float* drop;          // [B][32] or null
+  float* dpart;               // [NG][H][W][32]
+  float* xpart;               // [NG][H][W]
+  int B, H, W, NG;
+};
+
+__global__ __launch_bounds__(256) void sept_conv1_dsum_partial_kernel(C1DsumArgs a) {
+  const int H = a.H, W = a.W, Ho = H / 2, Wo = W / 2;
+  const int wc = blockIdx.x * 256 + threadIdx.x;
+  if (wc >= Ho * Wo * 4) return;
+  const int wi = wc >> 2, cc = wc & 3;
+  const int ho = wi / Wo, wo = wi - ho * Wo;
+  const int grp = blockIdx.y;
+  const int b0 = int(long(a.B) * grp / a.NG), b1 = int(long(a.B) * (grp + 1) / a.NG);
+  float acc[4][8];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[q][e] = 0.f;
+  float xs = 0.f;
+  const size_t po = (size_t(ho) * Wo + wo) * kC + cc * 8;
+  const size_t per_b = size_t(Ho) * Wo * kC;
+  const size_t xo = size_t(2 * ho + (cc >> 1)) * W + 2 * wo + (cc & 1);   // this thread's pixel of the window (for Xbar)
+  auto one = [&](int b) {
+    const uint4 gv = *reinterpret_cast<const uint4*>(a.dyp + size_t(b) * per_b + po);
+    const uint2 ix = *reinterpret_cast<const uint2*>(a.idx + size_t(b) * per_b + po);
+    const float xv = a.x[size_t(b) * H * W + xo];
+    float d[8];
+    if (a.drop) {
+      const float4 d0 = *reinterpret_cast<const float4*>(a.drop + size_t(b) * kC + cc * 8);
+      const float4 d1 = *reinterpret_cast<const float4*>(a.drop + size_t(b) * kC + cc * 8 + 4);
+      d[0] = d0.x; d[1] = d0.y; d[2] = d0.z; d[3] = d0.w; d[4] = d1.x; d[5] = d1.y; d[6] = d1.z; d[7] = d1.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d[e] = 1.f;
+    }
+    const bf16x8 gq = __builtin_bit_cast(bf16x8, gv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const unsigned k = ((e < 4 ? ix.x : ix.y) >> (8 * (e & 3))) & 0xFFu;
+      const float v = float(gq[e]) * d[e];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q][e] += k == unsigned(q) ? v : 0.f;
+    }
+    xs += xv;
+  };
+  int b = b0;
+  for (; b + 1 < b1; b += 2) {   // two samples' loads in flight
+    one(b);
+    one(b + 1);
+  }
+  if (b < b1) one(b);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float* o = a.dpart + ((size_t(grp) * H + 2 * ho + (q >> 1)) * W + 2 * wo + (q & 1)) * kC + cc * 8;
+    *reinterpret_cast<float4*>(o) = make_float4(acc[q][0], acc[q][1], acc[q][2], acc[q][3]);
+    *reinterpret_cast<float4*>(o + 4) = make_float4(acc[q][4], acc[q][5], acc[q][6], acc[q][7]);
+  }
+  a.xpart[size_t(grp) * H * W + xo] = xs;
+}
+
+struct C1DsumApplyArgs {
+  const float* dpart;   // [NG][H][W][32]
+  const float* xpart;   // [NG][H][W]
+  const float* w;       // [32][25] fp32
+  const float *gamma, *invstd;
+  const float* coef;    // the 25 class kernels of sept_conv1_dense_coef_kernel
+  float* dxsum;         // [H][W]
+  int B, H, W, NG, rows;   // rows: image rows per workgroup
+};
+
+__global__ __launch_bounds__(256) void sept_conv1_dsum_apply_kernel(C1DsumApplyArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int H = a.H, W = a.W, W4 = W + 4, W8 = W + 8, tid = threadIdx.x;
+  float* Dt = reinterpret_cast<float*>(smem);                       // [a.rows + 4][W4][kDsumPS]
+  float* Xt = Dt + size_t(a.rows + 4) * W4 * kDsumPS;            // [a.rows + 8][W8]
+  float* ks = Xt + size_t(a.rows + 8) * W8;                      // [25][kCoefStride]
+  float* wsm = ks + kCoefClasses * kCoefStride;                     // [25][32]: sc_c * w[c][t]
+  const int r0 = blockIdx.x * a.rows;
+  const size_t HW = size_t(H) * W;
+  for (int i = tid; i < (a.rows + 4) * W4 * 8; i += 256) {
+    const int c4 = i & 7, px = i >> 3;
+    const int row = px / W4, col = px - row * W4;
+    const int h = r0 - 2 + row, w0 = col - 2;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (h >= 0 && h < H && w0 >= 0 && w0 < W) {
+      const float* src = a.dpart + (size_t(h) * W + w0) * kC + c4 * 4;
+      for (int g = 0; g < a.NG; ++g) {
+        const float4 t = *reinterpret_cast<const float4*>(src + size_t(g) * HW * kC);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+      }
+    }
+    *reinterpret_cast<float4*>(Dt + size_t(px) * kDsumPS + c4 * 4) = v;
+  }
+  for (int i = tid; i < (a.rows + 8) * W8; i += 256) {
+    const int row = i / W8, col = i - row * W8;
+    const int h = r0 - 4 + row, w0 = col - 4;
+    float v = 0.f;
+    if (h >= 0 && h < H && w0 >= 0 && w0 < W)
+      for (int g = 0; g < a.NG; ++g) v += a.xpart[size_t(g) * HW + size_t(h) * W + w0];
+    Xt[i] = v;
+  }
+  for (int i = tid; i < kCoefClasses * kCoefStride; i += 256) ks[i] = a.coef[i];
+  for (int i = tid; i < kTaps * kC; i += 256) {
+    const int t = i / kC, c = i - t * kC;
+    wsm[i] = a.gamma[c] * a.invstd[c] * a.w[c * kTaps + t];
+  }
+  __syncthreads();
+  for (int p = tid; p < a.rows * W; p += 256) {
+    const int hr = p / W, w0 = p - hr * W, h = r0 + hr;
+    if (h >= H) continue;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+#pragma unroll 1
+    for (int kh = 0; kh < 5; ++kh)
+#pragma unroll 1
+      for (int kw = 0; kw < 5; ++kw) {
+        const float* dp = Dt + (size_t(hr + 4 - kh) * W4 + (w0 + 4 - kw)) * kDsumPS;
+        const float* wp = wsm + (kh * 5 + kw) * kC;
+#pragma unroll
+        for (int c = 0; c < kC; c += 4) {
+          const float4 dv = *reinterpret_cast<const float4*>(dp + c), wv = *reinterpret_cast<const float4*>(wp + c);
+          acc0 = fmaf(dv.x, wv.x, acc0);
+          acc1 = fmaf(dv.y, wv.y, acc1);
+          acc2 = fmaf(dv.z, wv.z, acc2);
+          acc3 = fmaf(dv.w, wv.w, acc3);
+        }
+      }
+    const float* kc = ks + (border_class(h, H) * 5 + border_class(w0, W)) * kCoefStride;
+    float dn = float(a.B) * kc[kCoefConst];
+#pragma unroll 1
+    for (int ur = 0; ur < 9; ++ur)
+#pragma unroll
+      for (int uc = 0; uc < 9; ++uc) dn = fmaf(kc[ur * 12 + uc], Xt[(hr + ur) * W8 + w0 + uc], dn);
+    a.dxsum[size_t(h) * W + w0] = ((acc0 + acc1) + (acc2 + acc3)) + dn;
+  }
+}
+
 // coef: kCoefFloats floats of workspace (overwritten).  sums / n_total as for sept_conv1_backward_data_bn; idx_u8 from
 // sept_bn_relu_pool_forward_argmax.  H, W even, W a multiple of 4 and <= 128.
 extern "C" int sept_conv1_backward_data_sparse(const void* dy_pooled, const void* idx_u8, const float* x, const float* w_f32,
@@ -1854,4 +2222,39 @@ extern "C" int sept_conv1_backward_data_sparse(const void* dy_pooled, const void
   hipLaunchKernelGGL(sept_conv1_dense_dgrad_kernel, dim3((H + drows - 1) / drows, B), dim3(256), smem_d, st, x, coef, dx, B, H, W,
                      drows, pitch);
   return sept::launch_check("sept_conv1_backward_data_sparse");
+}
+
+// sum_b dL/dx_b for a pool-first block 1 (see sept_conv1_dsum_partial_kernel): dxsum (H, W) fp32.
+// ws: sept_conv1_dsum_workspace_floats(H, W) floats; coef: SEPT_CONV1_COEF_FLOATS floats (overwritten).
+extern "C" size_t sept_conv1_dsum_workspace_floats(int H, int W) { return size_t(kDsumGroups) * H * W * (kC + 1); }
+
+extern "C" int sept_conv1_backward_data_sum(const void* dy_pooled, const void* idx_u8, const float* x, const float* w_f32,
+                                            const float* bias, const float* mean, const float* invstd, const float* gamma,
+                                            const float* dropscale, const float* sums, double n_total, float* ws, float* coef,
+                                            float* dxsum, int B, int H, int W, void* stream) {
+  if (int e = conv1_check("sept_conv1_backward_data_sum", B, H, W)) return e;
+  SEPT_REQUIRE(B > 0 && dy_pooled && idx_u8 && x && w_f32 && mean && invstd && gamma && sums && ws && coef && dxsum && n_total > 0,
+               SEPT_ERR_INVALID, "sept_conv1_backward_data_sum: null argument / empty batch");
+  SEPT_REQUIRE(H % 2 == 0 && W % 2 == 0 && H >= 4 && W >= 8, SEPT_ERR_UNSUPPORTED,
+               "sept_conv1_backward_data_sum: H=%d W=%d (needs even H >= 4 and even W >= 8)", H, W);
+  int rows = 4;   // image rows per workgroup of the apply kernel: as many as the staged tile of D leaves room for
+  auto smem_for = [&](int r) {
+    return sizeof(float) * (size_t(r + 4) * (W + 4) * kDsumPS + size_t(r + 8) * (W + 8) + size_t(kCoefClasses) * kCoefStride +
+                            size_t(kTaps) * kC);
+  };
+  while (rows > 1 && smem_for(rows) > 150 * 1024) rows /= 2;
+  const size_t smem = smem_for(rows);
+  SEPT_REQUIRE(smem <= 160 * 1024, SEPT_ERR_UNSUPPORTED, "sept_conv1_backward_data_sum: W=%d needs %zu B of LDS", W, smem);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(sept_conv1_dense_coef_kernel, dim3(kCoefClasses), dim3(256), 0, st, w_f32, bias, mean, invstd, gamma, sums,
+                     float(1.0 / n_total), coef);
+  const int NG = std::min(kDsumGroups, B);
+  float* dpart = ws;
+  float* xpart = ws + size_t(kDsumGroups) * H * W * kC;
+  C1DsumArgs p{static_cast<const bf16*>(dy_pooled), static_cast<const unsigned char*>(idx_u8), x, dropscale, dpart, xpart, B, H, W, NG};
+  hipLaunchKernelGGL(sept_conv1_dsum_partial_kernel, dim3(((H / 2) * (W / 2) * 4 + 255) / 256, NG), dim3(256), 0, st, p);
+  C1DsumApplyArgs q{dpart, xpart, w_f32, gamma, invstd, coef, dxsum, B, H, W, NG, rows};
+  SEPT_HIP(sept::allow_max_lds(reinterpret_cast<const void*>(&sept_conv1_dsum_apply_kernel)));
+  hipLaunchKernelGGL(sept_conv1_dsum_apply_kernel, dim3((H + rows - 1) / rows), dim3(256), smem, st, q);
+  return sept::launch_check("sept_conv1_backward_data_sum");
 }

@@ -416,15 +416,35 @@ def grad_out_pair(p_fwd, p_rev):
     return fp.grad[off:off + 2 * n].view((2 * p_fwd.shape[0],) + tuple(p_fwd.shape[1:]))
 
 
+def zero_bias_grad(bias):
+    """The gradient of a conv bias that feeds straight into a training-mode BatchNorm: the BatchNorm's backward has zero
+    channel sum by construction, so d(bias) == 0 exactly (the reference gets fp32 summation noise around it).  Returns the
+    parameter's slot in the flat gradient buffer -- zero since the buffer was packed, written by nobody else, so no launch
+    is needed after the first one -- or a fresh zero tensor for a parameter without a slot."""
+    slot = getattr(bias, "_sept_flat", None)
+    if slot is None or not bias.requires_grad:
+        return ops.fill(torch.empty_like(bias), 0.0)
+    fp, off, n = slot
+    view = fp.grad[off:off + n].view(bias.shape)
+    clean = fp.__dict__.setdefault("_zero_slots", set())
+    if off not in clean or torch.cuda.is_current_stream_capturing():
+        # (inside a capture the fill is recorded: a replay then does not depend on what ran before it)
+        ops.fill(view, 0.0)
+        clean.add(off)
+    return view
+
+
 def _into(out, src):
     """src copied into the flat slot `out` when there is one"""
     return src if out is None else ops.copy_into(out, src.contiguous())
 
 
-def trunk_backward(S, P, dlogits, need_wgrad=True, need_dx=True):
+def trunk_backward(S, P, dlogits, need_wgrad=True, need_dx=True, sum_dx=False):
     """Returns (dx (B,H,W) fp32 or None, grads: dict parameter-tensor-id -> gradient) for one
     network.  With need_wgrad False (frozen model) only the data path is evaluated.  Weight gradients are
-    written straight into the flat gradient buffer of the trainer that owns the parameters (grad_out)."""
+    written straight into the flat gradient buffer of the trainer that owns the parameters (grad_out).
+    sum_dx: the caller only needs the input gradient SUMMED over the batch (the cloak's backward pass: its parameters are
+    shared by every sample) -- dx may then come back as (1,H,W), formed without any per-sample pass (pool-first block 1)."""
     B, T = S.B, S.T
     grads = {}
     gout = grad_out if need_wgrad else (lambda p: None)
@@ -451,7 +471,7 @@ def trunk_backward(S, P, dlogits, need_wgrad=True, need_dx=True):
                 put(P.dense1.weight, ops.linear_backward_weight(d_d1, S.z, out=gout(P.dense1.weight)))
                 put(P.dense1.bias, ops.colsum(d_d1, out=gout(P.dense1.bias)))
             sq.small(head_wgrads, dlogits, d_d1, S.d1a, S.z)
-        return _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq, gout)
+        return _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq, gout, sum_dx)
     d_d1a, c0 = None, 0
     for h in P.heads:
         n = h.weight.shape[0]
@@ -491,7 +511,7 @@ def trunk_backward(S, P, dlogits, need_wgrad=True, need_dx=True):
         ops.gemm_raw(d_a1, d_a1.stride(0), 1, w1, w1.shape[1], 1, dout, H2, B * T, H2, w1.shape[0], beta=1.0)
     else:
         dout = ops.mean_t_backward(dz, T) if S.pooling == "mean" else dz.view(B, T, H2)
-    return _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq, gout)
+    return _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq, gout, sum_dx)
 
 
 # Weight gradients are off the critical path of the backward pass (nothing downstream reads them until
@@ -534,10 +554,33 @@ L1_SPARSE = os.environ.get("SEPT_L1_SPARSE", "1") != "0"
 L1_POOL_FIRST = os.environ.get("SEPT_L1_POOL_FIRST", "1") != "0"
 
 
+# ... also for a network whose conv1 is TRAINED (its weight gradient from the pooled gradient, the position bytes and the 26 x 26
+# Gram matrix of the input patches: sept_conv1_backward_weight_sparse).  SEPT_L1_POOL_TRAIN=0: only where conv1 is frozen
+L1_POOL_TRAINABLE = os.environ.get("SEPT_L1_POOL_TRAIN", "1") != "0"
+
+
+# the cloak step only needs the input gradient summed over the batch: a pool-first block 1 forms that sum without any
+# per-sample data-gradient pass (sept_conv1_backward_data_sum).  SEPT_L1_DX_SUM=0: per-sample gradients, summed by the cloak kernel
+L1_DX_SUM = os.environ.get("SEPT_L1_DX_SUM", "1") != "0"
+
+
+def batch_sum_pair(dx1, dx2):
+    """the two branches' input gradients as equally shaped (rows, n) matrices for sept_cloak_backward: when one of them is
+    already summed over the batch (1 row) and the other is not, the other is summed too (one column-sum launch pair)"""
+    a, b = dx1.view(dx1.shape[0], -1), (None if dx2 is None else dx2.view(dx2.shape[0], -1))
+    if b is None or a.shape[0] == b.shape[0]:
+        return a, b
+    if a.shape[0] != 1:
+        a = ops.colsum(a.contiguous()).view(1, -1)
+    if b.shape[0] != 1:
+        b = ops.colsum(b.contiguous()).view(1, -1)
+    return a, b
+
+
 def _pool_first_backward_ok(cv, need_grad):
-    """the pool-first form has a backward pass for a conv1 without weight gradient (the frozen emotion network: sparse data
-    gradient from the pooled gradient + position bytes + input); a trainable conv1 still needs its stored output"""
-    return not need_grad or not cv.weight.requires_grad
+    """the pool-first form has a backward pass without conv1's stored output: always the sparse data gradient; the weight
+    gradient of a trainable conv1 through sept_conv1_backward_weight_sparse (L1_POOL_TRAINABLE)"""
+    return not need_grad or not cv.weight.requires_grad or L1_POOL_TRAINABLE
 
 
 # BatchNorm statistics of the 5x5 conv layers from the conv kernel's epilogue (SEPT_CONV_STATS=0: a separate pass)
@@ -672,7 +715,7 @@ def _run_tail_wgrads(device):
         _TAIL_WGRADS["ran"] += 1
 
 
-def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq, gout):
+def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq, gout, sum_dx=False):
     """The recurrent layers and the conv stack of trunk_backward, from the gradient of the last recurrent output."""
     B, T = S.B, S.T
     Hh = S.Hh
@@ -743,7 +786,17 @@ def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq, go
             if want_bn:
                 put(bn.weight, dgamma)
                 put(bn.bias, dbeta)
-            if need_dx:
+            if need_wgrad and cv.weight.requires_grad:
+                dw, _ = sq.big(lambda dact=dact, sums=sums: ops.conv1_backward_weight_from_sums(
+                    S.x, dact, blk.idx, sums, blk.mean, blk.invstd, bn.weight, blk.drop, cv.weight, cv.bias, need_bias=False,
+                    out_w=gout(cv.weight)), dact, sums, S.x, blk.idx)
+                put(cv.weight, dw)
+                if cv.bias is not None:
+                    put(cv.bias, zero_bias_grad(cv.bias))
+            if need_dx and sum_dx and L1_DX_SUM:
+                dx = ops.conv1_backward_data_sum(S.x, dact, blk.idx, sums, blk.mean, blk.invstd, bn.weight, blk.drop,
+                                                 cv.weight, cv.bias)
+            elif need_dx:
                 dx = ops.conv1_backward_data_from_sums(S.x, dact, blk.idx, sums, blk.mean, blk.invstd, bn.weight, blk.drop,
                                                        cv.weight, cv.bias, prep=_conv1_operand(cv))
             continue
@@ -773,10 +826,11 @@ def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq, go
                 put(bn.weight, dgamma)
                 put(bn.bias, dbeta)
             if want_w:
-                dw, db = sq.big(lambda dpre=dpre: ops.conv1_backward_weight(S.x, dpre, out_w=gout(cv.weight),
-                                                                            out_b=gout(cv.bias)), dpre, S.x)
+                dw, _ = sq.big(lambda dpre=dpre: ops.conv1_backward_weight(S.x, dpre, need_bias=False, out_w=gout(cv.weight)),
+                               dpre, S.x)
                 put(cv.weight, dw)
-                put(cv.bias, db)
+                if cv.bias is not None:     # in front of a training-mode BatchNorm: exactly zero (see zero_bias_grad)
+                    put(cv.bias, zero_bias_grad(cv.bias))
             continue
         if blk.l1_fused:
             dpre, dgamma, dbeta = ops.conv1_bn_relu_pool_backward(S.x, cv.weight, cv.bias, dact, blk.mean, blk.invstd,
@@ -802,10 +856,11 @@ def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq, go
             put(bn.bias, dbeta)
         if li == 0:
             if need_wgrad and cv.weight.requires_grad:
-                dw, db = sq.big(lambda dpre=dpre: ops.conv1_backward_weight(S.x, dpre, out_w=gout(cv.weight),
-                                                                            out_b=gout(cv.bias)), dpre, S.x)
+                dw, _ = sq.big(lambda dpre=dpre: ops.conv1_backward_weight(S.x, dpre, need_bias=False, out_w=gout(cv.weight)),
+                               dpre, S.x)
                 put(cv.weight, dw)
-                put(cv.bias, db)
+                if cv.bias is not None:     # in front of a training-mode BatchNorm: exactly zero (see zero_bias_grad)
+                    put(cv.bias, zero_bias_grad(cv.bias))
             if need_dx:
                 dx = ops.conv1_backward_data(dpre, cv.weight, prep=_conv1_operand(cv))
         else:
@@ -826,10 +881,8 @@ def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq, go
                     put(cv.weight, sq.big(lambda blk=blk, dpre=dpre: ops.conv5x5_backward_weight(blk.inp, dpre,
                                                                                                  out=gout(cv.weight)),
                                           dpre, blk.inp))
-                # the conv bias feeds straight into a training-mode BatchNorm, whose backward has
-                # zero channel sum by construction: d(bias) == 0 (the reference gets rounding noise)
-                ob = gout(cv.bias)
-                put(cv.bias, ops.fill(ob if ob is not None else torch.empty_like(cv.bias), 0.0))
+                if cv.bias is not None:
+                    put(cv.bias, zero_bias_grad(cv.bias))
             wtd = _cached("convdgrad", cv.weight, lambda: ops.conv5x5_prep_weights(cv.weight, 1))
             prev = S.blocks[li - 1]
             if prev.ext is not None:
@@ -1011,14 +1064,14 @@ class GrlPairFn(torch.autograd.Function):
             try:
                 if _BWD_ORDER == 1:
                     with torch.cuda.stream(s1):
-                        dx1, g1 = trunk_backward(S1, P1, d1, need_wgrad=ctx.need_w[0], need_dx=need_dx)
+                        dx1, g1 = trunk_backward(S1, P1, d1, need_wgrad=ctx.need_w[0], need_dx=need_dx, sum_dx=True)
                     with torch.cuda.stream(s2):
-                        dx2, g2 = trunk_backward(S2, P2, d2, need_wgrad=ctx.need_w[1], need_dx=need_dx)
+                        dx2, g2 = trunk_backward(S2, P2, d2, need_wgrad=ctx.need_w[1], need_dx=need_dx, sum_dx=True)
                 else:
                     with torch.cuda.stream(s2):    # the gender branch first: its recurrent chain is the critical path
-                        dx2, g2 = trunk_backward(S2, P2, d2, need_wgrad=ctx.need_w[1], need_dx=need_dx)
+                        dx2, g2 = trunk_backward(S2, P2, d2, need_wgrad=ctx.need_w[1], need_dx=need_dx, sum_dx=True)
                     with torch.cuda.stream(s1):
-                        dx1, g1 = trunk_backward(S1, P1, d1, need_wgrad=ctx.need_w[0], need_dx=need_dx)
+                        dx1, g1 = trunk_backward(S1, P1, d1, need_wgrad=ctx.need_w[0], need_dx=need_dx, sum_dx=True)
             finally:
                 _DEFERRED["on"] = prev
             cur.wait_stream(s1)
@@ -1033,15 +1086,15 @@ class GrlPairFn(torch.autograd.Function):
         else:
             _DEFERRED["on"] = False
             try:
-                dx2, g2 = trunk_backward(S2, P2, d2, need_wgrad=ctx.need_w[1], need_dx=need_dx)
-                dx1, g1 = trunk_backward(S1, P1, d1, need_wgrad=ctx.need_w[0], need_dx=need_dx)
+                dx2, g2 = trunk_backward(S2, P2, d2, need_wgrad=ctx.need_w[1], need_dx=need_dx, sum_dx=True)
+                dx1, g1 = trunk_backward(S1, P1, d1, need_wgrad=ctx.need_w[0], need_dx=need_dx, sum_dx=True)
             finally:
                 _DEFERRED["on"] = prev
         ctx.S = None
         dlocs = drhos = None
         if need_dx:
-            B = dx1.shape[0]
-            dlocs, drhos = ops.cloak_backward(dx1.view(B, -1), dx2.view(B, -1), -float(lam), rhos.detach(), eps, mask,
+            da, db_ = batch_sum_pair(dx1, dx2)
+            dlocs, drhos = ops.cloak_backward(da, db_, -float(lam), rhos.detach(), eps, mask,
                                               smin, smax, need_locs=ctx.need_cloak[0], need_rhos=ctx.need_cloak[1],
                                               out_locs=grad_out(locs) if ctx.need_cloak[0] else None,
                                               out_rhos=None)   # rhos may get a second term (scale loss): autograd adds
@@ -1142,7 +1195,7 @@ def grl_train_step(model, x, labels_emo, labels_gen, weights, gender_lambda, sca
             d = ops.cross_entropy(logits, labels, weights, coef / B, loss_slot)
             if with_scale and scale_mean is not None:
                 ops.loss_sub_log(loss_slot, scale_mean, float(scale_lamda))
-            r = trunk_backward(S, P, d, need_wgrad=need_w, need_dx=need_dx) if (need_w or need_dx) else (None, {})
+            r = trunk_backward(S, P, d, need_wgrad=need_w, need_dx=need_dx, sum_dx=True) if (need_w or need_dx) else (None, {})
             ops.stamp(tag + " backward done")
             return r
 
@@ -1216,7 +1269,8 @@ def grl_train_step(model, x, labels_emo, labels_gen, weights, gender_lambda, sca
                 _DEFERRED["on"] = prev
             (l1, dx1, g1), (l2, dx2, g2) = res[s1], res[s2]
         if need_dx:
-            dlocs, drhos = ops.cloak_backward(dx1.view(B, -1), dx2.view(B, -1), -lam, rhos.detach(), eps, m, smin, smax,
+            da, db_ = batch_sum_pair(dx1, dx2)
+            dlocs, drhos = ops.cloak_backward(da, db_, -lam, rhos.detach(), eps, m, smin, smax,
                                               scale_lambda=float(scale_lamda) if scale_mean is not None else 0.0,
                                               scale_mean=scale_mean, need_locs=locs.requires_grad,
                                               need_rhos=rhos.requires_grad,
@@ -1343,7 +1397,8 @@ def grl_train_step_segmented(sched, model, x, labels_emo, labels_gen, weights, g
                 prev = _DEFERRED["on"]
                 _DEFERRED["on"] = WGRAD_STREAM      # small weight gradients fork inside this segment ...
                 try:
-                    r = trunk_backward(S, P, d, need_wgrad=need_w, need_dx=need_dx) if (need_w or need_dx) else (None, {})
+                    r = trunk_backward(S, P, d, need_wgrad=need_w, need_dx=need_dx, sum_dx=True) if (need_w or need_dx) \
+                        else (None, {})
                 finally:
                     _DEFERRED["on"] = prev
                 here = torch.cuda.current_stream(dev)
@@ -1357,7 +1412,8 @@ def grl_train_step_segmented(sched, model, x, labels_emo, labels_gen, weights, g
         def last():         # main
             (l1, dx1, g1), (l2, dx2, g2) = st.r1, st.r2
             if need_dx:
-                dlocs, drhos = ops.cloak_backward(dx1.view(st.B, -1), dx2.view(st.B, -1), -lam, rhos.detach(), st.eps, m, smin,
+                da, db_ = batch_sum_pair(dx1, dx2)
+                dlocs, drhos = ops.cloak_backward(da, db_, -lam, rhos.detach(), st.eps, m, smin,
                                                   smax, scale_lambda=float(scale_lamda) if st.scale_mean is not None else 0.0,
                                                   scale_mean=st.scale_mean, need_locs=locs.requires_grad,
                                                   need_rhos=rhos.requires_grad,

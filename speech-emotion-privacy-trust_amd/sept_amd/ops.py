@@ -556,6 +556,41 @@ def conv1_backward_data_from_sums(x, dy, idx, sums, mean, invstd, gamma, dropsca
     return dx
 
 
+def conv1_backward_data_sum(x, dy, idx, sums, mean, invstd, gamma, dropscale, w, bias):
+    """sum over the batch of block 1's input gradient, (1, H, W) fp32 -- what the cloak's backward pass consumes
+    (include/sept.h, sept_conv1_backward_data_sum): one streaming reduction over the pooled gradient + position bytes +
+    input, then single-image kernels."""
+    require_cuda(x, dy, idx, w)
+    B, H, W = x.shape
+    ws = workspace("conv1_dsum", lib.sept_conv1_dsum_workspace_floats(H, W), x.device)
+    coef = torch.empty(2800, dtype=torch.float32, device=x.device)
+    dxs = torch.empty((1, H, W), dtype=torch.float32, device=x.device)
+    wf = w.detach().contiguous()
+    check(lib.sept_conv1_backward_data_sum(dy.data_ptr(), idx.data_ptr(), x.data_ptr(), wf.data_ptr(), _p(bias), mean.data_ptr(),
+                                           invstd.data_ptr(), gamma.data_ptr(), _p(dropscale), sums.data_ptr(),
+                                           float(B) * H * W, ws.data_ptr(), coef.data_ptr(), dxs.data_ptr(), B, H, W, _s(x)),
+          "sept_conv1_backward_data_sum")
+    return dxs
+
+
+def conv1_backward_weight_from_sums(x, dy, idx, sums, mean, invstd, gamma, dropscale, w, bias, need_bias=True, out_w=None,
+                                    out_b=None):
+    """conv1's weight (and bias) gradient for a pool-first block 1, from the pooled gradient dy, the position bytes idx,
+    the input x and the two channel sums (sept_conv1_backward_weight_sparse): sparse part on the MFMA weight-gradient
+    product with rows expanded in its loader, dense part from the 26 x 26 Gram matrix of the input patches."""
+    require_cuda(x, dy, idx, w)
+    B, H, W = x.shape
+    ws = workspace("conv1_wgrad_sparse", lib.sept_conv1_wgrad_sparse_workspace_floats(), x.device)
+    dw = torch.empty((32, 1, 5, 5), dtype=torch.float32, device=x.device) if out_w is None else out_w
+    db = (torch.empty(32, dtype=torch.float32, device=x.device) if out_b is None else out_b) if need_bias else None
+    wf = w.detach().contiguous()
+    check(lib.sept_conv1_backward_weight_sparse(dy.data_ptr(), idx.data_ptr(), x.data_ptr(), wf.data_ptr(), _p(bias),
+                                                mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), _p(dropscale),
+                                                sums.data_ptr(), float(B) * H * W, ws.data_ptr(), dw.data_ptr(), _p(db),
+                                                B, H, W, _s(x)), "sept_conv1_backward_weight_sparse")
+    return dw, db
+
+
 def conv5x5_backward_weight(x, dy, out=None):
     """x (B,H,W,cin) bf16, dy (B,H,W,cout) bf16 -> dW (cout,cin,5,5) fp32."""
     require_cuda(x, dy)

@@ -79,6 +79,7 @@ class FlatParams:
         self.n_active = getattr(self, "n_active", self.numel)
         flat = torch.empty(self.numel, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        self._zero_slots = set()     # functional.zero_bias_grad: slots known to hold zeros since this packing
         off = 0
         self.views = []
         for p in self.params:

@@ -376,6 +376,30 @@ def test_block1_pool_first_equals_the_stored_tensor_path(B, H, W, drop):
         dpre_t, _, _ = ops.bn_relu_pool_backward(dy, pre, mean, invstd, gamma, beta, dmask, 2)
         hip_dx = ops.conv1_backward_data(dpre_t, w)
         assert float((dx - hip_dx).norm() / hip_dx.norm()) < 8e-3
+        # ---- weight gradient: sparse product + Gram-matrix dense part vs (a) the stored-tensor passes, (b) torch autograd
+        # in fp32 through BatchNorm (batch statistics) / ReLU / MaxPool / Dropout2d on the stored bf16 pre-activations ----
+        import torch.nn.functional as Fn
+        dw, db = ops.conv1_backward_weight_from_sums(x, dy, idx, sums, mean, invstd, gamma, dmask, w, bias)
+        dw_old, db_old = ops.conv1_backward_weight(x, dpre_t)
+        pr = pre.float().permute(0, 3, 1, 2).contiguous().requires_grad_()
+        out = Fn.max_pool2d(Fn.relu(Fn.batch_norm(pr, None, None, gamma, beta, training=True, eps=1e-5)), 2)
+        if dmask is not None:
+            out = out * dmask[:, :, None, None]
+        out.backward(dy.float().permute(0, 3, 1, 2))
+        ref_dw = torch.nn.grad.conv2d_weight(x[:, None], (32, 1, 5, 5), pr.grad, padding=2)
+        e_new = float((dw - ref_dw).norm() / ref_dw.norm())
+        e_old = float((dw_old - ref_dw).norm() / ref_dw.norm())
+        assert e_new < 1e-2, (e_new, e_old)
+        # ---- the input gradient summed over the batch (all the cloak's backward needs), formed without a per-sample pass ----
+        ref_dxs = torch.nn.grad.conv2d_input((B, 1, H, W), w, pr.grad, padding=2)[:, 0].sum(0)
+        dxs = ops.conv1_backward_data_sum(x, dy, idx, sums, mean, invstd, gamma, dmask, w, bias)
+        assert dxs.shape == (1, H, W)
+        e_sum = float((dxs[0] - ref_dxs).norm() / ref_dxs.norm())
+        e_per = float((dx.sum(0) - ref_dxs).norm() / ref_dxs.norm())
+        assert e_sum < 2e-3 and e_sum <= e_per + 1e-4, (e_sum, e_per)     # fp32 weights, no bf16 rounding of scd * g
+        assert float((dw - dw_old).norm() / dw_old.norm()) < 1.5e-2
+        # the bias gradient of a conv in front of a train-mode BatchNorm vanishes: rounding noise only
+        assert float(db.abs().max()) < 2e-2 * float(ref_dw.abs().max()) * 25
 
 
 @pytest.mark.parametrize("B,H,W,cin,cout", [(3, 100, 40, 64, 32), (2, 50, 20, 128, 64)])
