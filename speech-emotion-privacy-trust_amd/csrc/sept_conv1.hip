@@ -1001,11 +1001,17 @@ struct C1WgSparseArgs {
   int B, H, W;
 };
 
+// A tile is FOUR image rows (two rows of pooling windows) of one image, so a (window, 8-channel chunk) is expanded once, by
+// one thread, into its four pixels' dy chunks: bf16(g * drop) is formed once and selected four times -- the first version
+// tiled 256 flattened pixels and every pixel chunk re-did the whole expansion (and re-loaded g and the position bytes):
+// 3x the VALU work per pixel, 142 us.  NSW = 16-pixel steps per wave and tile = W / 16.
+template <int NSW>
 __global__ __launch_bounds__(256, 3) void sept_conv1_wgrad_sparse_kernel(C1WgSparseArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int H = a.H, W = a.W, HW = H * W, W4 = W + 4, Ho = H / 2, Wo = W / 2;
-  float* xt = reinterpret_cast<float*>(smem);
-  unsigned char* yt = smem + ((sizeof(float) * nr_max(W) * W4 + 15) & ~size_t(15));
+  const int H = a.H, W = a.W, W4 = W + 4, Ho = H / 2, Wo = W / 2;
+  constexpr int PT = 64 * NSW;          // pixels per tile = 4 * W
+  float* xt = reinterpret_cast<float*>(smem);                                    // [8][W4]
+  unsigned char* yt = smem + ((sizeof(float) * 8 * W4 + 15) & ~size_t(15));      // [PT][kDyPSt]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tap = lane & 31, k_hi = lane >> 5;
   const int tapoff = tap < kTaps ? (tap / 5) * W4 + (tap % 5) : 0;
@@ -1014,25 +1020,26 @@ __global__ __launch_bounds__(256, 3) void sept_conv1_wgrad_sparse_kernel(C1WgSpa
   f32x16 acc, ghh, glh;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = ghh[r] = glh[r] = 0.f;
-  const int tiles_per_img = (HW + kMT - 1) / kMT;
+  const int tiles_per_img = (H + 3) / 4;
   const long n_tiles = long(a.B) * tiles_per_img;
-  const float inv_w = 1.0f / float(W);
-  // the pooled gradient / position bytes of the NEXT tile are fetched into registers while the current one is computed
-  // on (unconditional, clamped addresses); a thread's four chunks share its channel group cc = tid & 3
-  constexpr int NY = kMT * 4 / 256;
+  constexpr int NI = (PT + 255) / 256;   // (window, chunk) items per thread and tile
   const int cc = tid & 3;
-  uint4 gr[NY];
-  uint2 ir[NY];
+  uint4 gr[NI];
+  uint2 ir[NI];
   float dsc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) dsc[e] = 1.0f;
   const long tile_end = n_tiles * (blockIdx.x + 1) / gridDim.x;
+  // item i of a tile: chunk cc = i & 3 of window (i >> 2): window row rp = win / Wo (0 or 1), column wo = win % Wo
   auto fetch = [&](long tile_id) {
     const long tc = min(tile_id, n_tiles - 1);
-    const int b = int(tc / tiles_per_img), q0 = int(tc % tiles_per_img) * kMT;
+    const int b = int(tc / tiles_per_img), tl = int(tc % tiles_per_img);
 #pragma unroll
-    for (int j = 0; j < NY; ++j) {
-      const int q = min(q0 + ((tid + 256 * j) >> 2), HW - 1);
-      const int h = int((float(q) + 0.5f) * inv_w), w = q - h * W;
-      const size_t o = ((size_t(b) * Ho + (h >> 1)) * Wo + (w >> 1)) * kC + cc * 8;
+    for (int j = 0; j < NI; ++j) {
+      const int win = min((tid + 256 * j) >> 2, 2 * Wo - 1);
+      const int rp = win >= Wo ? 1 : 0, wo = win - rp * Wo;
+      const int ho = min(2 * tl + rp, Ho - 1);
+      const size_t o = ((size_t(b) * Ho + ho) * Wo + wo) * kC + cc * 8;
       gr[j] = *reinterpret_cast<const uint4*>(a.dyp + o);
       ir[j] = *reinterpret_cast<const uint2*>(a.idx + o);
     }
@@ -1043,67 +1050,78 @@ __global__ __launch_bounds__(256, 3) void sept_conv1_wgrad_sparse_kernel(C1WgSpa
       dsc[4] = d1.x; dsc[5] = d1.y; dsc[6] = d1.z; dsc[7] = d1.w;
     }
   };
-#pragma unroll
-  for (int e = 0; e < 8; ++e) dsc[e] = 1.0f;
   long tile_id = n_tiles * blockIdx.x / gridDim.x;
   if (tile_id < tile_end) fetch(tile_id);
   for (; tile_id < tile_end; ++tile_id) {
-    const int b = tile_id / tiles_per_img, q0 = int(tile_id % tiles_per_img) * kMT;
-    const int h_first = q0 / W, h_last = min(q0 + kMT - 1, HW - 1) / W;
+    const int b = tile_id / tiles_per_img, tl = int(tile_id % tiles_per_img);
+    const int h0 = 4 * tl;
     __syncthreads();
-    stage_x(a.x + size_t(b) * HW, xt, h_first, h_last - h_first + 5, H, W);
+    stage_x(a.x + size_t(b) * H * W, xt, h0, 8, H, W);      // rows h0 - 2 .. h0 + 5
 #pragma unroll
-    for (int j = 0; j < NY; ++j) {
-      const int t = (tid + 256 * j) >> 2;
-      const int q = q0 + t;
-      const int qc = min(q, HW - 1);
-      const int h = int((float(qc) + 0.5f) * inv_w), w = qc - h * W;
-      const unsigned pos = unsigned(2 * (h & 1) + (w & 1));
-      const bf16x8 gq = __builtin_bit_cast(bf16x8, gr[j]);
-      bf16x8 o;
+    for (int j = 0; j < NI; ++j) {
+      const int i = tid + 256 * j;
+      if (i < PT) {
+        const int win = i >> 2;
+        const int rp = win >= Wo ? 1 : 0, wo = win - rp * Wo;
+        const bool inside = 2 * tl + rp < Ho;
+        const bf16x8 gq = __builtin_bit_cast(bf16x8, gr[j]);
+        bf16x8 o0, o1, o2, o3;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const unsigned k = ((e < 4 ? ir[j].x : ir[j].y) >> (8 * (e & 3))) & 0xFFu;
-        o[e] = (k == pos && q < HW) ? (bf16)(float(gq[e]) * dsc[e]) : (bf16)0.f;
+        for (int e = 0; e < 8; ++e) {
+          const unsigned k = inside ? ((e < 4 ? ir[j].x : ir[j].y) >> (8 * (e & 3))) & 0xFFu : 4u;
+          const bf16 v = (bf16)(float(gq[e]) * dsc[e]), z = (bf16)0.f;
+          o0[e] = k == 0 ? v : z;
+          o1[e] = k == 1 ? v : z;
+          o2[e] = k == 2 ? v : z;
+          o3[e] = k == 3 ? v : z;
+        }
+        unsigned char* base = yt + (size_t(2 * rp) * W + 2 * wo) * kDyPSt + cc * 16;
+        *reinterpret_cast<uint4*>(base) = __builtin_bit_cast(uint4, o0);
+        *reinterpret_cast<uint4*>(base + kDyPSt) = __builtin_bit_cast(uint4, o1);
+        *reinterpret_cast<uint4*>(base + size_t(W) * kDyPSt) = __builtin_bit_cast(uint4, o2);
+        *reinterpret_cast<uint4*>(base + size_t(W + 1) * kDyPSt) = __builtin_bit_cast(uint4, o3);
       }
-      *reinterpret_cast<uint4*>(yt + size_t(t) * kDyPSt + cc * 16) = __builtin_bit_cast(uint4, o);
     }
     fetch(tile_id + 1);      // past the range: re-reads a valid tile, never used
     sept::lds_barrier();     // LDS-only wait: the loads just issued stay in flight across the barrier
-    const int last_q = HW - 8;
-    constexpr int NS = kMT / 64;
-    bf16x8 afrag[NS], bfrag[NS], lfrag[NS];
+    // the steps of a tile in groups of at most four: all operands of a group are requested first, then its MFMAs run
+    // (all NSW steps at once would hold 12 NSW fragment registers: spills from NSW = 5 on at three waves per SIMD)
+    constexpr int GMAX = NSW > 5 ? 2 : 4;   // (two items per thread are prefetched from NSW = 5 on: fewer registers to spare)
 #pragma unroll
-    for (int ks = 0; ks < NS; ++ks) {
-      const int kb = wave * (kMT / 4) + ks * 16;
-      const int ta = kb + 8 * k_hi + tr_q;
-      const bf16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-          (__attribute__((address_space(3))) bf16x4*)(reinterpret_cast<uintptr_t>(yt + size_t(ta) * kDyPSt + tr_ch * 2)));
-      const bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-          (__attribute__((address_space(3))) bf16x4*)(reinterpret_cast<uintptr_t>(yt + size_t(ta + 4) * kDyPSt + tr_ch * 2)));
-      afrag[ks] = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
-      const int qg = q0 + kb + 8 * k_hi;
-      const int q = min(qg, last_q);
-      const int gh = int((float(q) + 0.5f) * inv_w), gw = q - __mul24(gh, W);
-      const float* xp = xt + __mul24(gh - h_first, W4) + gw + tapoff;
-      f32x8 xv;
+    for (int g0 = 0; g0 < NSW; g0 += GMAX) {
+      bf16x8 afrag[GMAX], bfrag[GMAX], lfrag[GMAX];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) xv[e] = xp[e];
-      // pixel groups past the image contribute nothing to the Gram products either (the sparse product is safe through
-      // dy = 0 there, the Gram products have no such factor): zero the whole column
-      const bool live = qg < HW;
+      for (int u = 0; u < GMAX; ++u) {
+        const int ks = g0 + u;
+        if (ks >= NSW) break;
+        const int kb = (wave + 4 * ks) * 16;          // first pixel of this 16-pixel step (within one image row: W % 16 == 0)
+        const int ta = kb + 8 * k_hi + tr_q;
+        const bf16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+            (__attribute__((address_space(3))) bf16x4*)(reinterpret_cast<uintptr_t>(yt + size_t(ta) * kDyPSt + tr_ch * 2)));
+        const bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+            (__attribute__((address_space(3))) bf16x4*)(reinterpret_cast<uintptr_t>(yt + size_t(ta + 4) * kDyPSt + tr_ch * 2)));
+        afrag[u] = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
+        const int r = kb / W, col = kb - r * W + 8 * k_hi;
+        const float* xp = xt + r * W4 + col + tapoff;
+        f32x8 xv;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) xv[e] = !live ? 0.f : (tap < kTaps ? xv[e] : (tap == kTaps ? 1.0f : 0.0f));
-      bfrag[ks] = __builtin_convertvector(xv, bf16x8);
-      f32x8 res = xv - __builtin_convertvector(bfrag[ks], f32x8);
-      lfrag[ks] = __builtin_convertvector(res, bf16x8);
-    }
-    __builtin_amdgcn_sched_barrier(0);
+        for (int e = 0; e < 8; ++e) xv[e] = xp[e];
+        const bool live = h0 + r < H;   // rows past the image add nothing to the Gram products (dy is zero there anyway)
 #pragma unroll
-    for (int ks = 0; ks < NS; ++ks) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[ks], bfrag[ks], acc, 0, 0, 0);
-      ghh = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfrag[ks], bfrag[ks], ghh, 0, 0, 0);
-      glh = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lfrag[ks], bfrag[ks], glh, 0, 0, 0);
+        for (int e = 0; e < 8; ++e) xv[e] = !live ? 0.f : (tap < kTaps ? xv[e] : (tap == kTaps ? 1.0f : 0.0f));
+        bfrag[u] = __builtin_convertvector(xv, bf16x8);
+        const f32x8 res = xv - __builtin_convertvector(bfrag[u], f32x8);
+        lfrag[u] = __builtin_convertvector(res, bf16x8);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < GMAX; ++u) {
+        if (g0 + u >= NSW) break;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[u], bfrag[u], acc, 0, 0, 0);
+        ghh = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfrag[u], bfrag[u], ghh, 0, 0, 0);
+        glh = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lfrag[u], bfrag[u], glh, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   // fixed-order sum of the four waves, three [16][64] slabs per workgroup
@@ -1124,15 +1142,36 @@ __global__ __launch_bounds__(256, 3) void sept_conv1_wgrad_sparse_kernel(C1WgSpa
   for (int i = tid; i < 3072; i += 256) slab[i] = red[i];
 }
 
+// column sums of the [nparts][3072] slab matrix: thread (column e = 64 blockIdx + (tid & 63), part group pg = tid >> 6) adds
+// parts pg, pg + 16, ... with coalesced 256-byte wave loads, eight in flight; the 16 groups meet in LDS in a fixed order
+// (the first version gave every element to one wave whose lanes read 64 different slabs: uncoalesced, 42 us).
 // slab element e = r * 64 + lane of a 32 x 32 accumulator is (row (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), column lane & 31)
-__global__ void sept_conv1_wgrad_sparse_reduce_kernel(const float* ws, int nparts, double* tot) {
-  const int e = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;  // one wave per slab element
-  if (e >= 3072) return;
-  const double s = sept::wave_sum_partials(ws, nparts, size_t(3072), e);
-  if (threadIdx.x & 63) return;
+__global__ __launch_bounds__(1024) void sept_conv1_wgrad_sparse_reduce_kernel(const float* ws, int nparts, double* tot) {
+  __shared__ double part[16][64];
+  const int col = threadIdx.x & 63, pg = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + col;
+  double s0 = 0.0, s1 = 0.0;
+  int p = pg;
+  for (; p + 112 < nparts; p += 128) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = ws[size_t(p + 16 * u) * 3072 + e];
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) {
+      s0 += double(v[u]);
+      s1 += double(v[u + 1]);
+    }
+  }
+  for (; p < nparts; p += 16) s0 += double(ws[size_t(p) * 3072 + e]);
+  part[pg][col] = s0 + s1;
+  __syncthreads();
+  if (pg != 0) return;
+  double s = 0.0;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) s += part[g][col];
   const int which = e >> 10, lane = e & 63, r = (e & 1023) >> 6;
-  const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = lane & 31;
-  tot[which * 1024 + row * 32 + col] = s;     // row-major [3][32][32]: S[c][t], HH[s][t], LH[s][t]
+  const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), cl = lane & 31;
+  tot[which * 1024 + row * 32 + cl] = s;     // row-major [3][32][32]: S[c][t], HH[s][t], LH[s][t]
 }
 
 // dW[c][t] = sc_c S[c][t] + c0_c R[25][t] + c1_c sum_{s <= 25} w~[c][s] R[s][t],  R = HH + LH;   t = 25: the bias gradient
@@ -1141,15 +1180,18 @@ __global__ __launch_bounds__(1024) void sept_conv1_wgrad_sparse_combine_kernel(c
                                                                               const float* gamma, const float* sums, float inv_n,
                                                                               float* dw, float* db) {
   __shared__ double R[32 * 32];
+  __shared__ float wl[kC * kTaps];
   const int c = threadIdx.x >> 5, t = threadIdx.x & 31;
   R[threadIdx.x] = tot[1024 + threadIdx.x] + tot[2048 + threadIdx.x];
+  if (threadIdx.x < kC * kTaps) wl[threadIdx.x] = w[threadIdx.x];
   __syncthreads();
   if (t > kTaps) return;
   const double is = invstd[c], sc = double(gamma[c]) * is;
   const double c1 = -sc * (double(sums[kC + c]) * inv_n) * is;
   const double c0 = -sc * (double(sums[c]) * inv_n) - c1 * double(mean[c]);
   double dot = (bias ? double(bias[c]) : 0.0) * R[kTaps * 32 + t];
-  for (int s2 = 0; s2 < kTaps; ++s2) dot += double(w[c * kTaps + s2]) * R[s2 * 32 + t];
+#pragma unroll 5
+  for (int s2 = 0; s2 < kTaps; ++s2) dot += double(wl[c * kTaps + s2]) * R[s2 * 32 + t];
   const double v = sc * tot[c * 32 + t] + c0 * R[kTaps * 32 + t] + c1 * dot;
   if (t < kTaps)
     dw[c * kTaps + t] = float(v);
@@ -1794,19 +1836,25 @@ extern "C" int sept_conv1_backward_weight_sparse(const void* dy_pooled, const vo
   if (int e = conv1_check("sept_conv1_backward_weight_sparse", B, H, W)) return e;
   SEPT_REQUIRE(B > 0 && dy_pooled && idx_u8 && x && w_f32 && mean && invstd && gamma && sums && ws && dw && n_total > 0,
                SEPT_ERR_INVALID, "sept_conv1_backward_weight_sparse: null argument / empty batch");
-  SEPT_REQUIRE(H % 2 == 0 && W % 8 == 0 && H * W >= 8, SEPT_ERR_UNSUPPORTED,
-               "sept_conv1_backward_weight_sparse: H=%d W=%d (needs an even H and W %% 8 == 0)", H, W);
-  const size_t smem = std::max(((sizeof(float) * size_t(nr_max(W)) * (W + 4) + 15) & ~size_t(15)) + size_t(kMT) * kDyPS,
+  SEPT_REQUIRE(H % 2 == 0 && W % 16 == 0 && W <= 128, SEPT_ERR_UNSUPPORTED,
+               "sept_conv1_backward_weight_sparse: H=%d W=%d (needs an even H and W a multiple of 16 up to 128)", H, W);
+  const size_t smem = std::max(((sizeof(float) * 8 * size_t(W + 4) + 15) & ~size_t(15)) + size_t(4) * W * kDyPSt,
                                sizeof(float) * 3072);
-  SEPT_REQUIRE(smem <= 160 * 1024, SEPT_ERR_UNSUPPORTED, "sept_conv1_backward_weight_sparse: W=%d needs %zu B of LDS", W, smem);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const long n_tiles = long(B) * ((H * W + kMT - 1) / kMT);
-  const int grid = int(std::min<long>(n_tiles, 768));   // three workgroups per CU (167 VGPRs): one resident round
+  const long n_tiles = long(B) * ((H + 3) / 4);
+  const int grid = int(std::min<long>(n_tiles, 768));   // three workgroups per CU: one resident round
   C1WgSparseArgs a{x, static_cast<const bf16*>(dy_pooled), static_cast<const unsigned char*>(idx_u8), dropscale, ws, B, H, W};
-  SEPT_HIP(sept::allow_max_lds(reinterpret_cast<const void*>(&sept_conv1_wgrad_sparse_kernel)));
-  hipLaunchKernelGGL(sept_conv1_wgrad_sparse_kernel, dim3(grid), dim3(256), smem, st, a);
+  switch (W / 16) {
+#define SEPT_WGS_CASE(N)                                                                                              \
+    case N:                                                                                                           \
+      hipLaunchKernelGGL(sept_conv1_wgrad_sparse_kernel<N>, dim3(grid), dim3(256), smem, st, a);                      \
+      break;
+    SEPT_WGS_CASE(1) SEPT_WGS_CASE(2) SEPT_WGS_CASE(3) SEPT_WGS_CASE(4) SEPT_WGS_CASE(5) SEPT_WGS_CASE(6) SEPT_WGS_CASE(7)
+    SEPT_WGS_CASE(8)
+#undef SEPT_WGS_CASE
+  }
   double* tot = reinterpret_cast<double*>(ws + size_t(kWgParts) * 3072);   // 3072 doubles = 2 * 3072 floats, 8-byte aligned
-  hipLaunchKernelGGL(sept_conv1_wgrad_sparse_reduce_kernel, dim3(3072 / 4), dim3(256), 0, st, ws, grid, tot);
+  hipLaunchKernelGGL(sept_conv1_wgrad_sparse_reduce_kernel, dim3(3072 / 64), dim3(1024), 0, st, ws, grid, tot);
   hipLaunchKernelGGL(sept_conv1_wgrad_sparse_combine_kernel, dim3(1), dim3(1024), 0, st, tot, w_f32, bias, mean, invstd, gamma,
                      sums, float(1.0 / n_total), dw, db);
   return sept::launch_check("sept_conv1_backward_weight_sparse");
@@ -2108,80 +2156,108 @@ __global__ __launch_bounds__(256) void sept_conv1_dsum_partial_kernel(C1DsumArgs
   a.xpart[size_t(grp) * H * W + xo] = xs;
 }
 
-struct C1DsumApplyArgs {
+// second stage: D = sc_c * (sum of the batch-group partials), Xbar likewise -- one elementwise pass, so that the apply
+// kernel below stages plain rows (the first version summed the eight partials inside its tile loader: 168 dependent-ish
+// loads per thread in 50 workgroups, 93 us on the critical chain)
+struct C1DsumReduceArgs {
   const float* dpart;   // [NG][H][W][32]
   const float* xpart;   // [NG][H][W]
-  const float* w;       // [32][25] fp32
   const float *gamma, *invstd;
-  const float* coef;    // the 25 class kernels of sept_conv1_dense_coef_kernel
-  float* dxsum;         // [H][W]
-  int B, H, W, NG, rows;   // rows: image rows per workgroup
+  float* D;             // [H][W][32], scaled by sc_c = gamma_c * invstd_c
+  float* X;             // [H][W]
+  int H, W, NG;
 };
 
-__global__ __launch_bounds__(256) void sept_conv1_dsum_apply_kernel(C1DsumApplyArgs a) {
+__global__ __launch_bounds__(256) void sept_conv1_dsum_reduce_kernel(C1DsumReduceArgs a) {
+  const size_t HW = size_t(a.H) * a.W;
+  const size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;     // float4 chunk of D
+  if (i < HW * 8) {
+    const int c4 = int(i & 7);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 t[kDsumGroups];
+#pragma unroll
+    for (int g = 0; g < kDsumGroups; ++g)    // unconditional (clamped) loads, all in flight together
+      t[g] = reinterpret_cast<const float4*>(a.dpart + size_t(min(g, a.NG - 1)) * HW * kC)[i];
+#pragma unroll
+    for (int g = 0; g < kDsumGroups; ++g) {
+      const float m = g < a.NG ? 1.f : 0.f;
+      v.x = fmaf(m, t[g].x, v.x); v.y = fmaf(m, t[g].y, v.y); v.z = fmaf(m, t[g].z, v.z); v.w = fmaf(m, t[g].w, v.w);
+    }
+    const float4 ga = reinterpret_cast<const float4*>(a.gamma)[c4], is = reinterpret_cast<const float4*>(a.invstd)[c4];
+    reinterpret_cast<float4*>(a.D)[i] = make_float4(v.x * ga.x * is.x, v.y * ga.y * is.y, v.z * ga.z * is.z, v.w * ga.w * is.w);
+  }
+  if (i < HW) {
+    float v = 0.f;
+    for (int g = 0; g < a.NG; ++g) v += a.xpart[size_t(g) * HW + i];
+    a.X[i] = v;
+  }
+}
+
+struct C1DsumApplyArgs {
+  const float* D;       // [H][W][32] (scaled)
+  const float* X;       // [H][W]
+  const float* w;       // [32][25] fp32
+  const float* coef;    // the 25 class kernels of sept_conv1_dense_coef_kernel
+  float* dxsum;         // [H][W]
+  int B, H, W;
+};
+
+__device__ __forceinline__ float quad_sum(float v) {   // sum over the four lanes of a quad, in every lane
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // [2,3,0,1]
+  return v;
+}
+
+// one workgroup per image row, four lanes per pixel (lane q of the quad takes channels 8q .. 8q+7 of the sparse part and
+// rows q, q+4, q+8 of the 9 x 9 dense kernel); blockDim = 4 * W
+__global__ __launch_bounds__(512) void sept_conv1_dsum_apply_kernel(C1DsumApplyArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int H = a.H, W = a.W, W4 = W + 4, W8 = W + 8, tid = threadIdx.x;
-  float* Dt = reinterpret_cast<float*>(smem);                       // [a.rows + 4][W4][kDsumPS]
-  float* Xt = Dt + size_t(a.rows + 4) * W4 * kDsumPS;            // [a.rows + 8][W8]
-  float* ks = Xt + size_t(a.rows + 8) * W8;                      // [25][kCoefStride]
-  float* wsm = ks + kCoefClasses * kCoefStride;                     // [25][32]: sc_c * w[c][t]
-  const int r0 = blockIdx.x * a.rows;
-  const size_t HW = size_t(H) * W;
-  for (int i = tid; i < (a.rows + 4) * W4 * 8; i += 256) {
+  const int H = a.H, W = a.W, W4 = W + 4, W8 = W + 8, tid = threadIdx.x, nthr = blockDim.x;
+  float* Dt = reinterpret_cast<float*>(smem);                       // [5][W4][kDsumPS]
+  float* Xt = Dt + size_t(5) * W4 * kDsumPS;                        // [9][W8]
+  float* ks = Xt + size_t(9) * W8;                                  // [5 column classes][kCoefStride] of this row's class
+  float* wsm = ks + 5 * kCoefStride;                                // [25][32]: w[c][t]
+  const int h = blockIdx.x;
+  for (int i = tid; i < 5 * W4 * 8; i += nthr) {
     const int c4 = i & 7, px = i >> 3;
     const int row = px / W4, col = px - row * W4;
-    const int h = r0 - 2 + row, w0 = col - 2;
+    const int hh = h - 2 + row, w0 = col - 2;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (h >= 0 && h < H && w0 >= 0 && w0 < W) {
-      const float* src = a.dpart + (size_t(h) * W + w0) * kC + c4 * 4;
-      for (int g = 0; g < a.NG; ++g) {
-        const float4 t = *reinterpret_cast<const float4*>(src + size_t(g) * HW * kC);
-        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-      }
-    }
+    if (hh >= 0 && hh < H && w0 >= 0 && w0 < W) v = *reinterpret_cast<const float4*>(a.D + (size_t(hh) * W + w0) * kC + c4 * 4);
     *reinterpret_cast<float4*>(Dt + size_t(px) * kDsumPS + c4 * 4) = v;
   }
-  for (int i = tid; i < (a.rows + 8) * W8; i += 256) {
+  for (int i = tid; i < 9 * W8; i += nthr) {
     const int row = i / W8, col = i - row * W8;
-    const int h = r0 - 4 + row, w0 = col - 4;
-    float v = 0.f;
-    if (h >= 0 && h < H && w0 >= 0 && w0 < W)
-      for (int g = 0; g < a.NG; ++g) v += a.xpart[size_t(g) * HW + size_t(h) * W + w0];
-    Xt[i] = v;
+    const int hh = h - 4 + row, w0 = col - 4;
+    Xt[i] = (hh >= 0 && hh < H && w0 >= 0 && w0 < W) ? a.X[size_t(hh) * W + w0] : 0.f;
   }
-  for (int i = tid; i < kCoefClasses * kCoefStride; i += 256) ks[i] = a.coef[i];
-  for (int i = tid; i < kTaps * kC; i += 256) {
+  const int rcls = border_class(h, H);
+  for (int i = tid; i < 5 * kCoefStride; i += nthr) ks[i] = a.coef[rcls * 5 * kCoefStride + i];
+  for (int i = tid; i < kTaps * kC; i += nthr) {
     const int t = i / kC, c = i - t * kC;
-    wsm[i] = a.gamma[c] * a.invstd[c] * a.w[c * kTaps + t];
+    wsm[i] = a.w[c * kTaps + t];
   }
   __syncthreads();
-  for (int p = tid; p < a.rows * W; p += 256) {
-    const int hr = p / W, w0 = p - hr * W, h = r0 + hr;
-    if (h >= H) continue;
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-#pragma unroll 1
-    for (int kh = 0; kh < 5; ++kh)
-#pragma unroll 1
-      for (int kw = 0; kw < 5; ++kw) {
-        const float* dp = Dt + (size_t(hr + 4 - kh) * W4 + (w0 + 4 - kw)) * kDsumPS;
-        const float* wp = wsm + (kh * 5 + kw) * kC;
-#pragma unroll
-        for (int c = 0; c < kC; c += 4) {
-          const float4 dv = *reinterpret_cast<const float4*>(dp + c), wv = *reinterpret_cast<const float4*>(wp + c);
-          acc0 = fmaf(dv.x, wv.x, acc0);
-          acc1 = fmaf(dv.y, wv.y, acc1);
-          acc2 = fmaf(dv.z, wv.z, acc2);
-          acc3 = fmaf(dv.w, wv.w, acc3);
-        }
-      }
-    const float* kc = ks + (border_class(h, H) * 5 + border_class(w0, W)) * kCoefStride;
-    float dn = float(a.B) * kc[kCoefConst];
-#pragma unroll 1
-    for (int ur = 0; ur < 9; ++ur)
-#pragma unroll
-      for (int uc = 0; uc < 9; ++uc) dn = fmaf(kc[ur * 12 + uc], Xt[(hr + ur) * W8 + w0 + uc], dn);
-    a.dxsum[size_t(h) * W + w0] = ((acc0 + acc1) + (acc2 + acc3)) + dn;
+  const int w0 = tid >> 2, q = tid & 3;
+  if (w0 >= W) return;     // (whole quads leave together)
+  float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll 5
+  for (int t = 0; t < kTaps; ++t) {
+    const int kh = t / 5, kw = t - kh * 5;
+    const float* dp = Dt + (size_t(4 - kh) * W4 + (w0 + 4 - kw)) * kDsumPS + 8 * q;
+    const float* wp = wsm + t * kC + 8 * q;
+    const float4 d0 = *reinterpret_cast<const float4*>(dp), d1 = *reinterpret_cast<const float4*>(dp + 4);
+    const float4 u0 = *reinterpret_cast<const float4*>(wp), u1 = *reinterpret_cast<const float4*>(wp + 4);
+    acc0 = fmaf(d0.x, u0.x, acc0); acc1 = fmaf(d0.y, u0.y, acc1); acc0 = fmaf(d0.z, u0.z, acc0); acc1 = fmaf(d0.w, u0.w, acc1);
+    acc0 = fmaf(d1.x, u1.x, acc0); acc1 = fmaf(d1.y, u1.y, acc1); acc0 = fmaf(d1.z, u1.z, acc0); acc1 = fmaf(d1.w, u1.w, acc1);
   }
+  const float* kc = ks + border_class(w0, W) * kCoefStride;
+  float dn = q == 0 ? float(a.B) * kc[kCoefConst] : 0.f;
+  for (int ur = q; ur < 9; ur += 4)
+#pragma unroll
+    for (int uc = 0; uc < 9; ++uc) dn = fmaf(kc[ur * 12 + uc], Xt[ur * W8 + w0 + uc], dn);
+  const float tot = quad_sum((acc0 + acc1) + dn);
+  if (q == 0) a.dxsum[size_t(h) * W + w0] = tot;
 }
 
 // coef: kCoefFloats floats of workspace (overwritten).  sums / n_total as for sept_conv1_backward_data_bn; idx_u8 from
@@ -2226,7 +2302,7 @@ extern "C" int sept_conv1_backward_data_sparse(const void* dy_pooled, const void
 
 // sum_b dL/dx_b for a pool-first block 1 (see sept_conv1_dsum_partial_kernel): dxsum (H, W) fp32.
 // ws: sept_conv1_dsum_workspace_floats(H, W) floats; coef: SEPT_CONV1_COEF_FLOATS floats (overwritten).
-extern "C" size_t sept_conv1_dsum_workspace_floats(int H, int W) { return size_t(kDsumGroups) * H * W * (kC + 1); }
+extern "C" size_t sept_conv1_dsum_workspace_floats(int H, int W) { return size_t(kDsumGroups + 1) * H * W * (kC + 1); }
 
 extern "C" int sept_conv1_backward_data_sum(const void* dy_pooled, const void* idx_u8, const float* x, const float* w_f32,
                                             const float* bias, const float* mean, const float* invstd, const float* gamma,
@@ -2235,26 +2311,25 @@ extern "C" int sept_conv1_backward_data_sum(const void* dy_pooled, const void* i
   if (int e = conv1_check("sept_conv1_backward_data_sum", B, H, W)) return e;
   SEPT_REQUIRE(B > 0 && dy_pooled && idx_u8 && x && w_f32 && mean && invstd && gamma && sums && ws && coef && dxsum && n_total > 0,
                SEPT_ERR_INVALID, "sept_conv1_backward_data_sum: null argument / empty batch");
-  SEPT_REQUIRE(H % 2 == 0 && W % 2 == 0 && H >= 4 && W >= 8, SEPT_ERR_UNSUPPORTED,
-               "sept_conv1_backward_data_sum: H=%d W=%d (needs even H >= 4 and even W >= 8)", H, W);
-  int rows = 4;   // image rows per workgroup of the apply kernel: as many as the staged tile of D leaves room for
-  auto smem_for = [&](int r) {
-    return sizeof(float) * (size_t(r + 4) * (W + 4) * kDsumPS + size_t(r + 8) * (W + 8) + size_t(kCoefClasses) * kCoefStride +
-                            size_t(kTaps) * kC);
-  };
-  while (rows > 1 && smem_for(rows) > 150 * 1024) rows /= 2;
-  const size_t smem = smem_for(rows);
-  SEPT_REQUIRE(smem <= 160 * 1024, SEPT_ERR_UNSUPPORTED, "sept_conv1_backward_data_sum: W=%d needs %zu B of LDS", W, smem);
+  SEPT_REQUIRE(H % 2 == 0 && W % 2 == 0 && H >= 4 && W >= 8 && W <= 128, SEPT_ERR_UNSUPPORTED,
+               "sept_conv1_backward_data_sum: H=%d W=%d (needs even H >= 4 and even W in 8 .. 128)", H, W);
+  const size_t smem = sizeof(float) * (size_t(5) * (W + 4) * kDsumPS + size_t(9) * (W + 8) + size_t(5) * kCoefStride +
+                                       size_t(kTaps) * kC);
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(sept_conv1_dense_coef_kernel, dim3(kCoefClasses), dim3(256), 0, st, w_f32, bias, mean, invstd, gamma, sums,
                      float(1.0 / n_total), coef);
   const int NG = std::min(kDsumGroups, B);
-  float* dpart = ws;
-  float* xpart = ws + size_t(kDsumGroups) * H * W * kC;
+  const size_t HW = size_t(H) * W;
+  float* dpart = ws;                                   // [kDsumGroups][H][W][32]
+  float* xpart = dpart + size_t(kDsumGroups) * HW * kC;   // [kDsumGroups][H][W]
+  float* D = xpart + size_t(kDsumGroups) * HW;         // [H][W][32]
+  float* X = D + HW * kC;                              // [H][W]
   C1DsumArgs p{static_cast<const bf16*>(dy_pooled), static_cast<const unsigned char*>(idx_u8), x, dropscale, dpart, xpart, B, H, W, NG};
   hipLaunchKernelGGL(sept_conv1_dsum_partial_kernel, dim3(((H / 2) * (W / 2) * 4 + 255) / 256, NG), dim3(256), 0, st, p);
-  C1DsumApplyArgs q{dpart, xpart, w_f32, gamma, invstd, coef, dxsum, B, H, W, NG, rows};
+  C1DsumReduceArgs r{dpart, xpart, gamma, invstd, D, X, H, W, NG};
+  hipLaunchKernelGGL(sept_conv1_dsum_reduce_kernel, dim3(int((HW * 8 + 255) / 256)), dim3(256), 0, st, r);
+  C1DsumApplyArgs q{D, X, w_f32, coef, dxsum, B, H, W};
   SEPT_HIP(sept::allow_max_lds(reinterpret_cast<const void*>(&sept_conv1_dsum_apply_kernel)));
-  hipLaunchKernelGGL(sept_conv1_dsum_apply_kernel, dim3((H + rows - 1) / rows), dim3(256), smem, st, q);
+  hipLaunchKernelGGL(sept_conv1_dsum_apply_kernel, dim3(H), dim3(4 * ((W + 15) / 16 * 16)), smem, st, q);
   return sept::launch_check("sept_conv1_backward_data_sum");
 }
