@@ -386,6 +386,9 @@ int sept_conv5x5_dgrad_bnsums_ext(const void* dy_out, const void* wt, void* dx_o
 int sept_scale(const float* x, float a, float* y, long n, void* stream);
 /* y[i] = value (zero gradients of conv biases in front of a train-mode BatchNorm; flat-buffer housekeeping) */
 int sept_fill(float* y, float value, long n, void* stream);
+/* dst[0 .. nbytes) = src, device to device, any dtype (the host-fed step's swap of a staged batch into the captured
+ * graph's static input tensors, training_cloak_with_grl.py:125-132) */
+int sept_copy_bytes(const void* src, void* dst, long nbytes, void* stream);
 /* y = x * m  (GRU inter-layer dropout with a pre-scaled mask) */
 int sept_mul(const float* x, const float* m, float* y, long n, void* stream);
 /* diagnostics: *slot = the device's 100 MHz wall clock when `stream` reaches this launch (also inside a graph replay) */

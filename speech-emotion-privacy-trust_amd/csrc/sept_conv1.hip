@@ -1010,6 +1010,7 @@ __global__ __launch_bounds__(256, 3) void sept_conv1_wgrad_sparse_kernel(C1WgSpa
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int H = a.H, W = a.W, W4 = W + 4, Ho = H / 2, Wo = W / 2;
   constexpr int PT = 64 * NSW;          // pixels per tile = 4 * W
+  constexpr int NX = (8 * (16 * NSW + 4) + 255) / 256;   // staged input samples per thread and tile (8 rows of W + 4)
   float* xt = reinterpret_cast<float*>(smem);                                    // [8][W4]
   unsigned char* yt = smem + ((sizeof(float) * 8 * W4 + 15) & ~size_t(15));      // [PT][kDyPSt]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1026,11 +1027,18 @@ __global__ __launch_bounds__(256, 3) void sept_conv1_wgrad_sparse_kernel(C1WgSpa
   const int cc = tid & 3;
   uint4 gr[NI];
   uint2 ir[NI];
+  float xr[NX];
+  unsigned xok = 0;
   float dsc[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) dsc[e] = 1.0f;
   const long tile_end = n_tiles * (blockIdx.x + 1) / gridDim.x;
-  // item i of a tile: chunk cc = i & 3 of window (i >> 2): window row rp = win / Wo (0 or 1), column wo = win % Wo
+  const float inv_w4 = 1.0f / float(W4);
+  // EVERYTHING the next tile needs from global memory -- the pooled gradient / position bytes of its windows, the Dropout2d
+  // scale of its image and its eight input rows -- is requested while the current tile is computed on (unconditional,
+  // clamped addresses) and written to LDS at the top of the next iteration: no global round trip sits in the tile loop
+  // (the first versions staged x inside the loop: one exposed round trip per tile, ~4 us per tile for a few hundred
+  // instructions of work).  item i of a tile: chunk cc = i & 3 of window (i >> 2): window row rp = win / Wo, column wo.
   auto fetch = [&](long tile_id) {
     const long tc = min(tile_id, n_tiles - 1);
     const int b = int(tc / tiles_per_img), tl = int(tc % tiles_per_img);
@@ -1049,14 +1057,26 @@ __global__ __launch_bounds__(256, 3) void sept_conv1_wgrad_sparse_kernel(C1WgSpa
       dsc[0] = d0.x; dsc[1] = d0.y; dsc[2] = d0.z; dsc[3] = d0.w;
       dsc[4] = d1.x; dsc[5] = d1.y; dsc[6] = d1.z; dsc[7] = d1.w;
     }
+    const float* xb = a.x + size_t(b) * H * W;
+    xok = 0;
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      const int i = min(tid + 256 * j, 8 * W4 - 1);
+      const int row = int((float(i) + 0.5f) * inv_w4), col = i - row * W4;
+      const int h = 4 * tl - 2 + row, w = col - 2;
+      xok |= (h >= 0 && h < H && w >= 0 && w < W) ? (1u << j) : 0u;
+      xr[j] = xb[size_t(min(max(h, 0), H - 1)) * W + min(max(w, 0), W - 1)];
+    }
   };
   long tile_id = n_tiles * blockIdx.x / gridDim.x;
   if (tile_id < tile_end) fetch(tile_id);
   for (; tile_id < tile_end; ++tile_id) {
-    const int b = tile_id / tiles_per_img, tl = int(tile_id % tiles_per_img);
+    const int tl = int(tile_id % tiles_per_img);
     const int h0 = 4 * tl;
     __syncthreads();
-    stage_x(a.x + size_t(b) * H * W, xt, h0, 8, H, W);      // rows h0 - 2 .. h0 + 5
+#pragma unroll
+    for (int j = 0; j < NX; ++j)
+      if (tid + 256 * j < 8 * W4) xt[tid + 256 * j] = (xok >> j) & 1u ? xr[j] : 0.f;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       const int i = tid + 256 * j;
@@ -1086,7 +1106,7 @@ __global__ __launch_bounds__(256, 3) void sept_conv1_wgrad_sparse_kernel(C1WgSpa
     sept::lds_barrier();     // LDS-only wait: the loads just issued stay in flight across the barrier
     // the steps of a tile in groups of at most four: all operands of a group are requested first, then its MFMAs run
     // (all NSW steps at once would hold 12 NSW fragment registers: spills from NSW = 5 on at three waves per SIMD)
-    constexpr int GMAX = NSW > 5 ? 2 : 4;   // (two items per thread are prefetched from NSW = 5 on: fewer registers to spare)
+    constexpr int GMAX = 2;   // (the prefetched tile holds ~20 registers: two steps of fragments at a time fit under 168)
 #pragma unroll
     for (int g0 = 0; g0 < NSW; g0 += GMAX) {
       bf16x8 afrag[GMAX], bfrag[GMAX], lfrag[GMAX];

@@ -97,6 +97,11 @@ __global__ __launch_bounds__(kCbWaves * 64) void cloak_bwd_kernel(const float* d
 
 // ---------------- generic elementwise ----------------
 __global__ void scale_kernel(const float* x, float a, float* y, long n) { GRID_STRIDE(i, n) y[i] = a * x[i]; }
+// dst = src, any dtype: 16-byte chunks when both pointers are 16-byte aligned, the tail (and unaligned buffers) by bytes
+__global__ void copy_bytes_kernel(const unsigned char* src, unsigned char* dst, long n16, long nbytes) {
+  GRID_STRIDE(i, n16) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+  GRID_STRIDE(i, nbytes - 16 * n16) dst[16 * n16 + i] = src[16 * n16 + i];
+}
 __global__ void fill_kernel(float* y, float v, long n) { GRID_STRIDE(i, n) y[i] = v; }
 
 __global__ void mul_kernel(const float* x, const float* m, float* y, long n) { GRID_STRIDE(i, n) y[i] = x[i] * m[i]; }
@@ -882,6 +887,18 @@ extern "C" int sept_scale(const float* x, float a, float* y, long n, void* strea
   SEPT_REQUIRE(x && y && n > 0, SEPT_ERR_INVALID, "sept_scale: bad argument");
   hipLaunchKernelGGL(scale_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, ST(stream), x, a, y, n);
   return sept::launch_check("scale_kernel");
+}
+
+// dst[0 .. nbytes) = src (device to device, a shader copy at HBM speed: hipMemcpyAsync device-to-device took 0.2 ms for the
+// 10 MB waveform batch of the host-fed step, this takes microseconds)
+extern "C" int sept_copy_bytes(const void* src, void* dst, long nbytes, void* stream) {
+  if (nbytes == 0) return SEPT_OK;
+  SEPT_REQUIRE(src && dst && nbytes > 0, SEPT_ERR_INVALID, "sept_copy_bytes: bad argument");
+  const bool aligned = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+  const long n16 = aligned ? nbytes / 16 : 0;
+  hipLaunchKernelGGL(copy_bytes_kernel, dim3(blocks_for(std::max(n16, nbytes - 16 * n16))), dim3(kThreads), 0, ST(stream),
+                     static_cast<const unsigned char*>(src), static_cast<unsigned char*>(dst), n16, nbytes);
+  return sept::launch_check("copy_bytes_kernel");
 }
 
 extern "C" int sept_fill(float* y, float value, long n, void* stream) {

@@ -156,6 +156,7 @@ SIGNATURES = {
     "sept_conv1_backward_weight_sparse": (c_int, [c_void_p] * 10 + [c_double] + [c_void_p] * 3 + [c_int] * 3 + [c_void_p]),
     "sept_conv1_dsum_workspace_floats": (c_size_t, [c_int, c_int]),
     "sept_conv1_backward_data_sum": (c_int, [c_void_p] * 10 + [c_double] + [c_void_p] * 3 + [c_int] * 3 + [c_void_p]),
+    "sept_copy_bytes": (c_int, [c_void_p, c_void_p, c_long, c_void_p]),
     "sept_sgd_step_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_float, c_float, c_float, c_void_p]),
     "sept_adam_step_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_float, c_float, c_float,
                                    c_float, c_void_p, c_float, c_void_p]),

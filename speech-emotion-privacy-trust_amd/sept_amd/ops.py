@@ -792,6 +792,16 @@ def copy_into(dst, src):
     return dst
 
 
+def copy_bytes(dst, src):
+    """dst[...] = src bit for bit (contiguous tensors of equal byte size, any dtype) through a HIP copy kernel."""
+    require_cuda(dst, src)
+    n = src.numel() * src.element_size()
+    if n != dst.numel() * dst.element_size() or not (src.is_contiguous() and dst.is_contiguous()):
+        raise SeptError("copy_bytes: contiguous tensors of equal byte size expected")
+    check(lib.sept_copy_bytes(src.data_ptr(), dst.data_ptr(), n, _s(src)), "sept_copy_bytes")
+    return dst
+
+
 def scale(x, a, out=None):
     y = torch.empty_like(x) if out is None else out
     check(lib.sept_scale(x.data_ptr(), float(a), y.data_ptr(), x.numel(), _s(x)), "sept_scale")

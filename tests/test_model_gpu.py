@@ -427,6 +427,51 @@ def test_graph_replay_equals_eager_step():
     assert torch.equal(results[0][1], results[1][1])          # deterministic kernels: bit-identical
 
 
+def test_host_fed_replays_equal_eager_steps_on_the_same_batches():
+    """Input ingestion (training_cloak_with_grl.py:125-132: every batch goes host -> device inside the loop): two DIFFERENT
+    pinned host batches fed through HostFeed (H2D on a copy stream under the previous replay, device-to-device into the
+    graph's static tensors) must give exactly the parameters two eager steps on the same batches give."""
+    from sept_amd.trainer import FusedPipeline, GrlTrainer, HostFeed
+    F = 80
+    g = torch.Generator().manual_seed(4)
+    batches = []
+    for _ in range(3):
+        wav = torch.randn(2, 48000, generator=g) * 0.1
+        le = torch.randint(0, 4, (2,), generator=g).repeat_interleave(3)
+        lg = torch.randint(0, 2, (2,), generator=g).repeat_interleave(3)
+        w = 1.0 + torch.rand(2, generator=g).repeat_interleave(3)
+        batches.append((wav, le, lg, w))
+    mean, std = torch.full((F,), -20.0).cuda(), torch.full((F,), 12.0).cuda()
+    results = []
+    for fed in (False, True):
+        grl = build_grl(F).train()
+        zero_dropout(grl)
+        tr = GrlTrainer(grl, optimizer="sgd")
+        pipe = FusedPipeline(tr, n_mels=F, mean=mean, std=std)
+        pipe.train_step(*[t.cuda() for t in batches[0]])                      # warm-up / first step (eager in both)
+        if fed:
+            feed = HostFeed([t.cuda() for t in batches[0]])
+            step = pipe.capture(*feed.statics)
+            host = [feed.pack(b) for b in batches]
+            feed.prefetch(host[1])
+            for k in (1, 2):
+                feed.swap_in()
+                loss, _, _ = step()
+                if k < 2:
+                    feed.prefetch(host[k + 1])      # behind the graph launch (see HostFeed)
+            with pytest.raises(RuntimeError):
+                feed.swap_in()                                                # nothing prefetched
+            with pytest.raises(ValueError):
+                feed.prefetch(torch.zeros(8, dtype=torch.uint8))              # not a packed, pinned batch
+        else:
+            for k in (1, 2):
+                loss, _, _ = pipe.train_step(*[t.cuda() for t in batches[k]])
+        torch.cuda.synchronize()
+        results.append((float(loss), tr.flat.flat.clone()))
+    assert results[0][0] == pytest.approx(results[1][0], rel=1e-6)
+    assert torch.equal(results[0][1], results[1][1])
+
+
 def test_one_d_cnn_multitask_and_unrunnable_options():
     """one_d_cnn_lstm pred='multitask' (baseline_models.py:129-132): an (emotion, gender) pair from the shared
     classifier; both heads' losses flow back.  att='self_att' and a global feature cannot run in the reference
