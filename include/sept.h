@@ -199,6 +199,10 @@ int sept_gemm_nt_split(const void* A, long lda, int a_is_bf16, const float* B, l
 size_t sept_gemm_tn_workspace_floats(int M, int N);
 int sept_gemm_tn_split(const float* A, long lda, const void* B, long ldb, int b_is_bf16, float* C, long ldc,
                        int M, int N, int K, float* ws, long ws_floats, void* stream);
+/* the same product that also leaves colsum[m] = sum_k A[k][m] (M floats): a layer's bias gradient beside its weight
+ * gradient, from the gradient rows the product stages anyway (autograd of nn.GRU / nn.Linear, baseline_models.py:191-210) */
+int sept_gemm_tn_split_colsum(const float* A, long lda, const void* B, long ldb, int b_is_bf16, float* C, long ldc,
+                              float* colsum, int M, int N, int K, float* ws, long ws_floats, void* stream);
 
 /* Recurrent part of nn.GRU(.., hidden 64, bidirectional, batch_first) -- one launch per layer
  * for both directions and all T steps (baseline_models.py:191-193; gate order r, z, n).
@@ -215,6 +219,15 @@ int sept_gru_forward(const float* gi, const float* whh_fwd, const float* whh_rev
 int sept_gru_backward(const float* dout, const float* out, const float* gates, const float* whh_fwd,
                       const float* whh_rev, float* dgi, float* dgh, float* hprev, int B, int T, int H,
                       void* stream);
+/* The dropout between the two recurrent layers (nn.GRU(dropout=0.2), baseline_models.py:191-193) folded into the
+ * recurrences: the forward also writes out_masked = out * mask (mask: (B, T, 2H) scale values, 0 or 1/(1-p)), the next
+ * layer's input; the backward takes the gradient of that masked output and multiplies it by the mask as it is fetched. */
+int sept_gru_forward_masked(const float* gi, const float* whh_fwd, const float* whh_rev, const float* bhh_fwd,
+                            const float* bhh_rev, float* out, float* gates, const float* mask, float* out_masked, int B,
+                            int T, int H, void* stream);
+int sept_gru_backward_masked(const float* dout, const float* dout_mask, const float* out, const float* gates,
+                             const float* whh_fwd, const float* whh_rev, float* dgi, float* dgh, float* hprev, int B, int T,
+                             int H, void* stream);
 
 /* LSTM recurrence (gate order i, f, g, o; nn.LSTM of deep_two_d_cnn_lstm_tmp, baseline_models.py:388-509, and the
  * rnn_cell='lstm' option of the other classes): gi (B, T, 2, 4H) = x W_ih^T + b_ih for both directions;
@@ -448,6 +461,7 @@ int sept_dropout_mask(float* out, long n, float p, unsigned long long seed, cons
 int sept_normal(float* out, long n, float mean, float stdv, unsigned long long seed, const long long* offset_dev,
                 unsigned long long offset, void* stream);
 int sept_counter_add(long long* counter, long long inc, void* stream);
+int sept_counter_add2(long long* counter0, long long* counter1, long long inc, void* stream);   /* both, one launch */
 /* Fused classifier head for the common case (att None, mean pooling, no global features; baseline_models.py:231-258):
  * z = mean_t(x (B, T, D)); d1 = z W1^T + b1; d1a = relu(d1) * dropscale (NULL = 1); logits (B, NC) = d1a Wh^T + bh, Wh
  * (NC, D1) being the prediction layer (both layers stacked for pred='multitask').  z, d1, d1a are kept for the

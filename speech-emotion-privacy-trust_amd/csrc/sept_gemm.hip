@@ -399,6 +399,10 @@ struct TnArgs {
   float* ws;
   long lda, ldb, ldc;
   int M, N, K, kchunk, splits;
+  // optional: colsum[m] = sum_k A[k][m] (the bias gradient that goes with the weight gradient dW = dy^T x: the same dy rows
+  // are staged here anyway).  Formed by the workgroups of the first n-tile; with K split, partials [splits][M] sit behind
+  // the C slabs in ws and the reduce kernel adds them up in the same fixed order.
+  float* colsum;
 };
 
 constexpr int TN_RS = 192;              // bytes per LDS row: 64 bf16 + pad (4 rows x 64 B hit 64 distinct banks)
@@ -452,11 +456,16 @@ __global__ __launch_bounds__(256) void sept_gemm_tn_split_kernel(TnArgs g) {
       b16 = *reinterpret_cast<const uint4*>(static_cast<const bf16*>(g.B) + long(k) * g.ldb + bcol16);
     }
   };
+  const bool want_cs = g.colsum != nullptr && blockIdx.x == 0;
+  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);   // this thread's running sums of its 4 columns (both of its k rows)
   auto store_lds = [&](int buf) {
     bf16x4 hi, lo;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int e = tid + 256 * i, off = (e >> 4) * TN_RS + (e & 15) * 8;
+      if (want_cs) {
+        cs.x += a4[i].x; cs.y += a4[i].y; cs.z += a4[i].z; cs.w += a4[i].w;
+      }
       split4(a4[i], hi, lo);
       *reinterpret_cast<bf16x4*>(&As[buf][0][off]) = hi;
       *reinterpret_cast<bf16x4*>(&As[buf][1][off]) = lo;
@@ -497,6 +506,22 @@ __global__ __launch_bounds__(256) void sept_gemm_tn_split_kernel(TnArgs g) {
     if (ks + 1 < nk) store_lds(buf ^ 1);
     sept::lds_barrier();
   }
+  if (want_cs) {   // 16 threads (k rows) per column group: fixed-order sum through LDS (the staging planes are free now)
+    float4* red = reinterpret_cast<float4*>(&As[0][0][0]);
+    red[tid] = cs;
+    __syncthreads();
+    if (tid < 16) {
+      float4 t = red[tid];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) {
+        const float4 u = red[tid + 16 * r];
+        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+      }
+      float* co = (g.splits > 1 ? g.ws + size_t(g.splits) * g.M * g.N + size_t(blockIdx.z) * g.M : g.colsum) + acol[0];
+      co[0] = t.x; co[1] = t.y; co[2] = t.z; co[3] = t.w;   // scalar stores: the caller's slot need not be 16-byte aligned
+                                                            // (clamped edge groups rewrite the last group's values: identical)
+    }
+  }
   const int n = n0 + wn + (lane & 31);
   if (n >= g.N) return;
   float* out = g.splits > 1 ? g.ws + size_t(blockIdx.z) * g.M * g.N : g.C;
@@ -515,6 +540,12 @@ __global__ void sept_gemm_tn_reduce_kernel(TnArgs g) {
     for (int z = 0; z < g.splits; ++z) s += g.ws[size_t(z) * total + i];
     g.C[(i / g.N) * g.ldc + i % g.N] = s;
   }
+  if (g.colsum)
+    for (long i = long(blockIdx.x) * blockDim.x + threadIdx.x; i < g.M; i += long(gridDim.x) * blockDim.x) {
+      float s = 0.f;
+      for (int z = 0; z < g.splits; ++z) s += g.ws[size_t(g.splits) * total + size_t(z) * g.M + i];
+      g.colsum[i] = s;
+    }
 }
 
 }  // namespace
@@ -570,10 +601,25 @@ extern "C" int sept_gemm_nt_split(const void* A, long lda, int a_is_bf16, const 
 }
 
 
-extern "C" size_t sept_gemm_tn_workspace_floats(int M, int N) { return size_t(16) * size_t(M) * size_t(N); }
+extern "C" size_t sept_gemm_tn_workspace_floats(int M, int N) { return size_t(16) * size_t(M) * (size_t(N) + 1); }
 
+namespace {
+int tn_split_impl(const float* A, long lda, const void* B, long ldb, int b_is_bf16, float* C, long ldc, int M, int N, int K,
+                  float* ws, long ws_floats, float* colsum, void* stream);
+}
 extern "C" int sept_gemm_tn_split(const float* A, long lda, const void* B, long ldb, int b_is_bf16, float* C, long ldc,
                                   int M, int N, int K, float* ws, long ws_floats, void* stream) {
+  return tn_split_impl(A, lda, B, ldb, b_is_bf16, C, ldc, M, N, K, ws, ws_floats, nullptr, stream);
+}
+// the same product that also leaves colsum[m] = sum_k A[k][m] (M floats): a layer's bias gradient beside its weight gradient
+extern "C" int sept_gemm_tn_split_colsum(const float* A, long lda, const void* B, long ldb, int b_is_bf16, float* C, long ldc,
+                                         float* colsum, int M, int N, int K, float* ws, long ws_floats, void* stream) {
+  SEPT_REQUIRE(colsum || M == 0 || N == 0, SEPT_ERR_INVALID, "sept_gemm_tn_split_colsum: null colsum");
+  return tn_split_impl(A, lda, B, ldb, b_is_bf16, C, ldc, M, N, K, ws, ws_floats, colsum, stream);
+}
+namespace {
+int tn_split_impl(const float* A, long lda, const void* B, long ldb, int b_is_bf16, float* C, long ldc, int M, int N, int K,
+                  float* ws, long ws_floats, float* colsum, void* stream) {
   SEPT_REQUIRE(M >= 0 && N >= 0 && K >= 0, SEPT_ERR_INVALID, "sept_gemm_tn_split: M=%d N=%d K=%d", M, N, K);
   if (M == 0 || N == 0) return SEPT_OK;
   SEPT_REQUIRE(A && B && C && K > 0, SEPT_ERR_INVALID, "sept_gemm_tn_split: null argument or K == 0");
@@ -582,12 +628,12 @@ extern "C" int sept_gemm_tn_split(const float* A, long lda, const void* B, long 
                    reinterpret_cast<uintptr_t>(A) % 16 == 0 && reinterpret_cast<uintptr_t>(B) % 16 == 0,
                SEPT_ERR_INVALID, "sept_gemm_tn_split: M=%d N=%d lda=%ld ldb=%ld ldc=%ld need 16-byte aligned rows", M, N,
                lda, ldb, ldc);
-  TnArgs g{A, B, C, ws, lda, ldb, ldc, M, N, K, 0, 1};
+  TnArgs g{A, B, C, ws, lda, ldb, ldc, M, N, K, 0, 1, colsum};
   const int tiles = ((N + 63) / 64) * ((M + 63) / 64);
   int splits = 1;
   if (ws && tiles < 1024 && K >= 256) {
     splits = std::min({16, (1024 + tiles - 1) / tiles, K / 128});
-    while (splits > 1 && long(splits) * M * N > ws_floats) --splits;
+    while (splits > 1 && long(splits) * M * (N + (colsum ? 1 : 0)) > ws_floats) --splits;
   }
   splits = std::max(splits, 1);
   g.kchunk = ((K + splits - 1) / splits + 31) / 32 * 32;
@@ -603,3 +649,4 @@ extern "C" int sept_gemm_tn_split(const float* A, long lda, const void* B, long 
   }
   return sept::launch_check("sept_gemm_tn_split_kernel");
 }
+}  // namespace

@@ -29,6 +29,11 @@ struct GruArgs {
   float* dgh;        // [B][T][2][3H]
   float* hprev;      // [B][T][2][H]
   int B, T;
+  // inter-layer dropout (nn.GRU(dropout=0.2), baseline_models.py:191-193) folded into the recurrences (MASKED kernels):
+  // forward: out_masked = out * mask, the next layer's input, written beside out; backward: dout is multiplied by mask as
+  // it is fetched -- two elementwise launches per network and direction of the step saved (mask: [B][T][2H] scale values)
+  const float* mask;
+  float* out_masked;
 };
 
 // the gate nonlinearities sit on the 25-step serial chain: one exp + one hardware reciprocal each (1 ulp; an IEEE division
@@ -44,7 +49,7 @@ __device__ __forceinline__ float pair_sum(float v) {
 
 // kH = hidden size (64: the trainer's lstm_hidden_size; 128: the class default); each hidden unit is owned by a
 // PAIR of lanes, each with half (kHH) of the k range
-template <int kH>
+template <int kH, bool MASKED = false>
 __global__ __launch_bounds__(kBS * kH * 2) void sept_gru_fwd_kernel(GruArgs a) {
   constexpr int kHH = kH / 2;
   __shared__ __attribute__((aligned(16))) float hs[2][kBS][kH];   // ping-pong: one barrier per step
@@ -72,9 +77,9 @@ __global__ __launch_bounds__(kBS * kH * 2) void sept_gru_fwd_kernel(GruArgs a) {
     const float* g = a.gi + ((size_t(b) * a.T + t) * 2 + dir) * 3 * kH;
     gr = g[j]; gz = g[kH + j]; gn = g[2 * kH + j];
   };
-  auto store_step = [&](int t, float v0, float v1, float v2) {
+  auto store_step = [&](int t, float v0, float v1, float v2, float v3) {
     // five values per hidden unit, three unconditional stores per lane (the pair shares them;
-    // the second lane writes its second value twice)
+    // the second lane writes its second value twice); MASKED: a fourth store, the masked output (second lane: a repeat)
     float* gs = a.gates + ((size_t(b) * a.T + t) * 2 + dir) * 4 * kH;
     float* p0 = half ? gs + 2 * kH + j : a.out + (size_t(b) * a.T + t) * 2 * kH + dir * kH + j;
     float* p1 = half ? gs + 3 * kH + j : gs + j;
@@ -82,18 +87,30 @@ __global__ __launch_bounds__(kBS * kH * 2) void sept_gru_fwd_kernel(GruArgs a) {
     *p0 = v0;
     *p1 = v1;
     *p2 = v2;
+    if constexpr (MASKED) {
+      float* p3 = half ? gs + 3 * kH + j : a.out_masked + (size_t(b) * a.T + t) * 2 * kH + dir * kH + j;
+      *p3 = v3;
+    }
+  };
+  auto mask_at = [&](int step) {   // the dropout scale of this lane's output element at the given step (prefetched with gi)
+    if constexpr (!MASKED) return 1.0f;
+    const int st = min(step, a.T - 1);
+    const int t = dir == 0 ? st : a.T - 1 - st;
+    return a.mask[(size_t(b) * a.T + t) * 2 * kH + dir * kH + j];
   };
   float gr, gz, gn;
   gi_at(0, gr, gz, gn);
+  float mk = mask_at(0);
   // Placeholder stores to the first step's slots (overwritten by that step): the loop is then
   // entered with the same queue of outstanding memory operations (3 loads, 3 stores) that its
   // back edge carries, so the wait for the prefetched loads never includes draining the stores.
-  store_step(dir == 0 ? 0 : a.T - 1, 0.f, 0.f, 0.f);
+  store_step(dir == 0 ? 0 : a.T - 1, 0.f, 0.f, 0.f, 0.f);
   sept::lds_barrier();
   for (int step = 0; step < a.T; ++step) {
     const int t = dir == 0 ? step : a.T - 1 - step;
     float ngr, ngz, ngn;
     gi_at(step + 1, ngr, ngz, ngn);
+    const float nmk = mask_at(step + 1);
     float ar = br, az = bz, an = bn, ar2 = 0.f, az2 = 0.f, an2 = 0.f;   // two chains per gate: half the dependent depth
     const float* hc = &hs[step & 1][s][half * kHH];
 #pragma unroll
@@ -112,12 +129,13 @@ __global__ __launch_bounds__(kBS * kH * 2) void sept_gru_fwd_kernel(GruArgs a) {
     h = (1.f - z) * n + z * h;
     hs[(step + 1) & 1][s][j] = h;   // both lanes of the pair write the same value; the other buffer is still being read
     sept::lds_barrier();            // LDS-only wait: global prefetches / stores stay in flight across the barrier
-    store_step(t, half ? n : h, half ? an : r, half ? an : z);
+    store_step(t, half ? n : h, half ? an : r, half ? an : z, half ? an : h * mk);
     gr = ngr; gz = ngz; gn = ngn;
+    mk = nmk;
   }
 }
 
-template <int kH>
+template <int kH, bool MASKED = false>
 __global__ __launch_bounds__(kBS * kH * 2) void sept_gru_bwd_kernel(GruArgs a) {
   constexpr int kHH = kH / 2;
   __shared__ __attribute__((aligned(16))) float ds[2][kBS][3 * kH];   // ping-pong: one barrier per step
@@ -148,6 +166,7 @@ __global__ __launch_bounds__(kBS * kH * 2) void sept_gru_bwd_kernel(GruArgs a) {
     const float hp = a.out[(size_t(b) * a.T + min(max(tp, 0), a.T - 1)) * 2 * kH + dir * kH + j];
     v.hp = (tp >= 0 && tp < a.T) ? hp : 0.f;
     v.dout = a.dout[bt * 2 * kH + dir * kH + j];
+    if constexpr (MASKED) v.dout *= a.mask[bt * 2 * kH + dir * kH + j];
     return v;
   };
   auto store_step = [&](int t, float v0, float v1, float v2, float v3) {
@@ -207,42 +226,75 @@ __global__ __launch_bounds__(kBS * kH * 2) void sept_gru_bwd_kernel(GruArgs a) {
 
 }  // namespace
 
-extern "C" int sept_gru_forward(const float* gi, const float* whh_fwd, const float* whh_rev, const float* bhh_fwd,
-                                const float* bhh_rev, float* out, float* gates, int B, int T, int H, void* stream) {
-  SEPT_REQUIRE(H == 64 || H == 128, SEPT_ERR_UNSUPPORTED, "sept_gru_forward: hidden size %d (supported: 64, 128)", H);
-  SEPT_REQUIRE(B >= 0 && T > 0, SEPT_ERR_INVALID, "sept_gru_forward: B=%d T=%d", B, T);
+namespace {
+int gru_forward_impl(const char* who, const float* gi, const float* whh_fwd, const float* whh_rev, const float* bhh_fwd,
+                     const float* bhh_rev, float* out, float* gates, const float* mask, float* out_masked, int B, int T, int H,
+                     void* stream) {
+  SEPT_REQUIRE(H == 64 || H == 128, SEPT_ERR_UNSUPPORTED, "%s: hidden size %d (supported: 64, 128)", who, H);
+  SEPT_REQUIRE(B >= 0 && T > 0, SEPT_ERR_INVALID, "%s: B=%d T=%d", who, B, T);
   if (B == 0) return SEPT_OK;
-  SEPT_REQUIRE(gi && whh_fwd && whh_rev && bhh_fwd && bhh_rev && out && gates, SEPT_ERR_INVALID,
-               "sept_gru_forward: null argument");
+  SEPT_REQUIRE(gi && whh_fwd && whh_rev && bhh_fwd && bhh_rev && out && gates && (!mask == !out_masked), SEPT_ERR_INVALID,
+               "%s: null argument", who);
   GruArgs a{};
   a.gi = gi; a.whh[0] = whh_fwd; a.whh[1] = whh_rev; a.bhh[0] = bhh_fwd; a.bhh[1] = bhh_rev;
-  a.out = out; a.gates = gates; a.B = B; a.T = T;
-  if (H == 64)
-    hipLaunchKernelGGL(sept_gru_fwd_kernel<64>, dim3((B + kBS - 1) / kBS, 2), dim3(kBS * 64 * 2), 0,
-                       static_cast<hipStream_t>(stream), a);
-  else
-    hipLaunchKernelGGL(sept_gru_fwd_kernel<128>, dim3((B + kBS - 1) / kBS, 2), dim3(kBS * 128 * 2), 0,
-                       static_cast<hipStream_t>(stream), a);
+  a.out = out; a.gates = gates; a.B = B; a.T = T; a.mask = mask; a.out_masked = out_masked;
+  const dim3 grid((B + kBS - 1) / kBS, 2);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (H == 64 && mask) hipLaunchKernelGGL((sept_gru_fwd_kernel<64, true>), grid, dim3(kBS * 64 * 2), 0, st, a);
+  else if (H == 64) hipLaunchKernelGGL((sept_gru_fwd_kernel<64, false>), grid, dim3(kBS * 64 * 2), 0, st, a);
+  else if (mask) hipLaunchKernelGGL((sept_gru_fwd_kernel<128, true>), grid, dim3(kBS * 128 * 2), 0, st, a);
+  else hipLaunchKernelGGL((sept_gru_fwd_kernel<128, false>), grid, dim3(kBS * 128 * 2), 0, st, a);
   return sept::launch_check("sept_gru_fwd_kernel");
 }
+}  // namespace
+
+extern "C" int sept_gru_forward(const float* gi, const float* whh_fwd, const float* whh_rev, const float* bhh_fwd,
+                                const float* bhh_rev, float* out, float* gates, int B, int T, int H, void* stream) {
+  return gru_forward_impl("sept_gru_forward", gi, whh_fwd, whh_rev, bhh_fwd, bhh_rev, out, gates, nullptr, nullptr, B, T, H, stream);
+}
+
+// forward that also writes out_masked = out * mask (the dropout between the two recurrent layers: the next layer's input)
+extern "C" int sept_gru_forward_masked(const float* gi, const float* whh_fwd, const float* whh_rev, const float* bhh_fwd,
+                                       const float* bhh_rev, float* out, float* gates, const float* mask, float* out_masked,
+                                       int B, int T, int H, void* stream) {
+  SEPT_REQUIRE(B == 0 || (mask && out_masked), SEPT_ERR_INVALID, "sept_gru_forward_masked: null mask / output");
+  return gru_forward_impl("sept_gru_forward_masked", gi, whh_fwd, whh_rev, bhh_fwd, bhh_rev, out, gates, mask, out_masked, B, T, H,
+                          stream);
+}
+
+namespace {
+int gru_backward_impl(const char* who, const float* dout, const float* dout_mask, const float* out, const float* gates,
+                      const float* whh_fwd, const float* whh_rev, float* dgi, float* dgh, float* hprev, int B, int T, int H,
+                      void* stream) {
+  SEPT_REQUIRE(H == 64 || H == 128, SEPT_ERR_UNSUPPORTED, "%s: hidden size %d (supported: 64, 128)", who, H);
+  SEPT_REQUIRE(B >= 0 && T > 0, SEPT_ERR_INVALID, "%s: B=%d T=%d", who, B, T);
+  if (B == 0) return SEPT_OK;
+  SEPT_REQUIRE(dout && out && gates && whh_fwd && whh_rev && dgi && dgh && hprev, SEPT_ERR_INVALID, "%s: null argument", who);
+  GruArgs a{};
+  a.dout = dout; a.out = const_cast<float*>(out); a.gates = const_cast<float*>(gates);
+  a.whh[0] = whh_fwd; a.whh[1] = whh_rev;
+  a.dgi = dgi; a.dgh = dgh; a.hprev = hprev; a.B = B; a.T = T; a.mask = dout_mask;
+  const dim3 grid((B + kBS - 1) / kBS, 2);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (H == 64 && dout_mask) hipLaunchKernelGGL((sept_gru_bwd_kernel<64, true>), grid, dim3(kBS * 64 * 2), 0, st, a);
+  else if (H == 64) hipLaunchKernelGGL((sept_gru_bwd_kernel<64, false>), grid, dim3(kBS * 64 * 2), 0, st, a);
+  else if (dout_mask) hipLaunchKernelGGL((sept_gru_bwd_kernel<128, true>), grid, dim3(kBS * 128 * 2), 0, st, a);
+  else hipLaunchKernelGGL((sept_gru_bwd_kernel<128, false>), grid, dim3(kBS * 128 * 2), 0, st, a);
+  return sept::launch_check("sept_gru_bwd_kernel");
+}
+}  // namespace
 
 extern "C" int sept_gru_backward(const float* dout, const float* out, const float* gates, const float* whh_fwd,
                                  const float* whh_rev, float* dgi, float* dgh, float* hprev, int B, int T, int H,
                                  void* stream) {
-  SEPT_REQUIRE(H == 64 || H == 128, SEPT_ERR_UNSUPPORTED, "sept_gru_backward: hidden size %d (supported: 64, 128)", H);
-  SEPT_REQUIRE(B >= 0 && T > 0, SEPT_ERR_INVALID, "sept_gru_backward: B=%d T=%d", B, T);
-  if (B == 0) return SEPT_OK;
-  SEPT_REQUIRE(dout && out && gates && whh_fwd && whh_rev && dgi && dgh && hprev, SEPT_ERR_INVALID,
-               "sept_gru_backward: null argument");
-  GruArgs a{};
-  a.dout = dout; a.out = const_cast<float*>(out); a.gates = const_cast<float*>(gates);
-  a.whh[0] = whh_fwd; a.whh[1] = whh_rev;
-  a.dgi = dgi; a.dgh = dgh; a.hprev = hprev; a.B = B; a.T = T;
-  if (H == 64)
-    hipLaunchKernelGGL(sept_gru_bwd_kernel<64>, dim3((B + kBS - 1) / kBS, 2), dim3(kBS * 64 * 2), 0,
-                       static_cast<hipStream_t>(stream), a);
-  else
-    hipLaunchKernelGGL(sept_gru_bwd_kernel<128>, dim3((B + kBS - 1) / kBS, 2), dim3(kBS * 128 * 2), 0,
-                       static_cast<hipStream_t>(stream), a);
-  return sept::launch_check("sept_gru_bwd_kernel");
+  return gru_backward_impl("sept_gru_backward", dout, nullptr, out, gates, whh_fwd, whh_rev, dgi, dgh, hprev, B, T, H, stream);
+}
+
+// backward whose incoming gradient is dout * dout_mask (the gradient of the masked output the next layer consumed)
+extern "C" int sept_gru_backward_masked(const float* dout, const float* dout_mask, const float* out, const float* gates,
+                                        const float* whh_fwd, const float* whh_rev, float* dgi, float* dgh, float* hprev, int B,
+                                        int T, int H, void* stream) {
+  SEPT_REQUIRE(B == 0 || dout_mask, SEPT_ERR_INVALID, "sept_gru_backward_masked: null mask");
+  return gru_backward_impl("sept_gru_backward_masked", dout, dout_mask, out, gates, whh_fwd, whh_rev, dgi, dgh, hprev, B, T, H,
+                           stream);
 }

@@ -1084,6 +1084,17 @@ extern "C" int sept_normal(float* out, long n, float mean, float stdv, unsigned 
   return sept::launch_check("normal_kernel");
 }
 
+__global__ void counter_add2_kernel(long long* c0, long long* c1, long long inc) {
+  if (threadIdx.x == 0) *c0 += inc;
+  if (threadIdx.x == 1) *c1 += inc;
+}
+// two counters in one launch (the dropout and the epsilon stream of a step advance together)
+extern "C" int sept_counter_add2(long long* counter0, long long* counter1, long long inc, void* stream) {
+  SEPT_REQUIRE(counter0 && counter1 && counter0 != counter1, SEPT_ERR_INVALID, "sept_counter_add2: two distinct counters expected");
+  hipLaunchKernelGGL(counter_add2_kernel, dim3(1), dim3(64), 0, ST(stream), counter0, counter1, inc);
+  return sept::launch_check("counter_add2_kernel");
+}
+
 extern "C" int sept_counter_add(long long* counter, long long inc, void* stream) {
   SEPT_REQUIRE(counter, SEPT_ERR_INVALID, "sept_counter_add: null argument");
   hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, ST(stream), counter, inc);

@@ -157,6 +157,11 @@ SIGNATURES = {
     "sept_conv1_dsum_workspace_floats": (c_size_t, [c_int, c_int]),
     "sept_conv1_backward_data_sum": (c_int, [c_void_p] * 10 + [c_double] + [c_void_p] * 3 + [c_int] * 3 + [c_void_p]),
     "sept_copy_bytes": (c_int, [c_void_p, c_void_p, c_long, c_void_p]),
+    "sept_gru_forward_masked": (c_int, [c_void_p] * 9 + [c_int] * 3 + [c_void_p]),
+    "sept_gru_backward_masked": (c_int, [c_void_p] * 9 + [c_int] * 3 + [c_void_p]),
+    "sept_counter_add2": (c_int, [c_void_p, c_void_p, c_long, c_void_p]),
+    "sept_gemm_tn_split_colsum": (c_int, [c_void_p, c_long, c_void_p, c_long, c_int, c_void_p, c_long, c_void_p, c_int, c_int,
+                                          c_int, c_void_p, c_long, c_void_p]),
     "sept_sgd_step_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_float, c_float, c_float, c_void_p]),
     "sept_adam_step_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_float, c_float, c_float,
                                    c_float, c_void_p, c_float, c_void_p]),

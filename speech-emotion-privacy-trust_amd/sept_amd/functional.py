@@ -333,18 +333,23 @@ def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None, gfeat=Non
         # (B*T, 2G): both directions in one product, on the split-bf16 matrix pipe when K allows
         gi = ops.linear_nt_split(layer_in, wcat, bcat) if _nt_ok(K) else ops.linear_forward(layer_in, wcat, bcat)
         cells = None
+        lmask = None
+        if layer == 0 and train and (r.dropout > 0 or "rnn" in inj):
+            m = inj.get("rnn")
+            lmask = (m if m is not None else masks["rnn"]).contiguous()
+        outm = None
         if lstm:
             out, gates, cells = ops.lstm_forward(gi.view(B, T, 2, G), whf, whr, bhf, bhr)
+        elif lmask is not None:    # the inter-layer dropout is applied by the recurrence kernel itself (second output)
+            out, gates, outm = ops.gru_forward(gi.view(B, T, 2, G), whf, whr, bhf, bhr, mask=lmask.view(B, T, H2))
         else:
             out, gates = ops.gru_forward(gi.view(B, T, 2, G), whf, whr, bhf, bhr)
         Gs = SimpleNamespace(inp=layer_in, out=out, gates=gates, cells=cells, wcat=wcat, wcatT=wcatT, whf=whf, whr=whr,
-                             mask=None)
+                             mask=lmask)
         if layer == 0:
             nxt = out.view(B * T, H2)
-            if train and (r.dropout > 0 or "rnn" in inj):
-                m = inj.get("rnn")
-                Gs.mask = m if m is not None else masks["rnn"]
-                nxt = ops.mul(out, Gs.mask).view(B * T, H2)
+            if lmask is not None:
+                nxt = (outm if outm is not None else ops.mul(out, lmask)).view(B * T, H2)
             layer_in = nxt
         S.gru.append(Gs)
     out1 = S.gru[1].out
@@ -427,8 +432,7 @@ def zero_bias_grad(bias):
     fp, off, n = slot
     view = fp.grad[off:off + n].view(bias.shape)
     clean = fp.__dict__.setdefault("_zero_slots", set())
-    if off not in clean or torch.cuda.is_current_stream_capturing():
-        # (inside a capture the fill is recorded: a replay then does not depend on what ran before it)
+    if off not in clean:     # also under a capture: the slot was zeroed when it was first used and nothing ever writes it
         ops.fill(view, 0.0)
         clean.add(off)
     return view
@@ -728,8 +732,9 @@ def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq, go
         if S.lstm:   # gi and W_hh h enter the gates as a sum: one gradient serves both
             dgi, hprev = ops.lstm_backward(dout.contiguous(), Gs.out, Gs.gates, Gs.cells, Gs.whf, Gs.whr)
             dgh = dgi
-        else:
-            dgi, dgh, hprev = ops.gru_backward(dout.contiguous(), Gs.out, Gs.gates, Gs.whf, Gs.whr)
+        else:        # layer 0: the inter-layer dropout's backward (dout * mask) happens as the kernel fetches dout
+            dgi, dgh, hprev = ops.gru_backward(dout.contiguous(), Gs.out, Gs.gates, Gs.whf, Gs.whr,
+                                               dout_mask=Gs.mask if layer == 0 else None)
         dgi2, dgh2, hp2 = dgi.view(B * T, 2 * G), dgh.view(B * T, 2 * G), hprev.view(B * T, H2)
         K = Gs.inp.shape[1]
         if need_wgrad:
@@ -739,9 +744,14 @@ def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq, go
                 pair = (lambda n: grad_out_pair(getattr(r, n + sfx), getattr(r, n + sfx + "_reverse"))) if need_wgrad \
                     else (lambda n: None)
                 o_w, o_bi, o_bh = (pair("weight_ih") if layer == 1 else None), pair("bias_ih"), pair("bias_hh")
-                dwcat = ops.linear_backward_weight(dgi2, Gs.inp, out=o_w)      # (2G, K)
-                dbih = ops.colsum(dgi2, out=o_bi)
-                dbhh = (dbih if o_bh is None else ops.copy_into(o_bh, dbih)) if S.lstm else ops.colsum(dgh2, out=o_bh)
+                # bias gradients = column sums of the gate gradients: formed by the weight-gradient products themselves
+                # (ops.linear_backward_weight(colsum_out=...)), no launches of their own
+                dev_ = dgi2.device
+                dbih = o_bi if o_bi is not None else torch.empty(2 * G, dtype=torch.float32, device=dev_)
+                dwcat = ops.linear_backward_weight(dgi2, Gs.inp, out=o_w, colsum_out=dbih)      # (2G, K)
+                dbhh = dbih if S.lstm else (o_bh if o_bh is not None else torch.empty(2 * G, dtype=torch.float32, device=dev_))
+                if S.lstm and o_bh is not None:
+                    dbhh = ops.copy_into(o_bh, dbih)
                 for d, tag in ((0, ""), (1, "_reverse")):
                     gh = dgh2[:, d * G:(d + 1) * G]
                     dwih = dwcat[d * G:(d + 1) * G]
@@ -752,7 +762,8 @@ def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq, go
                     elif o_w is None:
                         dwih = _into(gout(wih), dwih)
                     put(wih, dwih)
-                    put(whh, ops.linear_backward_weight(gh, hp2[:, d * Hh:(d + 1) * Hh], out=gout(whh)))
+                    put(whh, ops.linear_backward_weight(gh, hp2[:, d * Hh:(d + 1) * Hh], out=gout(whh),
+                                                        colsum_out=None if S.lstm else dbhh[d * G:(d + 1) * G]))
                     put(bih, dbih[d * G:(d + 1) * G] if o_bi is not None else _into(gout(bih), dbih[d * G:(d + 1) * G]))
                     put(bhh, dbhh[d * G:(d + 1) * G] if o_bh is not None else _into(gout(bhh), dbhh[d * G:(d + 1) * G]))
             sq.small(rnn_wgrads, dgi2, dgh2, hp2, Gs.inp)
@@ -761,7 +772,7 @@ def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq, go
         din = ops.linear_nt_split(dgi2, Gs.wcatT, None, out_dtype=odt)
         if layer == 1:
             dout = din.view(B, T, H2)
-            if S.gru[0].mask is not None:
+            if S.gru[0].mask is not None and S.lstm:
                 dout = ops.mul(dout, S.gru[0].mask)
         else:
             dseq = din
@@ -1134,8 +1145,7 @@ def grl_train_step(model, x, labels_emo, labels_gen, weights, gender_lambda, sca
         ops.stamp("step start", dev)
         # ---- random numbers of the step on s2 while the caller's feature stage runs on cur
         def draws():
-            ops.rng(dev, "dropout").begin_step()
-            ops.rng(dev, "eps").begin_step()
+            ops.begin_step(dev)
             return noise._epsilon(1)
         masks1 = masks2 = None
         if two and before_cloak is not None:
@@ -1350,8 +1360,7 @@ def grl_train_step_segmented(sched, model, x, labels_emo, labels_gen, weights, g
     st = SimpleNamespace()
     with torch.no_grad():
         def draws():        # s2: the step's random numbers and its weight-only work, beside the feature stage
-            ops.rng(dev, "dropout").begin_step()
-            ops.rng(dev, "eps").begin_step()
+            ops.begin_step(dev)
             st.eps = noise._epsilon(1)
             w_in = rhos.shape[-1]
             prepare_operands(P2, w_in)

@@ -662,8 +662,10 @@ def linear_backward_input(dy, W, out=None, out_dtype=torch.float32):
     return gemm_raw(dy, dy.stride(0), 1, W, K, 1, out, out.stride(0), M, K, N)
 
 
-def linear_backward_weight(dy, x, out=None):
-    """dW[N][K] = dy[M][N]^T x[M][K]  (dy / x may be row-strided views)."""
+def linear_backward_weight(dy, x, out=None, colsum_out=None):
+    """dW[N][K] = dy[M][N]^T x[M][K]  (dy / x may be row-strided views).  colsum_out (N floats, optional) also receives
+    the column sums of dy -- the bias gradient that goes with dW -- from the same launch where the split-operand kernel
+    runs the product, from a column-sum launch otherwise."""
     M, N = dy.shape
     K = x.shape[1]
     if out is None:
@@ -675,10 +677,19 @@ def linear_backward_weight(dy, x, out=None):
         # long sample axis: split-operand bf16 MFMA with transposing LDS reads (sept_gemm_tn_split)
         wsn = lib.sept_gemm_tn_workspace_floats(N, K)
         ws = workspace("gemm_tn", wsn, dy.device)
+        if colsum_out is not None:
+            if colsum_out.numel() != N or colsum_out.dtype != torch.float32 or not colsum_out.is_contiguous():
+                raise SeptError(f"linear_backward_weight: colsum_out must hold {N} contiguous fp32 values")
+            check(lib.sept_gemm_tn_split_colsum(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), _is_bf16(x),
+                                                out.data_ptr(), out.stride(0), colsum_out.data_ptr(), N, K, M, ws.data_ptr(),
+                                                wsn, _s(out)), "sept_gemm_tn_split_colsum")
+            return out
         check(lib.sept_gemm_tn_split(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), _is_bf16(x),
                                      out.data_ptr(), out.stride(0), N, K, M, ws.data_ptr(), wsn, _s(out)),
               "sept_gemm_tn_split")
         return out
+    if colsum_out is not None:
+        colsum(dy, out=colsum_out)
     return gemm_raw(dy, 1, dy.stride(0), x, x.stride(0), 1, out, out.stride(0), N, K, M)
 
 
@@ -692,12 +703,21 @@ def colsum(a, out=None, accumulate=False):
     return out
 
 
-def gru_forward(gi, whh_f, whh_r, bhh_f, bhh_r):
-    """gi (B,T,2,3H), whh_* (3H,H), bhh_* (3H) -> out (B,T,2H), gates (B,T,2,4,H)."""
+def gru_forward(gi, whh_f, whh_r, bhh_f, bhh_r, mask=None):
+    """gi (B,T,2,3H), whh_* (3H,H), bhh_* (3H) -> out (B,T,2H), gates (B,T,2,4,H); with `mask` (B,T,2H) also
+    out * mask (the inter-layer dropout, written by the same kernel) as a third result."""
     B, T = gi.shape[0], gi.shape[1]
     H = whh_f.shape[1]
     out = torch.empty((B, T, 2 * H), dtype=torch.float32, device=gi.device)
     gates = torch.empty((B, T, 2, 4, H), dtype=torch.float32, device=gi.device)
+    if mask is not None:
+        if tuple(mask.shape) != (B, T, 2 * H) or mask.dtype != torch.float32 or not mask.is_contiguous():
+            raise SeptError(f"gru_forward: mask must be a contiguous fp32 (B, T, 2H) tensor, got {tuple(mask.shape)} {mask.dtype}")
+        outm = torch.empty_like(out)
+        check(lib.sept_gru_forward_masked(gi.data_ptr(), whh_f.data_ptr(), whh_r.data_ptr(), bhh_f.data_ptr(),
+                                          bhh_r.data_ptr(), out.data_ptr(), gates.data_ptr(), mask.data_ptr(), outm.data_ptr(),
+                                          B, T, H, _s(gi)), "sept_gru_forward_masked")
+        return out, gates, outm
     check(lib.sept_gru_forward(gi.data_ptr(), whh_f.data_ptr(), whh_r.data_ptr(), bhh_f.data_ptr(), bhh_r.data_ptr(),
                                out.data_ptr(), gates.data_ptr(), B, T, H, _s(gi)), "sept_gru_forward")
     return out, gates
@@ -727,12 +747,21 @@ def lstm_backward(dout, out, gates, cells, whh_f, whh_r):
     return dgates, hprev
 
 
-def gru_backward(dout, out, gates, whh_f, whh_r):
+def gru_backward(dout, out, gates, whh_f, whh_r, dout_mask=None):
+    """`dout_mask`: the incoming gradient is dout * dout_mask (the gradient of the masked output the next layer consumed),
+    multiplied inside the kernel."""
     B, T = dout.shape[0], dout.shape[1]
     H = whh_f.shape[1]
     dgi = torch.empty((B, T, 2, 3 * H), dtype=torch.float32, device=dout.device)
     dgh = torch.empty_like(dgi)
     hprev = torch.empty((B, T, 2, H), dtype=torch.float32, device=dout.device)
+    if dout_mask is not None:
+        if dout_mask.numel() != dout.numel() or dout_mask.dtype != torch.float32 or not dout_mask.is_contiguous():
+            raise SeptError("gru_backward: dout_mask must be a contiguous fp32 tensor of dout's size")
+        check(lib.sept_gru_backward_masked(dout.data_ptr(), dout_mask.data_ptr(), out.data_ptr(), gates.data_ptr(),
+                                           whh_f.data_ptr(), whh_r.data_ptr(), dgi.data_ptr(), dgh.data_ptr(), hprev.data_ptr(),
+                                           B, T, H, _s(dout)), "sept_gru_backward_masked")
+        return dgi, dgh, hprev
     check(lib.sept_gru_backward(dout.data_ptr(), out.data_ptr(), gates.data_ptr(), whh_f.data_ptr(), whh_r.data_ptr(),
                                 dgi.data_ptr(), dgh.data_ptr(), hprev.data_ptr(), B, T, H, _s(dout)),
           "sept_gru_backward")
@@ -1106,6 +1135,14 @@ class Rng:
 
 
 _RNGS = {}
+
+
+def begin_step(device):
+    """Advance the step counters of the device's 'dropout' and 'eps' Philox streams (and restart their call-site numbering)
+    in ONE launch: what every training step does first."""
+    a, b = rng(device, "dropout"), rng(device, "eps")
+    check(lib.sept_counter_add2(a.counter.data_ptr(), b.counter.data_ptr(), 1, _s(a.counter)), "sept_counter_add2")
+    a.sub = b.sub = 0
 
 
 def _derive_seed(base, name):

@@ -26,8 +26,7 @@ SEGMENTED = os.environ.get("SEPT_SEGMENTED", "0") == "1"
 
 def _advance_rng(device):
     """New Philox sub-streams for this step (device-side counters: also valid inside a graph)."""
-    ops.rng(device, "dropout").begin_step()
-    ops.rng(device, "eps").begin_step()
+    ops.begin_step(device)
 
 
 class FlatParams:
@@ -240,10 +239,10 @@ class _TrainerBase:
         gscale = 1.0 / self.world
         self._ensure_state()
         self.steps += 1
-        ops.counter_add(self.step_dev, 1)
-        if self.kind == "sgd":
+        if self.kind == "sgd":      # (only Adam reads the device-side step count)
             ops.sgd_step_dev(w, g, self._state[0], self.lr_dev, self.momentum, self.weight_decay, gscale)
         else:
+            ops.counter_add(self.step_dev, 1)
             ops.adam_step_dev(w, g, self._state[0], self._state[1], self.lr_dev, self.betas[0], self.betas[1],
                               self.eps, self.weight_decay, self.step_dev, gscale)
         SF.invalidate_weight_cache()  # parameters changed through raw pointers

@@ -85,6 +85,21 @@ def test_gemm_tn_split(S, N, K, xbf16):
         dyw, xw = dy.cuda(), x.cuda()
         got2 = ops.linear_backward_weight(dyw[:, N // 2:], xw[:, K // 2:])
         assert torch.allclose(got2, got[N // 2:, K // 2:], rtol=1e-5, atol=1e-4)
+    # the bias gradient (column sums of dy) from the same launch: same dW bit for bit, sums against float64, an output
+    # slot that is not 16-byte aligned (a parameter's place in the flat gradient buffer), and a column-slice view of dy
+    slot = torch.full((N + 3,), 7.0, device="cuda")
+    got3 = ops.linear_backward_weight(dy.cuda(), x.cuda(), colsum_out=slot[1:N + 1])
+    assert torch.equal(got3, got)
+    want_cs = dy.double().sum(0)
+    assert (slot[1:N + 1].cpu().double() - want_cs).abs().max() < 3e-6 * S ** 0.5 * (1 + want_cs.abs().max() / S ** 0.5)
+    assert float(slot[0]) == 7.0 and float(slot[N + 1]) == 7.0           # nothing written outside the slot
+    cs2 = torch.empty(N, device="cuda")
+    ops.linear_backward_weight(dy.cuda(), x.cuda(), colsum_out=cs2)
+    assert torch.equal(cs2, slot[1:N + 1])                               # deterministic
+    if N % 8 == 0 and K % 16 == 0:
+        cs3 = torch.empty(N - N // 2, device="cuda")
+        ops.linear_backward_weight(dyw[:, N // 2:], xw[:, K // 2:], colsum_out=cs3)
+        assert torch.allclose(cs3, cs2[N // 2:], rtol=1e-5, atol=1e-4)
 
 
 def test_gru_pack_matches_permute_and_transpose():
