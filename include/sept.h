@@ -360,22 +360,24 @@ int sept_conv1_bn_relu_pool_backward_apply(const float* x, const float* w, const
  *   ext (B, H/2, W/2, 32) bf16                the window's extremum of the rounded conv output,
  *   idx (B, H/2, W/2, 32) u8                  its window position (scan order 0..3, first one wins).
  * sept_bn_relu_ext_forward then forms y = dropscale * relu(sc * ext + sh) (bit-identical to sept_bn_relu_pool_forward
- * on the stored pre-activations) and re-marks idx = 4 where the ReLU is inactive (the convention of
- * sept_bn_relu_pool_forward_argmax); px_per_item = pooled pixels per batch item (the Dropout2d scale is per item).
- * Backward: (sum g, sum g * xhat) from (dy, ext, idx) -- xhat = (ext - mean) * invstd exactly, for any gamma -- either
- * in the epilogue of the data-gradient conv that produces dy (sept_conv5x5_dgrad_bnsums_ext, partials finished by
- * sept_bn_bwd_sums_from_partials) or by sept_bn_backward_sums_ext; then sept_conv1_backward_data_sparse (data gradient)
- * and sept_conv1_backward_weight_sparse (weight gradient) work from (dy, idx, x).  H even, W % 16 == 0
- * (sept_conv1_pool_supported); gamma NULL = all maxima. */
+ * on the stored pre-activations); px_per_item = pooled pixels per batch item (the Dropout2d scale is per item); with
+ * idx_u8 given it also re-marks idx = 4 where the ReLU is inactive (the convention of sept_bn_relu_pool_forward_argmax)
+ * -- the training path passes NULL and keeps the bytes pure positions.
+ * Backward: (sum g, sum g * xhat) from (dy, ext) -- the ReLU is active where fma(ext, sc, sh) > 0, xhat = (ext - mean) *
+ * invstd exactly, for any gamma -- either in the epilogue of the data-gradient conv that produces dy
+ * (sept_conv5x5_dgrad_bnsums_ext, partials finished by sept_bn_bwd_sums_from_partials) or by
+ * sept_bn_backward_sums_ext; BOTH leave dy MASKED (zero where the ReLU is inactive), which is what the consumers below
+ * rely on: sept_conv1_backward_data_sparse / _sum (data gradient) and sept_conv1_backward_weight_sparse (weight
+ * gradient) work from (masked dy, idx, x).  H even, W % 16 == 0 (sept_conv1_pool_supported); gamma NULL = all maxima. */
 int sept_conv1_pool_supported(int H, int W);
 int sept_conv1_forward_pool(const float* x, const float* w, const float* bias, float* wprep, const float* gamma,
                             void* ext_bf16, void* idx_u8, float* stats, int B, int H, int W, void* stream);
 int sept_bn_relu_ext_forward(const void* ext, void* idx_u8 /*nullable, in/out*/, const float* mean, const float* invstd,
                              const float* gamma, const float* beta, const float* dropscale, void* y, int B,
                              long px_per_item, int C, void* stream);
-int sept_bn_backward_sums_ext(const void* dy, const void* ext, const void* idx_u8, const float* mean, const float* invstd,
-                              const float* dropscale, float* ws, float* sums_out, float* dgamma, float* dbeta, int B,
-                              long px_per_item, int C, void* stream);
+int sept_bn_backward_sums_ext(void* dy /* masked in place */, const void* ext, const float* mean, const float* invstd,
+                              const float* gamma, const float* beta, const float* dropscale, float* ws, float* sums_out,
+                              float* dgamma, float* dbeta, int B, long px_per_item, int C, void* stream);
 size_t sept_conv1_wgrad_sparse_workspace_floats(void);
 int sept_conv1_backward_weight_sparse(const void* dy_pooled, const void* idx_u8, const float* x, const float* w_f32,
                                       const float* bias, const float* mean, const float* invstd, const float* gamma,
@@ -391,9 +393,10 @@ int sept_conv1_backward_data_sum(const void* dy_pooled, const void* idx_u8, cons
                                  const float* bias, const float* mean, const float* invstd, const float* gamma,
                                  const float* dropscale, const float* sums, double n_total, float* ws, float* coef,
                                  float* dxsum, int B, int H, int W, void* stream);
-int sept_conv5x5_dgrad_bnsums_ext(const void* dy_out, const void* wt, void* dx_out, const void* ext, const void* idx_u8,
-                                  const float* bn_mean, const float* bn_invstd, const float* dropscale, float* partials,
-                                  int B, int H, int W, int cin, int cout, void* stream);
+int sept_conv5x5_dgrad_bnsums_ext(const void* dy_out, const void* wt, void* dx_out /* stored masked */, const void* ext,
+                                  const float* bn_mean, const float* bn_invstd, const float* bn_gamma, const float* bn_beta,
+                                  const float* dropscale, float* partials, int B, int H, int W, int cin, int cout,
+                                  void* stream);
 
 /* y = a * x  (GradientReversalFunction.backward with a = -lambda, reversal_gradient.py:18-23) */
 int sept_scale(const float* x, float a, float* y, long n, void* stream);

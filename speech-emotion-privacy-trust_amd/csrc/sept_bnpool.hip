@@ -459,12 +459,14 @@ __global__ __launch_bounds__(256) void sept_bn_bwd_apply_kernel(BnBwdArgs a) {
 // ext [n_px][C] bf16 = the window's extremum of the conv output (maximum where gamma >= 0, minimum where gamma < 0),
 // idx [n_px][C] u8 = its position in the window.  Forward: y = dropscale * relu(sc * ext + sh), the same arithmetic
 // sept_bn_relu_pool_fwd_kernel applies to the winning element (bn is monotone per channel, so the window maximum of the
-// activations is the activation of the extremum: bit-identical); positions whose ReLU is inactive are re-marked P * P = 4
-// ("no gradient"), the convention sept_bn_relu_pool_forward_argmax established for the consumers of idx.
+// activations is the activation of the extremum: bit-identical).  With idx given, positions whose ReLU is inactive are
+// re-marked P * P = 4 ("no gradient", the convention of sept_bn_relu_pool_forward_argmax); the training path does NOT ask
+// for that (a read and a write of the byte tensor): the gradient of the pooled activation reaches its consumers already
+// masked (sept_conv5x5_dgrad_bnsums_ext / sept_bn_backward_sums_ext), so the bytes stay pure positions.
 struct BnExtArgs {
   const bf16* ext;
-  unsigned char* idx;       // in / out (nullable in the forward pass)
-  const bf16* dy;           // backward: gradient of the pooled activation
+  unsigned char* idx;       // forward: in / out, nullable (given: positions whose ReLU is inactive are re-marked 4)
+  bf16* dy;                 // backward: gradient of the pooled activation (masked in place)
   const float *mean, *invstd, *gamma, *beta, *drop;
   bf16* y;
   float* ws;                // backward: transposed partials [2C][blocks]
@@ -500,8 +502,10 @@ __global__ __launch_bounds__(256) void sept_bn_relu_ext_fwd_kernel(BnExtArgs a) 
   }
 }
 
-// backward sums of such a block from the pooled tensors alone: ge = dy * dropscale where idx != 4, xhat = (ext - mean) *
-// invstd EXACTLY (the extremum is the pre-activation the gradient lands on: no division by gamma, no tiny-|gamma| path)
+// backward sums of such a block from the pooled tensors alone: ge = dy * dropscale where the ReLU is active -- fma(ext, sc,
+// sh) > 0, the forward pass's own test -- and xhat = (ext - mean) * invstd EXACTLY (the extremum is the pre-activation the
+// gradient lands on: no division by gamma, no tiny-|gamma| path).  dy is MASKED IN PLACE (zero where inactive), as the
+// epilogue form of these sums (sept_conv5x5_dgrad_bnsums_ext) stores it: the consumers rely on that.
 template <int CPP>
 __global__ __launch_bounds__(256) void sept_bn_bwd_reduce_ext_kernel(BnExtArgs a) {
   constexpr int C = CPP * 8;
@@ -509,20 +513,26 @@ __global__ __launch_bounds__(256) void sept_bn_bwd_reduce_ext_kernel(BnExtArgs a
   const long n_items = a.n_px * CPP;
   const int chunk = threadIdx.x % CPP;
   const f32x8 mu = loadf8(a.mean + chunk * 8), is = loadf8(a.invstd + chunk * 8);
+  const f32x8 ga = loadf8(a.gamma + chunk * 8), be = loadf8(a.beta + chunk * 8);
+  const f32x8 sc = ga * is, sh = be - mu * ga * is;
   f32x8 s1 = {0, 0, 0, 0, 0, 0, 0, 0}, s2 = {0, 0, 0, 0, 0, 0, 0, 0};
   for (long i = long(blockIdx.x) * 256 + threadIdx.x; i < n_items; i += long(gridDim.x) * 256) {
     const long px = i / CPP;
     f32x8 g = load8(a.dy + px * C + chunk * 8);
-    const f32x8 xh = (load8(a.ext + px * C + chunk * 8) - mu) * is;
-    const uint2 pk = *reinterpret_cast<const uint2*>(a.idx + px * C + chunk * 8);
-    if (a.drop) g *= loadf8(a.drop + (px / a.per_b) * C + chunk * 8);
+    const f32x8 ex = load8(a.ext + px * C + chunk * 8);
+    const f32x8 xh = (ex - mu) * is;
+    bool any_off = false;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const unsigned k = ((e < 4 ? pk.x : pk.y) >> (8 * (e & 3))) & 0xFFu;
-      const float ge = k < 4u ? g[e] : 0.f;
-      s1[e] += ge;
-      s2[e] += ge * xh[e];
+      if (!(__builtin_fmaf(ex[e], sc[e], sh[e]) > 0.f)) {
+        g[e] = 0.f;
+        any_off = true;
+      }
     }
+    if (any_off) store8(a.dy + px * C + chunk * 8, g);   // (the surviving entries round-trip bf16 -> fp32 -> bf16 unchanged)
+    if (a.drop) g *= loadf8(a.drop + (px / a.per_b) * C + chunk * 8);
+    s1 += g;
+    s2 += g * xh;
   }
   block_reduce_2c<CPP>(s1, s2, a.ws, gridDim.x, lds);
 }
@@ -795,17 +805,18 @@ extern "C" int sept_bn_relu_ext_forward(const void* ext, void* idx_u8, const flo
   return sept::launch_check("sept_bn_relu_ext_fwd_kernel");
 }
 
-// sums_out[2C] = (sum g, sum g * xhat) (+ dgamma / dbeta) from (dy, ext, idx): the reduce pass for callers whose
-// producer did not leave partials (sept_conv5x5_dgrad_bnsums_ext does).  ws: sept_bn_workspace_floats(C) floats.
-extern "C" int sept_bn_backward_sums_ext(const void* dy, const void* ext, const void* idx_u8, const float* mean,
-                                         const float* invstd, const float* dropscale, float* ws, float* sums_out,
-                                         float* dgamma, float* dbeta, int B, long px_per_item, int C, void* stream) {
+// sums_out[2C] = (sum g, sum g * xhat) (+ dgamma / dbeta) from (dy, ext): the reduce pass for callers whose producer did
+// not leave partials (sept_conv5x5_dgrad_bnsums_ext does).  dy is masked IN PLACE (zero where the block's ReLU is inactive).
+// ws: sept_bn_workspace_floats(C) floats.
+extern "C" int sept_bn_backward_sums_ext(void* dy, const void* ext, const float* mean, const float* invstd, const float* gamma,
+                                         const float* beta, const float* dropscale, float* ws, float* sums_out, float* dgamma,
+                                         float* dbeta, int B, long px_per_item, int C, void* stream) {
   SEPT_REQUIRE(B > 0 && px_per_item > 0, SEPT_ERR_INVALID, "sept_bn_backward_sums_ext: B=%d px=%ld", B, px_per_item);
-  SEPT_REQUIRE(dy && ext && idx_u8 && mean && invstd && ws && sums_out, SEPT_ERR_INVALID, "sept_bn_backward_sums_ext: null argument");
+  SEPT_REQUIRE(dy && ext && mean && invstd && gamma && beta && ws && sums_out, SEPT_ERR_INVALID,
+               "sept_bn_backward_sums_ext: null argument");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  BnExtArgs a{static_cast<const bf16*>(ext), const_cast<unsigned char*>(static_cast<const unsigned char*>(idx_u8)),
-              static_cast<const bf16*>(dy), mean, invstd, nullptr, nullptr, dropscale, nullptr, ws, long(B) * px_per_item,
-              px_per_item};
+  BnExtArgs a{static_cast<const bf16*>(ext), nullptr, static_cast<bf16*>(dy), mean, invstd, gamma, beta, dropscale, nullptr, ws,
+              long(B) * px_per_item, px_per_item};
   const int grid = grid_for(a.n_px * (C / 8));
   SEPT_CPP_DISPATCH(C, hipLaunchKernelGGL(sept_bn_bwd_reduce_ext_kernel<CPP>, dim3(grid), dim3(256), 0, st, a));
   hipLaunchKernelGGL(sept_bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, ws, grid, C, dgamma, dbeta, sums_out, false);

@@ -51,10 +51,11 @@ struct ConvArgs {
   // exactly as sept_bn_bwd_reduce_pooled_kernel forms them (xhat = (y / drop - beta) / gamma where y > 0).
   const bf16* ypool;
   const float *bn_gamma, *bn_beta, *drop;
-  // ... or, for a block whose pooling window was resolved before its BatchNorm (sept_conv1_forward_pool): ypool = ext
-  // (the window's extremum of the pre-activation), bn_idx = its position bytes (4 = ReLU inactive), bn_mean / bn_invstd:
-  // xhat = (ext - mean) * invstd exactly, ge = g * drop where idx != 4 (no division by gamma)
-  const unsigned char* bn_idx;
+  // ... or, for a block whose pooling window was resolved before its BatchNorm (sept_conv1_forward_pool): bn_mean /
+  // bn_invstd non-null, ypool = ext (the window's extremum of the pre-activation): the ReLU is active where
+  // fma(ext, gamma * invstd, beta - mean * gamma * invstd) > 0 (the test the forward pass made), xhat = (ext - mean) *
+  // invstd exactly (no division by gamma), and the OUTPUT is stored MASKED -- zero where the ReLU is inactive -- so that
+  // the consumers of this gradient need no activity information of their own (the position bytes stay pure positions)
   const float *bn_mean, *bn_invstd;
 };
 
@@ -283,6 +284,35 @@ void sept_conv5x5_mfma_kernel(ConvArgs a) {
     }
   }
   __syncthreads();
+  constexpr int NGRP = STATS ? NTHR / COUT : 1;   // pixel groups summed side by side
+  float* red = reinterpret_cast<float*>(smem + size_t(MT) * SP);   // [NGRP][2][COUT]
+  bool sums_done = false;
+  if constexpr (EPI == kEpiBwSums) {
+    if (a.bn_mean) {
+      // pool-first block in front: sums over the ACTIVE elements, and the tile is masked in place before it leaves
+      const int c = tid % COUT, grp = tid / COUT;
+      const float d = a.drop ? a.drop[size_t(b) * COUT + c] : 1.0f;
+      const float mu = a.bn_mean[c], is = a.bn_invstd[c];
+      const float sc = a.bn_gamma[c] * is, sh = a.bn_beta[c] - mu * a.bn_gamma[c] * is;
+      const bf16* ep = a.ypool + (size_t(b) * HW + q0) * COUT + c;
+      const int np = min(MT, HW - q0);
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll 8
+      for (int p = grp; p < np; p += NGRP) {
+        bf16* gp = reinterpret_cast<bf16*>(smem + size_t(p) * SP + c * 2);
+        const float e = float(ep[size_t(p) * COUT]);
+        const bool active = __builtin_fmaf(e, sc, sh) > 0.f;
+        const float ge = active ? float(*gp) * d : 0.f;
+        if (!active) *gp = (bf16)0.f;
+        t1 += ge;
+        t2 += ge * ((e - mu) * is);
+      }
+      red[(grp * 2 + 0) * COUT + c] = t1;
+      red[(grp * 2 + 1) * COUT + c] = t2;
+      sums_done = true;
+      __syncthreads();
+    }
+  }
   {
     constexpr int CPR = COUT / 8;                       // 16-byte chunks per pixel
     const int nch = min(MT, HW - q0) * CPR;             // the tile's pixels inside the image
@@ -291,11 +321,9 @@ void sept_conv5x5_mfma_kernel(ConvArgs a) {
       dst[i] = *reinterpret_cast<const uint4*>(smem + size_t(i / CPR) * SP + (i % CPR) * 16);
   }
   if constexpr (STATS) {
-    constexpr int NGRP = NTHR / COUT;   // pixel groups summed side by side
     static_assert(NTHR % COUT == 0 && MT % NGRP == 0, "column sums need whole pixel groups");
-    float* red = reinterpret_cast<float*>(smem + size_t(MT) * SP);   // [NGRP][2][COUT]
-    __syncthreads();
-    {
+    if (!sums_done) {
+      __syncthreads();
       const int c = tid % COUT, grp = tid / COUT;
       float t1 = 0.f, t2 = 0.f;
       if constexpr (EPI == kEpiStats) {
@@ -304,20 +332,6 @@ void sept_conv5x5_mfma_kernel(ConvArgs a) {
           const float v = float(*reinterpret_cast<const bf16*>(smem + size_t(p) * SP + c * 2));
           t1 += v;
           t2 += v * v;
-        }
-      } else if (a.bn_idx) {
-        const float d = a.drop ? a.drop[size_t(b) * COUT + c] : 1.0f;
-        const float mu = a.bn_mean[c], is = a.bn_invstd[c];
-        const bf16* ep = a.ypool + (size_t(b) * HW + q0) * COUT + c;
-        const unsigned char* ip = a.bn_idx + (size_t(b) * HW + q0) * COUT + c;
-        const int np = min(MT, HW - q0);
-#pragma unroll 8
-        for (int p = grp; p < np; p += NGRP) {
-          const float g = float(*reinterpret_cast<const bf16*>(smem + size_t(p) * SP + c * 2)) * d;
-          const float xh = (float(ep[size_t(p) * COUT]) - mu) * is;
-          const float ge = ip[size_t(p) * COUT] < 4 ? g : 0.f;
-          t1 += ge;
-          t2 += ge * xh;
         }
       } else {
         const float d = a.drop ? a.drop[size_t(b) * COUT + c] : 1.0f;
@@ -491,8 +505,8 @@ const ConvVariant* conv_pick(int W, int cin, int cout, bool want_stats, size_t* 
 
 int conv_launch(const char* who, const void* x, const void* wt, const float* bias, void* y, float* stats, int B, int H,
                 int W, int cin, int cout, void* stream, const void* ypool = nullptr, const float* bn_gamma = nullptr,
-                const float* bn_beta = nullptr, const float* drop = nullptr, const void* bn_idx = nullptr,
-                const float* bn_mean = nullptr, const float* bn_invstd = nullptr) {
+                const float* bn_beta = nullptr, const float* drop = nullptr, const float* bn_mean = nullptr,
+                const float* bn_invstd = nullptr) {
   SEPT_REQUIRE(B >= 0 && H > 0 && W > 0, SEPT_ERR_INVALID, "%s: B=%d H=%d W=%d", who, B, H, W);
   if (B == 0) return SEPT_OK;
   SEPT_REQUIRE(x && wt && y, SEPT_ERR_INVALID, "%s: null argument", who);
@@ -512,7 +526,6 @@ int conv_launch(const char* who, const void* x, const void* wt, const float* bia
   a.bn_gamma = bn_gamma;
   a.bn_beta = bn_beta;
   a.drop = drop;
-  a.bn_idx = static_cast<const unsigned char*>(bn_idx);
   a.bn_mean = bn_mean;
   a.bn_invstd = bn_invstd;
   a.y = static_cast<bf16*>(y);
@@ -580,15 +593,15 @@ extern "C" int sept_conv5x5_dgrad_bnsums(const void* dy_out, const void* wt, voi
                      bn_gamma, bn_beta, dropscale);
 }
 
-// The same for a block in pool-first form (sept_conv1_forward_pool): ext / idx_u8 (B, H, W, cout) are that block's
-// extremum values and position bytes (after sept_bn_relu_ext_forward: 4 = ReLU inactive), mean / invstd its batch
-// statistics.  The partials are exact for every gamma: sept_bn_bwd_sums_from_partials finishes them.
+// The same for a block in pool-first form (sept_conv1_forward_pool): ext (B, H, W, cout) = that block's extremum values,
+// mean / invstd / gamma / beta its BatchNorm.  The partials are exact for every gamma (sept_bn_bwd_sums_from_partials
+// finishes them) and dx_out is stored MASKED: zero where that block's ReLU is inactive.
 extern "C" int sept_conv5x5_dgrad_bnsums_ext(const void* dy_out, const void* wt, void* dx_out, const void* ext,
-                                             const void* idx_u8, const float* bn_mean, const float* bn_invstd,
-                                             const float* dropscale, float* partials, int B, int H, int W, int cin, int cout,
-                                             void* stream) {
-  SEPT_REQUIRE(partials && ext && idx_u8 && bn_mean && bn_invstd && B > 0 && cin > cout, SEPT_ERR_INVALID,
+                                             const float* bn_mean, const float* bn_invstd, const float* bn_gamma,
+                                             const float* bn_beta, const float* dropscale, float* partials, int B, int H,
+                                             int W, int cin, int cout, void* stream) {
+  SEPT_REQUIRE(partials && ext && bn_mean && bn_invstd && bn_gamma && bn_beta && B > 0 && cin > cout, SEPT_ERR_INVALID,
                "sept_conv5x5_dgrad_bnsums_ext: null argument / empty batch / not a data-gradient shape (cin=%d cout=%d)", cin, cout);
   return conv_launch("sept_conv5x5_dgrad_bnsums_ext", dy_out, wt, nullptr, dx_out, partials, B, H, W, cin, cout, stream, ext,
-                     nullptr, nullptr, dropscale, idx_u8, bn_mean, bn_invstd);
+                     bn_gamma, bn_beta, dropscale, bn_mean, bn_invstd);
 }

@@ -476,7 +476,7 @@ size_t smem_of(int F) {
 const Variant kVariants[] = {
     SEPT_MEL_VARIANT(800, 160, 20, 20, 20, 2, true),   SEPT_MEL_VARIANT(800, 160, 20, 20, 20, 1, true),
     SEPT_MEL_VARIANT(1600, 160, 40, 20, 20, 2, false), SEPT_MEL_VARIANT(1600, 160, 40, 20, 20, 1, false),
-    SEPT_MEL_VARIANT(1024, 160, 16, 32, 16, 2, true),  SEPT_MEL_VARIANT(1024, 160, 16, 32, 16, 1, true),
+    SEPT_MEL_VARIANT(1024, 160, 16, 32, 16, 2, false), SEPT_MEL_VARIANT(1024, 160, 16, 32, 16, 1, false),
     SEPT_MEL_VARIANT(400, 200, 10, 20, 10, 2, true),   SEPT_MEL_VARIANT(400, 200, 10, 20, 10, 1, true),
     SEPT_MEL_VARIANT(400, 160, 10, 20, 10, 2, true),   SEPT_MEL_VARIANT(400, 160, 10, 20, 10, 1, true),
 };

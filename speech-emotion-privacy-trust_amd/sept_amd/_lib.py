@@ -150,8 +150,8 @@ SIGNATURES = {
     "sept_conv1_pool_supported": (c_int, [c_int, c_int]),
     "sept_conv1_forward_pool": (c_int, [c_void_p] * 8 + [c_int] * 3 + [c_void_p]),
     "sept_bn_relu_ext_forward": (c_int, [c_void_p] * 8 + [c_int, c_long, c_int, c_void_p]),
-    "sept_bn_backward_sums_ext": (c_int, [c_void_p] * 10 + [c_int, c_long, c_int, c_void_p]),
-    "sept_conv5x5_dgrad_bnsums_ext": (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_void_p]),
+    "sept_bn_backward_sums_ext": (c_int, [c_void_p] * 11 + [c_int, c_long, c_int, c_void_p]),
+    "sept_conv5x5_dgrad_bnsums_ext": (c_int, [c_void_p] * 10 + [c_int] * 5 + [c_void_p]),
     "sept_conv1_wgrad_sparse_workspace_floats": (c_size_t, []),
     "sept_conv1_backward_weight_sparse": (c_int, [c_void_p] * 10 + [c_double] + [c_void_p] * 3 + [c_int] * 3 + [c_void_p]),
     "sept_conv1_dsum_workspace_floats": (c_size_t, [c_int, c_int]),

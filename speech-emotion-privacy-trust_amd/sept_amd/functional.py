@@ -261,7 +261,7 @@ def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None, gfeat=Non
             if train and (P.drop_ps[li] > 0 or "drop2d" in inj):
                 d2 = inj.get("drop2d")
                 drop = d2[li] if d2 is not None else masks[("c", li)]
-            out = ops.bn_relu_ext_forward(ext, idx if need_grad else None, mean, invstd, bn.weight, bn.bias, drop)
+            out = ops.bn_relu_ext_forward(ext, None, mean, invstd, bn.weight, bn.bias, drop)   # idx stays pure positions
             S.blocks.append(SimpleNamespace(inp=None, pre=None, ext=ext, out=out, mean=mean, invstd=invstd, drop=drop, pool=pool,
                                             h=h, w=w, bn_train=True, sync=False, l1_fused=False, idx=idx))
             act = out
@@ -790,8 +790,8 @@ def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq, go
         if li == 0 and blk.ext is not None:
             # pool-first block 1: channel sums from (dy, ext, idx) -- formed by the data-gradient conv above when it could --
             # then the data gradient from the pooled gradient, the position bytes and the input
-            sums, dgamma, dbeta = ops.bn_backward_sums_ext(dact, blk.ext, blk.idx, blk.mean, blk.invstd, blk.drop, presums,
-                                                           need_param_grads=want_bn,
+            sums, dgamma, dbeta = ops.bn_backward_sums_ext(dact, blk.ext, blk.mean, blk.invstd, bn.weight, bn.bias, blk.drop,
+                                                           presums, need_param_grads=want_bn,
                                                            out_gamma=gout(bn.weight) if want_bn else None,
                                                            out_beta=gout(bn.bias) if want_bn else None)
             if want_bn:
@@ -897,7 +897,13 @@ def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq, go
             wtd = _cached("convdgrad", cv.weight, lambda: ops.conv5x5_prep_weights(cv.weight, 1))
             prev = S.blocks[li - 1]
             if prev.ext is not None:
-                dact, presums = ops.conv5x5_dgrad_bnsums_ext(dpre, wtd, prev.ext, prev.idx, prev.mean, prev.invstd, prev.drop)
+                # the producer masks the gradient (zero where block 1's ReLU is inactive) and leaves the sums; without such
+                # a kernel form the plain conv runs and ops.bn_backward_sums_ext masks + sums in the next iteration
+                pbn = P.bns[li - 1]
+                dact, presums = ops.conv5x5_dgrad_bnsums_ext(dpre, wtd, prev.ext, prev.mean, prev.invstd, pbn.weight, pbn.bias,
+                                                             prev.drop)
+                if dact is None:
+                    dact, presums = ops.conv5x5(dpre, wtd), None
             elif (BN_SUMS_IN_DGRAD and BN_POOLED_SUMS and prev.bn_train and not prev.sync and not prev.l1_fused
                     and prev.pool == 2):
                 # the data-gradient conv's epilogue also forms the backward sums of the BatchNorm in front (from its

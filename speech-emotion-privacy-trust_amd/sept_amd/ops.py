@@ -486,7 +486,8 @@ def conv1_forward_pool(x, w, bias, gamma, bn_running_mean=None, bn_running_var=N
 
 
 def bn_relu_ext_forward(ext, idx, mean, invstd, gamma, beta, dropscale=None):
-    """y = dropscale * relu(bn(ext)) for a pool-first block; idx (nullable) is re-marked 4 where the ReLU is inactive."""
+    """y = dropscale * relu(bn(ext)) for a pool-first block; idx (None on the training path: its backward works on a masked
+    gradient) is re-marked 4 where the ReLU is inactive."""
     require_cuda(ext, mean, invstd, gamma, beta)
     B, Ho, Wo, C = ext.shape
     y = torch.empty_like(ext)
@@ -496,30 +497,31 @@ def bn_relu_ext_forward(ext, idx, mean, invstd, gamma, beta, dropscale=None):
     return y
 
 
-def conv5x5_dgrad_bnsums_ext(dy_out, wtd, ext, idx, mean, invstd, dropscale=None):
-    """conv5x5_dgrad_bnsums for a block in pool-first form: the partials come from (dx, ext, idx) and are exact for any
-    gamma.  -> (dx, (partials, nparts)) or (dx, None) when the shape has no such kernel form."""
-    require_cuda(dy_out, wtd, ext, idx)
+def conv5x5_dgrad_bnsums_ext(dy_out, wtd, ext, mean, invstd, gamma, beta, dropscale=None):
+    """conv5x5_dgrad_bnsums for a block in pool-first form: the partials come from (dx, ext) and are exact for any gamma,
+    and dx is stored MASKED (zero where that block's ReLU is inactive).  -> (dx, (partials, nparts)) or (None, None) when the
+    shape has no such kernel form (the caller then runs the plain conv + bn_backward_sums_ext, which masks as well)."""
+    require_cuda(dy_out, wtd, ext)
     B, H, W, cin = dy_out.shape
     cout = wtd.shape[1]
     nparts = lib.sept_conv5x5_bwsums_parts(B, H, W, cin, cout)
-    if nparts <= 0 or tuple(ext.shape) != (B, H, W, cout) or tuple(idx.shape) != (B, H, W, cout):
-        return conv5x5(dy_out, wtd), None
+    if nparts <= 0 or tuple(ext.shape) != (B, H, W, cout):
+        return None, None
     dx = torch.empty((B, H, W, cout), dtype=torch.bfloat16, device=dy_out.device)
     parts = workspace(f"conv5x5_bwsums{cout}", nparts * 2 * cout, dy_out.device)
     h = TIMER.start(f"conv5x5_mfma<{cin},{cout}>") if TIMER is not None else None
-    check(lib.sept_conv5x5_dgrad_bnsums_ext(dy_out.data_ptr(), wtd.data_ptr(), dx.data_ptr(), ext.data_ptr(), idx.data_ptr(),
-                                            mean.data_ptr(), invstd.data_ptr(), _p(dropscale), parts.data_ptr(), B, H, W, cin,
-                                            cout, _s(dx)), "sept_conv5x5_dgrad_bnsums_ext")
+    check(lib.sept_conv5x5_dgrad_bnsums_ext(dy_out.data_ptr(), wtd.data_ptr(), dx.data_ptr(), ext.data_ptr(), mean.data_ptr(),
+                                            invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _p(dropscale),
+                                            parts.data_ptr(), B, H, W, cin, cout, _s(dx)), "sept_conv5x5_dgrad_bnsums_ext")
     if h is not None:
         TIMER.stop(h)
     return dx, (parts, nparts)
 
 
-def bn_backward_sums_ext(dy, ext, idx, mean, invstd, dropscale, presums=None, need_param_grads=True, out_gamma=None,
+def bn_backward_sums_ext(dy, ext, mean, invstd, gamma, beta, dropscale, presums=None, need_param_grads=True, out_gamma=None,
                          out_beta=None):
-    """(sum g, sum g * xhat) [2C] of a pool-first block (+ dgamma, dbeta): from a producer's partials, else by a reduce
-    pass over (dy, ext, idx)."""
+    """(sum g, sum g * xhat) [2C] of a pool-first block (+ dgamma, dbeta): from a producer's partials (dy is then already
+    masked), else by a reduce pass over (dy, ext) that also MASKS dy in place (zero where the block's ReLU is inactive)."""
     C = ext.shape[-1]
     dev = ext.device
     sums = torch.empty(2 * C, dtype=torch.float32, device=dev)
@@ -533,10 +535,12 @@ def bn_backward_sums_ext(dy, ext, idx, mean, invstd, dropscale, presums=None, ne
               "sept_bn_bwd_sums_from_partials")
     else:
         B, Ho, Wo, _ = ext.shape
+        if dy.dtype != torch.bfloat16 or not dy.is_contiguous() or tuple(dy.shape) != tuple(ext.shape):
+            raise SeptError("bn_backward_sums_ext: dy must be a contiguous bf16 tensor of ext's shape")
         ws = workspace("bn", lib.sept_bn_workspace_floats(C), dev)
-        check(lib.sept_bn_backward_sums_ext(dy.data_ptr(), ext.data_ptr(), idx.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
-                                            _p(dropscale), ws.data_ptr(), sums.data_ptr(), _p(dgamma), _p(dbeta), B, Ho * Wo, C,
-                                            _s(ext)), "sept_bn_backward_sums_ext")
+        check(lib.sept_bn_backward_sums_ext(dy.data_ptr(), ext.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+                                            beta.data_ptr(), _p(dropscale), ws.data_ptr(), sums.data_ptr(), _p(dgamma), _p(dbeta),
+                                            B, Ho * Wo, C, _s(ext)), "sept_bn_backward_sums_ext")
     return sums, dgamma, dbeta
 
 

@@ -356,20 +356,25 @@ def test_block1_pool_first_equals_the_stored_tensor_path(B, H, W, drop):
     order = torch.arange(4, device=hit.device).view(1, 1, 1, 4, 1)
     want_pos = torch.where(hit, order, torch.full_like(order, 4)).min(3).values.to(torch.uint8)
     assert torch.equal(idx, want_pos)
-    y_new = ops.bn_relu_ext_forward(ext, idx, mean, invstd, gamma, beta, dmask)   # same statistics as the old path: bit equality
+    y_new = ops.bn_relu_ext_forward(ext, None, mean, invstd, gamma, beta, dmask)   # same statistics as the old path: bit equality
     assert torch.equal(y_new, y_old)
-    # idx after the activation pass: 4 where the ReLU is inactive, else the old path's arg-max (which is the first
-    # maximum of the ACTIVATIONS: where gamma == 0 every position ties and ATen's rule picks 0, here the extremum of v)
-    live = gamma != 0
-    assert torch.equal(idx[..., live] == 4, idx_old[..., live] == 4)
-    both = (idx != 4) & (idx_old != 4)
-    assert torch.equal(idx[both & live], idx_old[both & live])
-    # ---- backward sums: window path of the stored tensor vs (dy, ext, idx) ----
+    assert torch.equal(idx, want_pos)             # the training path leaves the bytes pure positions
+    # with the bytes handed in, the activation pass re-marks 4 where the ReLU is inactive: the old path's convention
+    idx_m = idx.clone()
+    assert torch.equal(ops.bn_relu_ext_forward(ext, idx_m, mean, invstd, gamma, beta, dmask), y_old)
+    live = gamma != 0     # (gamma == 0: every position ties in the activations; ATen's rule picks 0, here the extremum of v)
+    assert torch.equal(idx_m[..., live] == 4, idx_old[..., live] == 4)
+    both = (idx_m != 4) & (idx_old != 4)
+    assert torch.equal(idx_m[both & live], idx_old[both & live])
+    # ---- backward sums: window path of the stored tensor vs (dy, ext); the reduce pass MASKS dy (zero where inactive) ----
     dy = torch.randn(B, H // 2, W // 2, 32, generator=g).bfloat16().cuda()
     _, want_dg, want_db = ops.bn_relu_pool_backward(dy, pre, mean, invstd, gamma, beta, dmask, 2)      # y=None: every window
-    sums, dg, db = ops.bn_backward_sums_ext(dy, ext, idx, mean, invstd, dmask)
+    dy_raw = dy.clone()
+    sums, dg, db = ops.bn_backward_sums_ext(dy, ext, mean, invstd, gamma, beta, dmask)
     assert torch.allclose(db[live], want_db[live], rtol=1e-4, atol=1e-4) and torch.allclose(dg[live], want_dg[live], rtol=1e-4, atol=1e-4)
     assert torch.equal(sums[:32], db) and torch.equal(sums[32:], dg)
+    off = idx_m == 4
+    assert torch.equal(dy[~off], dy_raw[~off]) and float(dy[off].abs().max()) == 0.0
     # ---- data gradient: sparse + dense form from (dy, idx, x, sums) vs the stored-tensor passes ----
     if W <= 128 and W >= 8 and H >= 4:
         dx = ops.conv1_backward_data_from_sums(x, dy, idx, sums, mean, invstd, gamma, dmask, w, bias)
@@ -405,21 +410,25 @@ def test_block1_pool_first_equals_the_stored_tensor_path(B, H, W, drop):
 @pytest.mark.parametrize("B,H,W,cin,cout", [(3, 100, 40, 64, 32), (2, 50, 20, 128, 64)])
 def test_dgrad_epilogue_sums_for_a_pool_first_block(B, H, W, cin, cout):
     """sept_conv5x5_dgrad_bnsums_ext: the data-gradient conv whose epilogue leaves (sum g, sum g * xhat) of the pool-first
-    block in front of its output, from its output tile and that block's (ext, idx): same dx as the plain conv, same sums
-    as the reduce kernel over the stored dx."""
+    block in front of its output, from its output tile and that block's ext, and stores its output MASKED (zero where that
+    block's ReLU is inactive): same as the plain conv followed by the masking reduce kernel."""
     from sept_amd import ops
     g = torch.Generator().manual_seed(cin + H)
     dyo = torch.randn(B, H, W, cin, generator=g).bfloat16().cuda()
     wt = ops.conv5x5_prep_weights((torch.randn(cin, cout, 5, 5, generator=g) * 0.05).cuda(), 1)
     ext = (torch.randn(B, H, W, cout, generator=g) * 1.5).bfloat16().cuda()
-    idx = torch.randint(0, 5, (B, H, W, cout), generator=g).to(torch.uint8).cuda()
     mean, invstd = (0.2 * torch.randn(cout, generator=g)).cuda(), (0.5 + torch.rand(cout, generator=g)).cuda()
+    gamma, beta = (1 + 0.3 * torch.randn(cout, generator=g)).cuda(), (0.2 * torch.randn(cout, generator=g)).cuda()
+    gamma[1] = -0.7
     dmask = ((torch.rand(B, cout, generator=g) > 0.2).float() * 1.25).cuda()
-    dx, presums = ops.conv5x5_dgrad_bnsums_ext(dyo, wt, ext, idx, mean, invstd, dmask)
+    dx, presums = ops.conv5x5_dgrad_bnsums_ext(dyo, wt, ext, mean, invstd, gamma, beta, dmask)
     assert presums is not None
-    assert torch.equal(dx, ops.conv5x5(dyo, wt))
-    sums, dg, db = ops.bn_backward_sums_ext(dx, ext, idx, mean, invstd, dmask, presums)
-    sums2, dg2, db2 = ops.bn_backward_sums_ext(dx, ext, idx, mean, invstd, dmask, None)
+    sums, dg, db = ops.bn_backward_sums_ext(dx, ext, mean, invstd, gamma, beta, dmask, presums)
+    plain = ops.conv5x5(dyo, wt)
+    sums2, dg2, db2 = ops.bn_backward_sums_ext(plain, ext, mean, invstd, gamma, beta, dmask, None)    # masks `plain` in place
+    assert torch.equal(dx, plain)
+    frac_off = float((plain == 0).float().mean())
+    assert 0.2 < frac_off < 0.8                      # the mask really bites
     scale = float(sums2.abs().max())
     assert torch.allclose(sums, sums2, rtol=1e-4, atol=1e-5 * scale)
     assert torch.equal(dg, sums[cout:]) and torch.equal(db, sums[:cout])

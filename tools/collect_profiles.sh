@@ -5,7 +5,7 @@
 # the mel kernel, HBM traffic (separate FETCH_SIZE / WRITE_SIZE passes) and the bench line itself.
 set -e
 export TMPDIR=/tmp
-O=$1; R=${2:-r02}
+O=$1; R=${2:-r03}
 mkdir -p $O
 python3 bench.py --steps 20 --warmup 3 > $O/${R}_bench.json 2> $O/bench.err
 rocprofv3 --kernel-trace --output-format csv -d $O/replay -- python3 bench.py --replay-only --steps 30 --warmup 3 > $O/replay.log 2>&1
@@ -26,4 +26,10 @@ python3 tools/pmc_sq_to_json.py $O/sq_step $O/${R}_pmc_sq_step.json "rocprofv3 -
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ref-batch > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ref-batch > $O/write.log 2>&1
 python3 tools/pmc_to_json.py $O/pmc_fetch $O/pmc_write $O/${R}_pmc_traffic.json
+python3 tools/step_traffic.py $O/${R}_pmc_traffic.json $O/${R}_replay_kernel_stats.csv > $O/${R}_step_traffic.txt
+head -3 $O/${R}_step_traffic.txt
+# kernel-only timings of every (n_fft, n_mels) the reference extracts (mel1 = 800, mel2 = 1600, default 1024, MFCC 400)
+for nf in 800 1600 1024 400; do for m in 80 128; do python3 tools/bench_mel.py --n_fft $nf --mels $m --iters 30 >> $O/${R}_mel_timings.txt; done; done
+SEPT_STAMPS=1 python3 tools/step_stamps.py > $O/${R}_step_stamps.txt 2>/dev/null
+rm -rf $O/replay $O/full $O/sq_conv $O/sq_mel $O/inst_mel $O/sq_step $O/pmc_fetch $O/pmc_write
 ls -la $O/${R}_*
