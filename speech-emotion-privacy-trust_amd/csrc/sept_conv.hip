@@ -287,7 +287,8 @@ void sept_conv5x5_mfma_kernel(ConvArgs a) {
   constexpr int NGRP = STATS ? NTHR / COUT : 1;   // pixel groups summed side by side
   float* red = reinterpret_cast<float*>(smem + size_t(MT) * SP);   // [NGRP][2][COUT]
   bool sums_done = false;
-  if constexpr (EPI == kEpiBwSums) {
+  if constexpr (EPI == kEpiBwSums && COUT <= 32) {   // (pool-first blocks have 32 channels; the batched loads below would cost
+                                                      // the 64-channel shapes their second workgroup per CU: 156 VGPRs)
     if (a.bn_mean) {
       // pool-first block in front: sums over the ACTIVE elements, and the tile is masked in place before it leaves
       const int c = tid % COUT, grp = tid / COUT;
@@ -296,16 +297,25 @@ void sept_conv5x5_mfma_kernel(ConvArgs a) {
       const float sc = a.bn_gamma[c] * is, sh = a.bn_beta[c] - mu * a.bn_gamma[c] * is;
       const bf16* ep = a.ypool + (size_t(b) * HW + q0) * COUT + c;
       const int np = min(MT, HW - q0);
+      // every ext value this thread needs is requested up front (clamped, unconditional): walked eight at a time the loop
+      // was four dependent global round trips per workgroup, all of them in front of the tile's stores (+40 us per launch)
+      constexpr int NIT = MT / NGRP;
+      float ev[NIT];
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) ev[i] = float(ep[size_t(min(grp + NGRP * i, np - 1)) * COUT]);
       float t1 = 0.f, t2 = 0.f;
-#pragma unroll 8
-      for (int p = grp; p < np; p += NGRP) {
-        bf16* gp = reinterpret_cast<bf16*>(smem + size_t(p) * SP + c * 2);
-        const float e = float(ep[size_t(p) * COUT]);
-        const bool active = __builtin_fmaf(e, sc, sh) > 0.f;
-        const float ge = active ? float(*gp) * d : 0.f;
-        if (!active) *gp = (bf16)0.f;
-        t1 += ge;
-        t2 += ge * ((e - mu) * is);
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        const int p = grp + NGRP * i;
+        if (p < np) {
+          bf16* gp = reinterpret_cast<bf16*>(smem + size_t(p) * SP + c * 2);
+          const float e = ev[i];
+          const bool active = __builtin_fmaf(e, sc, sh) > 0.f;
+          const float ge = active ? float(*gp) * d : 0.f;
+          if (!active) *gp = (bf16)0.f;
+          t1 += ge;
+          t2 += ge * ((e - mu) * is);
+        }
       }
       red[(grp * 2 + 0) * COUT + c] = t1;
       red[(grp * 2 + 1) * COUT + c] = t2;
@@ -339,7 +349,8 @@ void sept_conv5x5_mfma_kernel(ConvArgs a) {
         const bf16* yp = a.ypool + (size_t(b) * HW + q0) * COUT + c;
         const int np = min(MT, HW - q0);
 #pragma unroll 8
-        for (int p = grp; p < np; p += NGRP) {
+        for (int p = grp; p < np; p += NGRP) {   // (batching all loads up front here costs the 64-channel shape its second
+                                                 // workgroup per CU: 156 instead of 124 VGPRs)
           const float g = float(*reinterpret_cast<const bf16*>(smem + size_t(p) * SP + c * 2)) * d;
           const float y = float(yp[size_t(p) * COUT]) * rd;
           const float ge = y > 0.f ? g : 0.f;   // ReLU inactive (or channel dropped): no gradient
@@ -602,6 +613,7 @@ extern "C" int sept_conv5x5_dgrad_bnsums_ext(const void* dy_out, const void* wt,
                                              int W, int cin, int cout, void* stream) {
   SEPT_REQUIRE(partials && ext && bn_mean && bn_invstd && bn_gamma && bn_beta && B > 0 && cin > cout, SEPT_ERR_INVALID,
                "sept_conv5x5_dgrad_bnsums_ext: null argument / empty batch / not a data-gradient shape (cin=%d cout=%d)", cin, cout);
+  SEPT_REQUIRE(cout <= 32, SEPT_ERR_UNSUPPORTED, "sept_conv5x5_dgrad_bnsums_ext: cout=%d (pool-first blocks have 32 channels)", cout);
   return conv_launch("sept_conv5x5_dgrad_bnsums_ext", dy_out, wt, nullptr, dx_out, partials, B, H, W, cin, cout, stream, ext,
                      bn_gamma, bn_beta, dropscale, bn_mean, bn_invstd);
 }

@@ -505,7 +505,7 @@ def conv5x5_dgrad_bnsums_ext(dy_out, wtd, ext, mean, invstd, gamma, beta, dropsc
     B, H, W, cin = dy_out.shape
     cout = wtd.shape[1]
     nparts = lib.sept_conv5x5_bwsums_parts(B, H, W, cin, cout)
-    if nparts <= 0 or tuple(ext.shape) != (B, H, W, cout):
+    if nparts <= 0 or cout > 32 or tuple(ext.shape) != (B, H, W, cout):
         return None, None
     dx = torch.empty((B, H, W, cout), dtype=torch.bfloat16, device=dy_out.device)
     parts = workspace(f"conv5x5_bwsums{cout}", nparts * 2 * cout, dy_out.device)
