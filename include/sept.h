@@ -290,6 +290,10 @@ int sept_cloak_backward(const float* dxa, const float* dxb, float gscale_b, cons
  * as in sept_bn_relu_pool_backward's pooled path; sept_bn_relu_pool_backward_presummed then finishes that
  * BatchNorm's backward without a reduce pass (chunks with |gamma| < 1e-3 are re-summed from the windows of x). */
 int sept_conv5x5_bwsums_parts(int B, int H, int W, int cin, int cout);   /* 0: no such form for this shape */
+/* Which tile shape a launch at image width W takes (host-only, no GPU needed): out[6] = pixel blocks per wave, waves over
+ * pixels, waves over output channels, taps per barrier (0 / negative: double-buffered), input-channel slices, LDS bytes.
+ * Returns 0, or SEPT_ERR_UNSUPPORTED when the channel pair (or its statistics form, want_stats != 0) has no kernel. */
+int sept_conv5x5_variant(int W, int cin, int cout, int want_stats, int* out);
 int sept_conv5x5_dgrad_bnsums(const void* dy_out, const void* wt, void* dx_out, const void* ypool, const float* bn_gamma,
                               const float* bn_beta, const float* dropscale, float* partials, int B, int H, int W, int cin,
                               int cout, void* stream);

@@ -128,16 +128,20 @@ void sept_conv5x5_mfma_kernel(ConvArgs a) {
   // Weight-tile loads are UNCONDITIONAL (chunk index clamped; surplus lanes re-read the last chunk
   // and simply do not store it): a predicated load inside the tap loop makes the compiler drain
   // every outstanding load (s_waitcnt vmcnt(0)) instead of counting them.
-  auto wload = [&](int g, uint4 (&r)[WCH]) {  // group g = taps [g*TG, min(25, (g+1)*TG)), contiguous in wt
+  struct WRegs { uint4 v[WCH]; };   // (by value: a reference to a plain array kept the two-chunk forms' registers in scratch)
+  auto wload = [&](int g, WRegs& r) {  // group g = taps [g*TG, min(25, (g+1)*TG)), contiguous in wt
     const bf16* wsrc = a.wt + size_t(g) * TG * COUT * CINF + c0;
     const int n = min(TG, kTaps - g * TG) * COUT * CPP;
+    WRegs t;
 #pragma unroll
     for (int j = 0; j < WCH; ++j) {
       const int i = min(tid + NTHR * j, n - 1);
-      r[j] = *reinterpret_cast<const uint4*>(wsrc + size_t(i / CPP) * CINF + (i % CPP) * 8);
+      t.v[j] = *reinterpret_cast<const uint4*>(wsrc + size_t(i / CPP) * CINF + (i % CPP) * 8);
     }
+    r = t;
   };
-  auto wstore = [&](int g, const uint4 (&r)[WCH]) {
+  auto wstore = [&](int g, const WRegs rr) {
+    const uint4* r = rr.v;
     const int n = min(TG, kTaps - g * TG) * COUT * CPP;
     unsigned char* dst = wbuf + (DBUF ? size_t(g & 1) * TG * COUT * PSW : 0);
 #pragma unroll
@@ -194,7 +198,7 @@ void sept_conv5x5_mfma_kernel(ConvArgs a) {
     }
   }
   {
-    uint4 r[WCH];
+    WRegs r;
     wload(0, r);
     wstore(0, r);
   }
@@ -228,7 +232,7 @@ void sept_conv5x5_mfma_kernel(ConvArgs a) {
     // Two register sets: the weights of tap g + 2 are requested while tap g is computed and are
     // written to LDS one interval later, so a load has a whole interval (and an LDS-only barrier
     // that does not drain it) to land.  Taps past the end re-load the last tile (never stored).
-    uint4 wa[WCH], wb2[WCH];
+    WRegs wa, wb2;
     wload(min(1, NG - 1), wa);
     for (int g = 0; g < NG; g += 2) {
       wload(min(g + 2, NG - 1), wb2);
@@ -243,7 +247,7 @@ void sept_conv5x5_mfma_kernel(ConvArgs a) {
     }
   } else {
     for (int g = 0; g < NG; ++g) {
-      uint4 wreg[WCH];
+      WRegs wreg;
       if (g + 1 < NG) wload(g + 1, wreg);  // in flight under this group's MFMAs
       compute(g, 0);
       if (g + 1 < NG) {
@@ -406,30 +410,26 @@ struct ConvVariant {
 // forms by whether two workgroups fit on a CU -- e.g. 64->128 at 50x20: one workgroup (163 us),
 // single buffer -> two (136 us), two channel slices + double buffer -> two (105 us, 875 TFLOP/s).
 const ConvVariant kConvVariants[] = {
+    // (only shapes the dispatcher can reach at some image width are instantiated: sept_conv5x5_variant() scanned over
+    // W = 1 .. 400 for every channel pair, with and without the statistics epilogue; none of them uses scratch)
     // 512-pixel tiles, every wave all output channels (WN = 1: two 32-channel blocks per wave, one LDS read per MFMA):
     // 32 -> 64 91 us where the 256-pixel / two-channel-halves form takes 104-108, 128 -> 64 (four channel slices) 94.5
     // against 103-105 (same call, round 2); pairs of taps per barrier were slower here (111 us)
     SEPT_CONV_VARIANT(32, 64, 2, 8, 1, 0, 1),
     SEPT_CONV_VARIANT(32, 64, 2, 4, 2, 0, 1),   SEPT_CONV_VARIANT(32, 64, 2, 4, 2, 1, 1),   SEPT_CONV_VARIANT(32, 64, 1, 4, 1, 1, 1),
-    SEPT_CONV_VARIANT(64, 128, 2, 4, 2, 0, 1),  SEPT_CONV_VARIANT(64, 128, 2, 4, 2, 1, 1),  SEPT_CONV_VARIANT(64, 128, 1, 4, 2, 1, 1),
-    SEPT_CONV_VARIANT(64, 128, 1, 4, 1, 1, 1),  SEPT_CONV_VARIANT(64, 128, 2, 4, 2, 0, 2),  SEPT_CONV_VARIANT(64, 128, 2, 4, 2, 1, 2),
+    SEPT_CONV_VARIANT(64, 128, 1, 4, 2, 1, 1),  SEPT_CONV_VARIANT(64, 128, 2, 4, 2, 0, 2),  SEPT_CONV_VARIANT(64, 128, 2, 4, 2, 1, 2),
     // 64 -> 32 (data gradient of conv2): one 32-channel output block per wave, so a 256-pixel tile is only 2 MFMAs per
     // wave, tap and channel slice; 512-pixel tiles (two pixel blocks per wave) with pairs of taps per barrier measured
     // 109 us where the 256-pixel form takes 131 (same call, round 2)
-    SEPT_CONV_VARIANT(64, 32, 2, 8, 1, -2, 2),  SEPT_CONV_VARIANT(64, 32, 2, 8, 1, 0, 2),
-    SEPT_CONV_VARIANT(64, 32, 1, 8, 1, 0, 1),   SEPT_CONV_VARIANT(64, 32, 1, 8, 1, 1, 1),   SEPT_CONV_VARIANT(64, 32, 1, 4, 1, 1, 1),
+    SEPT_CONV_VARIANT(64, 32, 2, 8, 1, -2, 2),  SEPT_CONV_VARIANT(64, 32, 2, 8, 1, 0, 2),   SEPT_CONV_VARIANT(64, 32, 1, 4, 1, 1, 1),
     SEPT_CONV_VARIANT(64, 32, 1, 8, 1, 0, 2),   SEPT_CONV_VARIANT(64, 32, 1, 8, 1, 1, 2),
     // 64 -> 32 in two channel slices is only 2 MFMAs per wave and tap: pairs of taps per barrier (-2) measured
     // 115-120 us where one tap per barrier takes 123-130 (round 2 sweeps, gpurun_out/r2i, r2j); for the other shapes
     // groups of 2 / 3 / 5 taps, 128-pixel tiles with 3-4 workgroups per CU and four channel slices were all equal
     // or slower (more LDS or more registers cost the second workgroup per CU, which is worth 2x)
-    SEPT_CONV_VARIANT(64, 32, 1, 8, 1, -2, 2),  SEPT_CONV_VARIANT(64, 32, 1, 8, 1, -2, 1),
-    SEPT_CONV_VARIANT(128, 64, 2, 8, 1, 0, 4),
-    SEPT_CONV_VARIANT(128, 64, 2, 4, 2, 0, 2),  SEPT_CONV_VARIANT(128, 64, 2, 4, 2, 1, 2),  SEPT_CONV_VARIANT(128, 64, 2, 4, 2, 0, 1),
-    SEPT_CONV_VARIANT(128, 64, 1, 4, 2, 1, 1),  SEPT_CONV_VARIANT(128, 64, 1, 4, 1, 1, 1),
-
-    SEPT_CONV_VARIANT(128, 128, 2, 4, 2, 0, 2), SEPT_CONV_VARIANT(128, 128, 2, 4, 2, 1, 2), SEPT_CONV_VARIANT(128, 128, 1, 4, 2, 1, 1),
-    SEPT_CONV_VARIANT(128, 128, 1, 4, 1, 1, 1),
+    SEPT_CONV_VARIANT(64, 32, 1, 8, 1, -2, 2),
+    SEPT_CONV_VARIANT(128, 64, 2, 8, 1, 0, 4),  SEPT_CONV_VARIANT(128, 64, 2, 4, 2, 0, 2),  SEPT_CONV_VARIANT(128, 64, 2, 4, 2, 1, 2),
+    SEPT_CONV_VARIANT(128, 128, 2, 4, 2, 0, 2), SEPT_CONV_VARIANT(128, 128, 2, 4, 2, 1, 2),
 };
 
 }  // namespace
@@ -573,6 +573,15 @@ int conv_epilogue_parts(int B, int H, int W, int cin, int cout) {
 // partial-sum columns of sept_conv5x5_dgrad_bnsums (0: the shape has no such form; cin > cout only)
 extern "C" int sept_conv5x5_bwsums_parts(int B, int H, int W, int cin, int cout) {
   return cin > cout ? conv_epilogue_parts(B, H, W, cin, cout) : 0;
+}
+
+extern "C" int sept_conv5x5_variant(int W, int cin, int cout, int want_stats, int* out) {
+  SEPT_REQUIRE(out && W > 0, SEPT_ERR_INVALID, "sept_conv5x5_variant: null argument / W=%d", W);
+  size_t smem = 0;
+  const ConvVariant* v = conv_pick(W, cin, cout, want_stats != 0, &smem);
+  SEPT_REQUIRE(v, SEPT_ERR_UNSUPPORTED, "sept_conv5x5_variant: no kernel for cin=%d cout=%d W=%d stats=%d", cin, cout, W, want_stats);
+  out[0] = v->pb; out[1] = v->wp; out[2] = v->wn; out[3] = v->tg; out[4] = v->cs; out[5] = int(smem);
+  return SEPT_OK;
 }
 
 extern "C" int sept_conv5x5_stats_parts(int B, int H, int W, int cin, int cout) {

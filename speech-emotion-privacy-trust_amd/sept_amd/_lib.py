@@ -13,7 +13,7 @@ class SeptError(RuntimeError):
 
 
 def _load():
-    path = os.path.abspath(LIB_PATH)
+    path = os.path.abspath(os.environ.get("SEPT_LIB", LIB_PATH))   # SEPT_LIB: another build of the same library (A/B aid)
     if not os.path.exists(path):
         raise ImportError(
             f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -132,6 +132,7 @@ SIGNATURES = {
     "sept_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float, c_float,
                                c_float, c_int, c_float, c_void_p]),
     "sept_conv5x5_bwsums_parts": (c_int, [c_int] * 5),
+    "sept_conv5x5_variant": (c_int, [c_int] * 4 + [POINTER(c_int)]),
     "sept_conv5x5_dgrad_bnsums": (c_int, [c_void_p] * 8 + [c_int] * 5 + [c_void_p]),
     "sept_bn_relu_pool_backward_presummed": (c_int, [c_void_p] * 8 + [c_int, c_void_p, c_void_p, c_void_p, c_void_p] +
                                              [c_int] * 5 + [c_void_p]),
