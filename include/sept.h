@@ -290,6 +290,24 @@ int sept_cloak_backward(const float* dxa, const float* dxb, float gscale_b, cons
  * as in sept_bn_relu_pool_backward's pooled path; sept_bn_relu_pool_backward_presummed then finishes that
  * BatchNorm's backward without a reduce pass (chunks with |gamma| < 1e-3 are re-summed from the windows of x). */
 int sept_conv5x5_bwsums_parts(int B, int H, int W, int cin, int cout);   /* 0: no such form for this shape */
+/* Data gradient of a 5x5 conv whose incoming gradient is that of a BatchNorm + ReLU + MaxPool 2x2 (+ Dropout2d) block's
+ * PRE-ACTIVATIONS (baseline_models.py:178-188 + autograd: blocks 2 and 3 of a network whose conv weights need no gradient),
+ * with that block's backward apply pass inside the conv's tile loader: pre (B, H, W, cin) bf16 = the block's stored
+ * pre-activations, gpool (B, H/2, W/2, cin) bf16 = gradient of its pooled output, sums[2 cin] = (sum g, sum g xhat) as
+ * sept_bn_backward_sums_presummed / sept_bn_relu_pool_backward_reduce leave them, mean / invstd / gamma / beta [cin],
+ * dropscale [B][cin] or NULL; wt from sept_conv5x5_prep_weights(mode 1); dx_out (B, H, W, cout) bf16.  The (B, H, W, cin)
+ * gradient tensor sept_bn_relu_pool_backward would write (and the conv read) does not exist.  H, W even.
+ * Epilogue (optional): ep_ypool + ep_gamma + ep_beta (+ ep_dropscale) as sept_conv5x5_dgrad_bnsums; with ep_mean / ep_invstd
+ * too, ep_ypool is a pool-first block's ext, as sept_conv5x5_dgrad_bnsums_ext; partials[2 cout][sept_conv5x5_bnapply_parts()].
+ * sept_conv5x5_bnapply_parts(..., want_sums): columns of `partials` (want_sums != 0) or 1 (plain epilogue) when this shape
+ * has a loader form at this width, else 0 (the caller then runs the apply pass and the plain conv). */
+int sept_conv5x5_bnapply_parts(int B, int H, int W, int cin, int cout, int want_sums);
+int sept_conv5x5_dgrad_bnapply(const void* pre, const void* gpool, const float* sums, const float* mean,
+                               const float* invstd, const float* gamma, const float* beta, const float* dropscale,
+                               const void* wt, void* dx_out, const void* ep_ypool, const float* ep_mean,
+                               const float* ep_invstd, const float* ep_gamma, const float* ep_beta,
+                               const float* ep_dropscale, float* partials, int B, int H, int W, int cin, int cout,
+                               void* stream);
 /* Which tile shape a launch at image width W takes (host-only, no GPU needed): out[6] = pixel blocks per wave, waves over
  * pixels, waves over output channels, taps per barrier (0 / negative: double-buffered), input-channel slices, LDS bytes.
  * Returns 0, or SEPT_ERR_UNSUPPORTED when the channel pair (or its statistics form, want_stats != 0) has no kernel. */

@@ -22,6 +22,7 @@
 // (29-39 % of the LDS cycles were conflicts, r01 PMC).  12 extra slots per row make the row term
 // 48r = 0 mod 16 for every channel count in use (5, 9 or 17 slots per pixel): slot = 9q + const again.
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 
 #include "sept_common.h"
@@ -57,6 +58,16 @@ struct ConvArgs {
   // invstd exactly (no division by gamma), and the OUTPUT is stored MASKED -- zero where the ReLU is inactive -- so that
   // the consumers of this gradient need no activity information of their own (the position bytes stay pure positions)
   const float *bn_mean, *bn_invstd;
+  // LBN kernels (data-gradient launches whose INPUT is the gradient of a BatchNorm + ReLU + MaxPool 2x2 (+ Dropout2d)
+  // block's pre-activations): that gradient is formed in the tile loader instead of being read --
+  //   x = the block's stored pre-activations [B][H][W][CIN], lg = gradient of its pooled output [B][H/2][W/2][CIN],
+  //   l_sums[2 CIN] = (sum g, sum g xhat) over the batch, l_inv_n = 1 / (B H W), l_mean / l_invstd / l_gamma / l_beta [CIN],
+  //   l_drop [B][CIN] or null
+  // exactly the arithmetic of sept_bn_bwd_apply_kernel<CPP, 2> (same expressions, same bf16 rounding), so the
+  // [B][H][W][CIN] gradient tensor is neither written nor read.
+  const bf16* lg;
+  const float *l_sums, *l_mean, *l_invstd, *l_gamma, *l_beta, *l_drop;
+  float l_inv_n;
 };
 
 __host__ __device__ constexpr int conv_nr_max(int mt, int w) { return (mt + w - 2) / w + 5; }
@@ -88,9 +99,9 @@ __host__ __device__ constexpr size_t conv_stats_smem(int mt, int cout, int nthr)
 // (Second launch bound = waves per SIMD: the statistics form of an 8-wave shape that lives with two workgroups
 // per CU is held to the 128 VGPRs its plain form uses; shapes whose plain form needs more carry no cap.)
 enum { kEpiPlain = 0, kEpiStats = 1, kEpiBwSums = 2 };
-template <int CINF, int COUT, int PB, int WP, int WN, int TGP, int CS, int EPI = kEpiPlain>
+template <int CINF, int COUT, int PB, int WP, int WN, int TGP, int CS, int EPI = kEpiPlain, bool LBN = false>
 __global__ __launch_bounds__(64 * WP * WN,
-                             (EPI != kEpiPlain && WP * WN == 8 && !(TGP <= 0 && CINF >= 64 && (CS == 1 || CINF == 128))) ? 4 : 1)
+                             ((EPI != kEpiPlain || LBN) && WP * WN == 8 && !(TGP <= 0 && CINF >= 64 && (CS == 1 || CINF == 128))) ? 4 : 1)
 void sept_conv5x5_mfma_kernel(ConvArgs a) {
   constexpr bool STATS = EPI != kEpiPlain;   // the output tile goes through the LDS for per-channel column sums
   constexpr bool DBUF = TGP <= 0;                               // TGP <= 0: double-buffered groups of max(1, -TGP) taps
@@ -171,7 +182,93 @@ void sept_conv5x5_mfma_kernel(ConvArgs a) {
   c0 = cs * CIN;
   if (cs > 0) __syncthreads();  // previous slice's tile and weights are no longer read
   // ---- stage input rows [h_first-2, h_last+2] x cols [-2, W+2) ----
-  {
+  if constexpr (LBN) {
+    // the staged tile is COMPUTED: one thread per (2x2 window, FOUR channels) loads the window's four pre-activation
+    // pieces and the pooled gradient, repeats the forward's arg-max / ReLU decision and writes the four gradient pieces.
+    // (Four channels, 8-byte accesses: with eight the per-channel constants alone are 40 registers and the kernel loses
+    // the second workgroup per CU.)  d = sc (ge - m1 - xhat m2) is evaluated as sc ge + kb + kc x with kc = -sc invstd m2,
+    // kb = -sc m1 - kc mean: one rounding step away from sept_bn_bwd_apply_kernel's expression.
+    constexpr int QPP = CIN / 4;                 // channel quads per pixel of this slice
+    static_assert(NTHR % QPP == 0, "a thread keeps its channel quad");
+    const int cq = tid % QPP, ch = c0 + cq * 4;
+    f32x4 sc, sh, kb, kc, dr;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float mu = a.l_mean[ch + e], is = a.l_invstd[ch + e];
+      sc[e] = a.l_gamma[ch + e] * is;
+      sh[e] = a.l_beta[ch + e] - mu * sc[e];
+      kc[e] = -sc[e] * is * (a.l_sums[CINF + ch + e] * a.l_inv_n);
+      kb[e] = -sc[e] * (a.l_sums[ch + e] * a.l_inv_n) - kc[e] * mu;
+      dr[e] = a.l_drop ? a.l_drop[size_t(b) * CINF + ch + e] : 1.f;
+    }
+    const int hs = h_first - 2, he = h_last + 2;
+    const int wr0 = max(hs, 0) >> 1, wr1 = min(he, H - 1) >> 1, nwc = W >> 1;
+    const int nwin = (wr1 - wr0 + 1) * nwc;
+    const bf16* xb = a.x + size_t(b) * HW * CINF + ch;
+    const bf16* gb = a.lg + size_t(b) * (H >> 1) * nwc * CINF + ch;
+    constexpr int STEP = NTHR / QPP;
+    for (int wi0 = tid / QPP; wi0 < nwin; wi0 += 2 * STEP) {
+      bf16x4 xr[2][4], gr[2];
+      int h0[2], w0[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {   // ten loads in flight
+        const int wi = min(wi0 + j * STEP, nwin - 1);
+        const int wr = wi / nwc, wc = wi - wr * nwc;
+        h0[j] = (wr0 + wr) * 2;
+        w0[j] = wc * 2;
+        const bf16* xp = xb + (size_t(h0[j]) * W + w0[j]) * CINF;
+        xr[j][0] = *reinterpret_cast<const bf16x4*>(xp);
+        xr[j][1] = *reinterpret_cast<const bf16x4*>(xp + CINF);
+        xr[j][2] = *reinterpret_cast<const bf16x4*>(xp + size_t(W) * CINF);
+        xr[j][3] = *reinterpret_cast<const bf16x4*>(xp + size_t(W + 1) * CINF);
+        gr[j] = *reinterpret_cast<const bf16x4*>(gb + (size_t(wr0 + wr) * nwc + wc) * CINF);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (wi0 + j * STEP >= nwin) break;
+        f32x4 xv[4], gg = __builtin_convertvector(gr[j], f32x4) * dr, best;
+        int arg[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          best[e] = -INFINITY;
+          arg[e] = 0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          xv[q] = __builtin_convertvector(xr[j][q], f32x4);
+          const f32x4 v = xv[q] * sc + sh;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float r = fmaxf(v[e], 0.f);
+            if (r > best[e]) {
+              best[e] = r;
+              arg[e] = q;
+            }
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gg[e] = best[e] > 0.f ? gg[e] * sc[e] : 0.f;   // sc ge where the ReLU is active
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int h = h0[j] + (q >> 1);
+          f32x4 d;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) d[e] = ((arg[e] == q) ? gg[e] : 0.f) + (kb[e] + kc[e] * xv[q][e]);
+          if (h >= hs && h <= he)
+            *reinterpret_cast<bf16x4*>(tile + (h - hs) * RP + (w0[j] + (q & 1) + 2) * PS + cq * 8) =
+                __builtin_convertvector(d, bf16x4);
+        }
+      }
+    }
+    // the halo: two columns either side and the rows outside the image are zeros
+    const int total = NR * W4 * CPP;
+    for (int i = tid; i < total; i += NTHR) {
+      const int c = i % CPP, px = i / CPP;
+      const int row = px / W4, col = px - row * W4;
+      const int h = hs + row, w = col - 2;
+      if (!(h >= 0 && h < H && w >= 0 && w < W)) *reinterpret_cast<uint4*>(tile + row * RP + col * PS + c * 16) = make_uint4(0, 0, 0, 0);
+    }
+  } else {
     // four loads in flight per lane (unconditional: coordinates clamped into the image, the halo zeroed afterwards);
     // one load at a time, as the plain loop compiled, made this a chain of 4-7 serial HBM round trips per workgroup --
     // with the tile staged the whole prologue took as long as a third of the 25 taps (round-2 ablation)
@@ -400,10 +497,20 @@ struct ConvVariant {
   const void* fn;
   const void* fn_stats;   // the same kernel with the statistics epilogue (forward shapes) or the BatchNorm backward
                           // sums epilogue (data-gradient shapes, cin > cout)
+  const void* fn_lbn;        // data-gradient shapes: the input gradient formed in the tile loader (LBN), plain epilogue
+  const void* fn_lbn_stats;  // ... with the BatchNorm backward sums epilogue
 };
 #define SEPT_CONV_VARIANT(ci, co, pb, wp, wn, tg, cs) \
   { ci, co, pb, wp, wn, tg, cs, reinterpret_cast<const void*>(&sept_conv5x5_mfma_kernel<ci, co, pb, wp, wn, tg, cs>), \
-    reinterpret_cast<const void*>(&sept_conv5x5_mfma_kernel<ci, co, pb, wp, wn, tg, cs, (ci <= co) ? kEpiStats : kEpiBwSums>) }
+    reinterpret_cast<const void*>(&sept_conv5x5_mfma_kernel<ci, co, pb, wp, wn, tg, cs, (ci <= co) ? kEpiStats : kEpiBwSums>), \
+    nullptr, nullptr }
+// ... a data-gradient shape that also exists with the loader form (LBN): the ones whose loader fits the 128 registers that
+// keep two workgroups on a CU (the 512-pixel / four-slice form of 128 -> 64 does not: 184)
+#define SEPT_CONV_VARIANT_L(ci, co, pb, wp, wn, tg, cs) \
+  { ci, co, pb, wp, wn, tg, cs, reinterpret_cast<const void*>(&sept_conv5x5_mfma_kernel<ci, co, pb, wp, wn, tg, cs>), \
+    reinterpret_cast<const void*>(&sept_conv5x5_mfma_kernel<ci, co, pb, wp, wn, tg, cs, kEpiBwSums>), \
+    reinterpret_cast<const void*>(&sept_conv5x5_mfma_kernel<ci, co, pb, wp, wn, tg, cs, kEpiPlain, true>), \
+    reinterpret_cast<const void*>(&sept_conv5x5_mfma_kernel<ci, co, pb, wp, wn, tg, cs, kEpiBwSums, true>) }
 // Order = measured preference of tile shapes at the training shapes (tools/sweep_conv.py): the
 // 8-wave 256-pixel tiles first, smaller tiles for wide images.  Within the first tile shape that
 // fits, the dispatcher scores the buffering (TG 0 double / TG 1 single) and channel-slice (CS)
@@ -421,14 +528,14 @@ const ConvVariant kConvVariants[] = {
     // 64 -> 32 (data gradient of conv2): one 32-channel output block per wave, so a 256-pixel tile is only 2 MFMAs per
     // wave, tap and channel slice; 512-pixel tiles (two pixel blocks per wave) with pairs of taps per barrier measured
     // 109 us where the 256-pixel form takes 131 (same call, round 2)
-    SEPT_CONV_VARIANT(64, 32, 2, 8, 1, -2, 2),  SEPT_CONV_VARIANT(64, 32, 2, 8, 1, 0, 2),   SEPT_CONV_VARIANT(64, 32, 1, 4, 1, 1, 1),
-    SEPT_CONV_VARIANT(64, 32, 1, 8, 1, 0, 2),   SEPT_CONV_VARIANT(64, 32, 1, 8, 1, 1, 2),
+    SEPT_CONV_VARIANT_L(64, 32, 2, 8, 1, -2, 2),  SEPT_CONV_VARIANT(64, 32, 2, 8, 1, 0, 2),   SEPT_CONV_VARIANT_L(64, 32, 1, 4, 1, 1, 1),
+    SEPT_CONV_VARIANT(64, 32, 1, 8, 1, 0, 2),   SEPT_CONV_VARIANT_L(64, 32, 1, 8, 1, 1, 2),
     // 64 -> 32 in two channel slices is only 2 MFMAs per wave and tap: pairs of taps per barrier (-2) measured
     // 115-120 us where one tap per barrier takes 123-130 (round 2 sweeps, gpurun_out/r2i, r2j); for the other shapes
     // groups of 2 / 3 / 5 taps, 128-pixel tiles with 3-4 workgroups per CU and four channel slices were all equal
     // or slower (more LDS or more registers cost the second workgroup per CU, which is worth 2x)
-    SEPT_CONV_VARIANT(64, 32, 1, 8, 1, -2, 2),
-    SEPT_CONV_VARIANT(128, 64, 2, 8, 1, 0, 4),  SEPT_CONV_VARIANT(128, 64, 2, 4, 2, 0, 2),  SEPT_CONV_VARIANT(128, 64, 2, 4, 2, 1, 2),
+    SEPT_CONV_VARIANT_L(64, 32, 1, 8, 1, -2, 2),
+    SEPT_CONV_VARIANT(128, 64, 2, 8, 1, 0, 4),  SEPT_CONV_VARIANT(128, 64, 2, 4, 2, 0, 2),  SEPT_CONV_VARIANT_L(128, 64, 2, 4, 2, 1, 2),
     SEPT_CONV_VARIANT(128, 128, 2, 4, 2, 0, 2), SEPT_CONV_VARIANT(128, 128, 2, 4, 2, 1, 2),
 };
 
@@ -447,7 +554,7 @@ extern "C" int sept_conv5x5_prep_weights(const float* w_oihw, int cout, int cin,
 
 namespace {
 // The kernel for a shape; with want_stats only if its statistics form keeps the same number of workgroups per CU.
-const ConvVariant* conv_pick(int W, int cin, int cout, bool want_stats, size_t* smem_out) {
+const ConvVariant* conv_pick(int W, int cin, int cout, bool want_stats, size_t* smem_out, bool want_lbn = false) {
   const int force_pb = getenv("SEPT_CONV_PB") ? atoi(getenv("SEPT_CONV_PB")) : 0;  // tuning aids
   const int force_ns = getenv("SEPT_CONV_NS") ? atoi(getenv("SEPT_CONV_NS")) : 0;
   const int force_tg = getenv("SEPT_CONV_TG") ? atoi(getenv("SEPT_CONV_TG")) : 0;
@@ -463,13 +570,14 @@ const ConvVariant* conv_pick(int W, int cin, int cout, bool want_stats, size_t* 
   int best_score = -1;
   const ConvVariant* shape_best = nullptr;  // best form of the shape currently scanned (table entries of a shape need not be adjacent)
   for (const ConvVariant& lead : kConvVariants) {
-    if (lead.cin != cin || lead.cout != cout) continue;
+    if (lead.cin != cin || lead.cout != cout || (want_lbn && !lead.fn_lbn)) continue;
     if (best && best_score >= 20) break;
     // scan every form of lead's shape once (at the shape's first table entry)
     bool first_of_shape = true;
     for (const ConvVariant& u : kConvVariants) {
       if (&u == &lead) break;
-      if (u.cin == cin && u.cout == cout && u.pb == lead.pb && u.wp == lead.wp && u.wn == lead.wn) first_of_shape = false;
+      if (u.cin == cin && u.cout == cout && u.pb == lead.pb && u.wp == lead.wp && u.wn == lead.wn && !(want_lbn && !u.fn_lbn))
+        first_of_shape = false;
     }
     if (!first_of_shape) continue;
     shape_best = nullptr;
@@ -477,6 +585,7 @@ const ConvVariant* conv_pick(int W, int cin, int cout, bool want_stats, size_t* 
     int shape_score = -1;
     for (const ConvVariant& v : kConvVariants) {
       if (v.cin != cin || v.cout != cout || v.pb != lead.pb || v.wp != lead.wp || v.wn != lead.wn) continue;
+      if (want_lbn && !v.fn_lbn) continue;
       if (force_pb && v.pb != force_pb) continue;
       if (force_ns && v.wp * v.wn != 4 * force_ns) continue;
       if (force_wn && v.wn != force_wn) continue;
@@ -514,21 +623,37 @@ const ConvVariant* conv_pick(int W, int cin, int cout, bool want_stats, size_t* 
   return best;
 }
 
+struct ConvLbn {   // the BatchNorm block whose backward apply pass runs in the tile loader (ConvArgs: LBN kernels)
+  const void* g;
+  const float *sums, *mean, *invstd, *gamma, *beta, *drop;
+};
+
 int conv_launch(const char* who, const void* x, const void* wt, const float* bias, void* y, float* stats, int B, int H,
                 int W, int cin, int cout, void* stream, const void* ypool = nullptr, const float* bn_gamma = nullptr,
                 const float* bn_beta = nullptr, const float* drop = nullptr, const float* bn_mean = nullptr,
-                const float* bn_invstd = nullptr) {
+                const float* bn_invstd = nullptr, const ConvLbn* lbn = nullptr) {
   SEPT_REQUIRE(B >= 0 && H > 0 && W > 0, SEPT_ERR_INVALID, "%s: B=%d H=%d W=%d", who, B, H, W);
   if (B == 0) return SEPT_OK;
   SEPT_REQUIRE(x && wt && y, SEPT_ERR_INVALID, "%s: null argument", who);
   SEPT_REQUIRE(B <= 65528, SEPT_ERR_UNSUPPORTED, "%s: B=%d exceeds grid.y", who, B);
   size_t best_smem = 0;
-  const ConvVariant* best = conv_pick(W, cin, cout, stats != nullptr, &best_smem);
+  const ConvVariant* best = conv_pick(W, cin, cout, stats != nullptr, &best_smem, lbn != nullptr);
   SEPT_REQUIRE(best, SEPT_ERR_UNSUPPORTED,
                "%s: no kernel for cin=%d cout=%d W=%d (supported channel pairs: 32->64, "
                "64->128, 64->32, 128->64, 128->128; statistics form: see sept_conv5x5_stats_parts)", who, cin, cout, W);
-  const void* fn = stats ? best->fn_stats : best->fn;
+  const void* fn = lbn ? (stats ? best->fn_lbn_stats : best->fn_lbn) : (stats ? best->fn_stats : best->fn);
+  SEPT_REQUIRE(fn, SEPT_ERR_UNSUPPORTED, "%s: no kernel form for cin=%d cout=%d", who, cin, cout);
   ConvArgs a;
+  a.lg = nullptr;
+  a.l_sums = a.l_mean = a.l_invstd = a.l_gamma = a.l_beta = a.l_drop = nullptr;
+  a.l_inv_n = 0.f;
+  if (lbn) {
+    SEPT_REQUIRE(H % 2 == 0 && W % 2 == 0, SEPT_ERR_UNSUPPORTED, "%s: H=%d W=%d (the loader form needs whole 2x2 windows)", who, H, W);
+    a.lg = static_cast<const bf16*>(lbn->g);
+    a.l_sums = lbn->sums; a.l_mean = lbn->mean; a.l_invstd = lbn->invstd; a.l_gamma = lbn->gamma; a.l_beta = lbn->beta;
+    a.l_drop = lbn->drop;
+    a.l_inv_n = 1.0f / (float(B) * H * W);
+  }
   a.x = static_cast<const bf16*>(x);
   a.wt = static_cast<const bf16*>(wt);
   a.bias = bias;
@@ -569,6 +694,18 @@ int conv_epilogue_parts(int B, int H, int W, int cin, int cout) {
   return B * ((H * W + mt - 1) / mt);
 }
 }  // namespace
+
+// partial-sum columns of sept_conv5x5_dgrad_bnapply's epilogue (0: the shape has no loader form at this width); with
+// want_sums == 0: 1 when the plain-epilogue loader form exists, else 0
+extern "C" int sept_conv5x5_bnapply_parts(int B, int H, int W, int cin, int cout, int want_sums) {
+  if (cin <= cout || B <= 0 || H <= 0 || W <= 0 || H % 2 || W % 2) return 0;
+  size_t smem = 0;
+  const ConvVariant* v = conv_pick(W, cin, cout, want_sums != 0, &smem, true);
+  if (!v) return 0;
+  if (!want_sums) return 1;
+  const int mt = 32 * v->pb * v->wp;
+  return B * ((H * W + mt - 1) / mt);
+}
 
 // partial-sum columns of sept_conv5x5_dgrad_bnsums (0: the shape has no such form; cin > cout only)
 extern "C" int sept_conv5x5_bwsums_parts(int B, int H, int W, int cin, int cout) {
@@ -625,4 +762,28 @@ extern "C" int sept_conv5x5_dgrad_bnsums_ext(const void* dy_out, const void* wt,
   SEPT_REQUIRE(cout <= 32, SEPT_ERR_UNSUPPORTED, "sept_conv5x5_dgrad_bnsums_ext: cout=%d (pool-first blocks have 32 channels)", cout);
   return conv_launch("sept_conv5x5_dgrad_bnsums_ext", dy_out, wt, nullptr, dx_out, partials, B, H, W, cin, cout, stream, ext,
                      bn_gamma, bn_beta, dropscale, bn_mean, bn_invstd);
+}
+
+// Data gradient of a 5x5 conv whose incoming gradient is that of a BatchNorm + ReLU + MaxPool 2x2 (+ Dropout2d) block's
+// PRE-ACTIVATIONS, with the block's backward apply pass inside the tile loader: pre (B, H, W, cin) bf16 = the stored
+// pre-activations, gpool (B, H/2, W/2, cin) bf16 = gradient of the pooled output, sums[2 cin] = (sum g, sum g xhat) as
+// sept_bn_backward_sums_presummed / sept_bn_relu_pool_backward_reduce leave them, mean / invstd / gamma / beta [cin],
+// dropscale [B][cin] or NULL.  wt prepared with mode 1; dx_out (B, H, W, cout) bf16 -- bit-identical to
+// sept_bn_relu_pool_backward's dx fed to sept_conv5x5_forward, without that (B, H, W, cin) tensor.
+// Epilogue (optional, as the two entry points above): ep_ypool != NULL with ep_mean == NULL -> sept_conv5x5_dgrad_bnsums,
+// ep_ypool (= ext) with ep_mean / ep_invstd -> sept_conv5x5_dgrad_bnsums_ext; partials then receives the sums.
+extern "C" int sept_conv5x5_dgrad_bnapply(const void* pre, const void* gpool, const float* sums, const float* mean,
+                                          const float* invstd, const float* gamma, const float* beta,
+                                          const float* dropscale, const void* wt, void* dx_out, const void* ep_ypool,
+                                          const float* ep_mean, const float* ep_invstd, const float* ep_gamma,
+                                          const float* ep_beta, const float* ep_dropscale, float* partials, int B, int H,
+                                          int W, int cin, int cout, void* stream) {
+  SEPT_REQUIRE(pre && gpool && sums && mean && invstd && gamma && beta && B > 0 && cin > cout, SEPT_ERR_INVALID,
+               "sept_conv5x5_dgrad_bnapply: null argument / empty batch / not a data-gradient shape (cin=%d cout=%d)", cin, cout);
+  SEPT_REQUIRE((ep_ypool != nullptr) == (partials != nullptr) && (!ep_ypool || (ep_gamma && ep_beta)) &&
+                   ((ep_mean != nullptr) == (ep_invstd != nullptr)) && (!ep_mean || cout <= 32),
+               SEPT_ERR_INVALID, "sept_conv5x5_dgrad_bnapply: inconsistent epilogue arguments");
+  const ConvLbn l{gpool, sums, mean, invstd, gamma, beta, dropscale};
+  return conv_launch("sept_conv5x5_dgrad_bnapply", pre, wt, nullptr, dx_out, partials, B, H, W, cin, cout, stream, ep_ypool,
+                     ep_gamma, ep_beta, ep_dropscale, ep_mean, ep_invstd, &l);
 }

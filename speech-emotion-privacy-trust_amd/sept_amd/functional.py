@@ -568,6 +568,12 @@ L1_POOL_TRAINABLE = os.environ.get("SEPT_L1_POOL_TRAIN", "1") != "0"
 L1_DX_SUM = os.environ.get("SEPT_L1_DX_SUM", "1") != "0"
 
 
+# blocks 2 / 3 of a network whose conv weights need no gradient (the frozen emotion model): the BatchNorm backward apply
+# pass inside the tile loader of the data-gradient conv behind it (ops.conv5x5_dgrad_bnapply) -- the (B, H, W, C) gradient of
+# the pre-activations is neither written nor read (0.34 GB per step at 224 windows).  SEPT_BN_APPLY_CONV=0: separate pass
+BN_APPLY_IN_CONV = os.environ.get("SEPT_BN_APPLY_CONV", "1") != "0"
+
+
 def batch_sum_pair(dx1, dx2):
     """the two branches' input gradients as equally shaped (rows, n) matrices for sept_cloak_backward: when one of them is
     already summed over the batch (1 row) and the other is not, the other is summed too (one column-sum launch pair)"""
@@ -843,6 +849,34 @@ def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq, go
                 if cv.bias is not None:     # in front of a training-mode BatchNorm: exactly zero (see zero_bias_grad)
                     put(cv.bias, zero_bias_grad(cv.bias))
             continue
+        if (li >= 1 and BN_APPLY_IN_CONV and not (need_wgrad and cv.weight.requires_grad) and blk.pool == 2 and not blk.sync
+                and not blk.l1_fused and blk.pre.shape[1] % 2 == 0 and blk.pre.shape[2] % 2 == 0):
+            prev, pbn, cin_ = S.blocks[li - 1], P.bns[li - 1], cv.weight.shape[1]
+            ep = None   # what the conv's epilogue leaves for the block in front (as the unfused calls below)
+            if prev.ext is not None:
+                if cin_ <= 32 and tuple(prev.ext.shape) == tuple(blk.pre.shape[:3]) + (cin_,):
+                    ep = ("ext", prev.ext, prev.mean, prev.invstd, pbn.weight, pbn.bias, prev.drop)
+            elif (BN_SUMS_IN_DGRAD and BN_POOLED_SUMS and prev.bn_train and not prev.sync and not prev.l1_fused
+                    and prev.pool == 2 and tuple(prev.out.shape) == tuple(blk.pre.shape[:3]) + (cin_,)):
+                ep = ("pool", prev.out, pbn.weight, pbn.bias, prev.drop)
+            if ep is not None and not ops.conv5x5_bnapply_supported(blk.pre, cin_, True):
+                ep = None
+            if ep is not None or ops.conv5x5_bnapply_supported(blk.pre, cin_, False):
+                kw = dict(need_param_grads=want_bn, out_gamma=gout(bn.weight) if want_bn else None,
+                          out_beta=gout(bn.bias) if want_bn else None)
+                if presums is not None:
+                    sums, dgamma, dbeta = ops.bn_backward_sums_presummed(dact, blk.pre, blk.mean, blk.invstd, bn.weight, bn.bias,
+                                                                         blk.drop, presums, blk.pool, **kw)
+                else:
+                    sums, dgamma, dbeta = ops.bn_backward_sums(dact, blk.pre, blk.mean, blk.invstd, bn.weight, bn.bias, blk.drop,
+                                                               blk.pool, y=blk.out if BN_POOLED_SUMS else None, **kw)
+                if want_bn:
+                    put(bn.weight, dgamma)
+                    put(bn.bias, dbeta)
+                wtd = _cached("convdgrad", cv.weight, lambda: ops.conv5x5_prep_weights(cv.weight, 1))
+                dact, presums = ops.conv5x5_dgrad_bnapply(blk.pre, dact, sums, blk.mean, blk.invstd, bn.weight, bn.bias,
+                                                          blk.drop, wtd, ep)
+                continue
         if blk.l1_fused:
             dpre, dgamma, dbeta = ops.conv1_bn_relu_pool_backward(S.x, cv.weight, cv.bias, dact, blk.mean, blk.invstd,
                                                                   bn.weight, bn.bias, blk.drop, need_param_grads=want_bn,

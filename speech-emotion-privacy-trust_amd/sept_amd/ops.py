@@ -518,6 +518,90 @@ def conv5x5_dgrad_bnsums_ext(dy_out, wtd, ext, mean, invstd, gamma, beta, dropsc
     return dx, (parts, nparts)
 
 
+def bn_backward_sums(dy, x, mean, invstd, gamma, beta, dropscale=None, pool=2, y=None, need_param_grads=True, out_gamma=None,
+                     out_beta=None):
+    """(sum g, sum g * xhat) [2C] (+ dgamma, dbeta) of a BatchNorm + ReLU + MaxPool block by the reduce pass alone (from the
+    pooled tensors when the pooled output `y` is given, from every window of x otherwise): for a consumer that applies them
+    itself (conv5x5_dgrad_bnapply)."""
+    require_cuda(dy, x)
+    B, H, W, C = x.shape
+    ws = workspace("bn", lib.sept_bn_workspace_floats(C), x.device)
+    sums = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+    dgamma = dbeta = None
+    if need_param_grads:
+        dgamma = torch.empty(C, dtype=torch.float32, device=x.device) if out_gamma is None else out_gamma
+        dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if out_beta is None else out_beta
+    check(lib.sept_bn_relu_pool_backward_reduce(dy.data_ptr(), x.data_ptr(), _p(y), mean.data_ptr(), invstd.data_ptr(),
+                                                gamma.data_ptr(), beta.data_ptr(), _p(dropscale), ws.data_ptr(),
+                                                sums.data_ptr(), _p(dgamma), _p(dbeta), B, H, W, C, pool, _s(x)),
+          "sept_bn_relu_pool_backward_reduce")
+    return sums, dgamma, dbeta
+
+
+def bn_backward_sums_presummed(dy, x, mean, invstd, gamma, beta, dropscale, presums, pool=2, need_param_grads=True,
+                               out_gamma=None, out_beta=None):
+    """(sum g, sum g * xhat) [2C] (+ dgamma, dbeta) of a BatchNorm + ReLU + MaxPool block from the partials a data-gradient conv
+    left (conv5x5_dgrad_bnsums), WITHOUT the apply pass: for a consumer that applies them itself (conv5x5_dgrad_bnapply)."""
+    require_cuda(dy, x)
+    B, H, W, C = x.shape
+    parts, nparts = presums
+    ws = workspace("bn", lib.sept_bn_workspace_floats(C), x.device)
+    sums = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+    dgamma = dbeta = None
+    if need_param_grads:
+        dgamma = torch.empty(C, dtype=torch.float32, device=x.device) if out_gamma is None else out_gamma
+        dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if out_beta is None else out_beta
+    check(lib.sept_bn_backward_sums_presummed(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+                                              beta.data_ptr(), _p(dropscale), parts.data_ptr(), nparts, ws.data_ptr(),
+                                              sums.data_ptr(), _p(dgamma), _p(dbeta), B, H, W, C, pool, _s(x)),
+          "sept_bn_backward_sums_presummed")
+    return sums, dgamma, dbeta
+
+
+def conv5x5_bnapply_supported(pre, cout, want_sums):
+    """does conv5x5_dgrad_bnapply have a kernel form for this block (pre (B,H,W,cin) bf16 NHWC, even H and W)?"""
+    B, H, W, cin = pre.shape
+    return pre.dtype == torch.bfloat16 and pre.is_contiguous() and \
+        lib.sept_conv5x5_bnapply_parts(B, H, W, cin, cout, 1 if want_sums else 0) > 0
+
+
+def conv5x5_dgrad_bnapply(pre, gpool, sums, mean, invstd, gamma, beta, dropscale, wtd, ep=None):
+    """Data gradient of a 5x5 conv straight from a BatchNorm + ReLU + MaxPool 2x2 block's backward inputs: pre (B,H,W,cin) bf16
+    = the block's stored pre-activations, gpool (B,H/2,W/2,cin) bf16 = gradient of its pooled output, sums [2 cin] (from
+    bn_backward_sums_presummed).  The block's apply pass runs in the conv's tile loader; its (B,H,W,cin) gradient tensor is
+    neither written nor read.  ep: None (plain), ("pool", ypool, gamma, beta, drop) as conv5x5_dgrad_bnsums, or
+    ("ext", ext, mean, invstd, gamma, beta, drop) as conv5x5_dgrad_bnsums_ext.  -> (dx (B,H,W,cout) bf16, presums or None)."""
+    require_cuda(pre, gpool, wtd)
+    B, H, W, cin = pre.shape
+    cout = wtd.shape[1]
+    if tuple(gpool.shape) != (B, H // 2, W // 2, cin) or gpool.dtype != torch.bfloat16 or not gpool.is_contiguous():
+        raise SeptError(f"conv5x5_dgrad_bnapply: gpool {tuple(gpool.shape)} {gpool.dtype} for pre {tuple(pre.shape)}")
+    if sums.numel() != 2 * cin or min(mean.numel(), invstd.numel(), gamma.numel(), beta.numel()) != cin:
+        raise SeptError("conv5x5_dgrad_bnapply: per-channel arguments must have cin elements (sums: 2 cin)")
+    nparts = lib.sept_conv5x5_bnapply_parts(B, H, W, cin, cout, 1 if ep is not None else 0)
+    if nparts <= 0:
+        raise SeptError(f"conv5x5_dgrad_bnapply: no kernel form for {cin}->{cout} at {H}x{W} (conv5x5_bnapply_supported)")
+    dx = torch.empty((B, H, W, cout), dtype=torch.bfloat16, device=pre.device)
+    parts = None
+    e_y = e_mean = e_invstd = e_gamma = e_beta = e_drop = None
+    if ep is not None:
+        if ep[0] == "pool":
+            _, e_y, e_gamma, e_beta, e_drop = ep
+        else:
+            _, e_y, e_mean, e_invstd, e_gamma, e_beta, e_drop = ep
+        if tuple(e_y.shape) != (B, H, W, cout) or e_y.dtype != torch.bfloat16 or not e_y.is_contiguous():
+            raise SeptError(f"conv5x5_dgrad_bnapply: epilogue tensor {tuple(e_y.shape)} for an output of {(B, H, W, cout)}")
+        parts = workspace(f"conv5x5_bwsums{cout}", nparts * 2 * cout, pre.device)
+    h = TIMER.start(f"conv5x5_mfma<{cin},{cout}>") if TIMER is not None else None
+    check(lib.sept_conv5x5_dgrad_bnapply(pre.data_ptr(), gpool.data_ptr(), sums.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                         gamma.data_ptr(), beta.data_ptr(), _p(dropscale), wtd.data_ptr(), dx.data_ptr(),
+                                         _p(e_y), _p(e_mean), _p(e_invstd), _p(e_gamma), _p(e_beta), _p(e_drop), _p(parts),
+                                         B, H, W, cin, cout, _s(dx)), "sept_conv5x5_dgrad_bnapply")
+    if h is not None:
+        TIMER.stop(h)
+    return dx, ((parts, nparts) if ep is not None else None)
+
+
 def bn_backward_sums_ext(dy, ext, mean, invstd, gamma, beta, dropscale, presums=None, need_param_grads=True, out_gamma=None,
                          out_beta=None):
     """(sum g, sum g * xhat) [2C] of a pool-first block (+ dgamma, dbeta): from a producer's partials (dy is then already

@@ -432,3 +432,72 @@ def test_dgrad_epilogue_sums_for_a_pool_first_block(B, H, W, cin, cout):
     scale = float(sums2.abs().max())
     assert torch.allclose(sums, sums2, rtol=1e-4, atol=1e-5 * scale)
     assert torch.equal(dg, sums[cout:]) and torch.equal(db, sums[:cout])
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,ep,drop", [
+    (3, 100, 40, 64, 32, "ext", True), (2, 100, 40, 64, 32, None, False), (5, 50, 20, 128, 64, "pool", True),
+    (3, 50, 32, 128, 64, None, True), (2, 26, 12, 64, 32, "pool", False), (4, 100, 64, 64, 32, "ext", False)])
+def test_dgrad_with_the_batchnorm_apply_pass_in_its_loader(B, H, W, cin, cout, ep, drop):
+    """sept_conv5x5_dgrad_bnapply (blocks 2 / 3 of a network without conv weight gradients): the data-gradient conv that forms
+    the gradient of a BatchNorm + ReLU + MaxPool block's pre-activations in its tile loader, against the apply pass
+    (sept_bn_relu_pool_backward: baseline_models.py:179-182 + autograd) followed by the conv on the stored tensor -- for the
+    plain epilogue and both sums epilogues, tiles that start on odd rows, ragged last tiles and dropped channels."""
+    from sept_amd import ops
+    g = torch.Generator().manual_seed(cin + H + W)
+    pre = (torch.randn(B, H, W, cin, generator=g) * 1.3).bfloat16().cuda()
+    gp = torch.randn(B, H // 2, W // 2, cin, generator=g).bfloat16().cuda()
+    wt = ops.conv5x5_prep_weights((torch.randn(cin, cout, 5, 5, generator=g) * 0.05).cuda(), 1)
+    mean, invstd = (0.2 * torch.randn(cin, generator=g)).cuda(), (0.5 + torch.rand(cin, generator=g)).cuda()
+    gamma, beta = (1 + 0.3 * torch.randn(cin, generator=g)).cuda(), (0.2 * torch.randn(cin, generator=g)).cuda()
+    gamma[3] = -0.6
+    dmask = ((torch.rand(B, cin, generator=g) > 0.2).float() * 1.25).cuda() if drop else None
+    assert ops.conv5x5_bnapply_supported(pre, cout, ep is not None)
+    # the unfused pair: reduce + apply pass, then the conv on the stored gradient
+    dpre, _, _ = ops.bn_relu_pool_backward(gp, pre, mean, invstd, gamma, beta, dmask, 2, need_param_grads=False)
+    sums, _, _ = ops.bn_backward_sums(gp, pre, mean, invstd, gamma, beta, dmask, 2, need_param_grads=False)
+    e_mean, e_invstd = (0.1 * torch.randn(cout, generator=g)).cuda(), (0.5 + torch.rand(cout, generator=g)).cuda()
+    e_gamma, e_beta = (1 + 0.3 * torch.randn(cout, generator=g)).cuda(), (0.2 * torch.randn(cout, generator=g)).cuda()
+    e_drop = ((torch.rand(B, cout, generator=g) > 0.2).float() * 1.25).cuda() if drop else None
+    if ep == "ext":
+        ext = (torch.randn(B, H, W, cout, generator=g) * 1.5).bfloat16().cuda()
+        want, wsums = ops.conv5x5_dgrad_bnsums_ext(dpre, wt, ext, e_mean, e_invstd, e_gamma, e_beta, e_drop)
+        got, gsums = ops.conv5x5_dgrad_bnapply(pre, gp, sums, mean, invstd, gamma, beta, dmask, wt,
+                                               ("ext", ext, e_mean, e_invstd, e_gamma, e_beta, e_drop))
+    elif ep == "pool":
+        ypool = torch.relu(torch.randn(B, H, W, cout, generator=g)).bfloat16().cuda()
+        want, wsums = ops.conv5x5_dgrad_bnsums(dpre, wt, ypool, e_gamma, e_beta, e_drop)
+        got, gsums = ops.conv5x5_dgrad_bnapply(pre, gp, sums, mean, invstd, gamma, beta, dmask, wt,
+                                               ("pool", ypool, e_gamma, e_beta, e_drop))
+    else:
+        want, wsums = ops.conv5x5(dpre, wt), None
+        got, gsums = ops.conv5x5_dgrad_bnapply(pre, gp, sums, mean, invstd, gamma, beta, dmask, wt, None)
+    # the loader evaluates sc (ge - m1 - xhat m2) as sc ge + kb + kc x: single bf16 roundings of the staged gradient may differ
+    w32, g32 = want.float(), got.float()
+    assert float((g32 - w32).norm() / w32.norm()) < 3e-3
+    assert float((g32 - w32).abs().max()) < 2e-2 * float(w32.abs().max())
+    if ep == "ext":
+        assert torch.equal(got == 0, want == 0) or float(((got == 0) != (want == 0)).float().mean()) < 1e-4   # same mask
+    if wsums is not None:
+        assert gsums is not None    # (the loader form may run another tile shape: the number of partial columns may differ)
+        a = gsums[0][:2 * cout * gsums[1]].view(2 * cout, -1).sum(1)
+        b = wsums[0][:2 * cout * wsums[1]].view(2 * cout, -1).sum(1)
+        assert torch.allclose(a, b, rtol=5e-3, atol=5e-3 * float(b.abs().max()))
+    # and against plain torch: the whole block's backward + transposed conv in fp32
+    if ep is None and B <= 3:
+        x32 = pre.float().permute(0, 3, 1, 2).requires_grad_(True)
+        sc = (gamma * invstd).view(1, -1, 1, 1)
+        # BatchNorm with the GIVEN statistics treated as batch statistics is not what autograd would differentiate: the sums
+        # (m1, m2) are inputs here, so restate the formula instead
+        xh = (x32.detach() - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)
+        y = torch.relu(xh * gamma.view(1, -1, 1, 1) + beta.view(1, -1, 1, 1))
+        yp, idx = torch.nn.functional.max_pool2d(y, 2, return_indices=True)
+        gg = gp.float().permute(0, 3, 1, 2) * (dmask.view(B, -1, 1, 1) if drop else 1.0)
+        gg = torch.where(yp > 0, gg, torch.zeros_like(gg))
+        ge = torch.nn.functional.max_unpool2d(gg, idx, 2, output_size=(H, W))
+        n = float(B * H * W)
+        m1, m2 = (sums[:cin] / n).view(1, -1, 1, 1), (sums[cin:] / n).view(1, -1, 1, 1)
+        d = (sc * (ge - m1 - xh * m2)).bfloat16().float()
+        wfull = wt.float()   # [25][cout][cin], taps already flipped for the data gradient
+        wconv = wfull.view(5, 5, cout, cin).permute(2, 3, 0, 1).contiguous()
+        ref = torch.nn.functional.conv2d(d, wconv, padding=2).permute(0, 2, 3, 1)
+        assert float((g32 - ref).norm() / ref.norm()) < 6e-3
