@@ -408,7 +408,19 @@ def main():
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             dtf = float(t.item())
         feed.swap_in()                          # leave nothing pending
+        # the transfer by itself (nothing else on the GPU): tells a slow PCIe link / host of this box from a scheduling problem
+        h2d = []
+        for k in range(5):
+            torch.cuda.synchronize()
+            t0h = time.perf_counter()
+            feed.prefetch(host[k % 2])
+            feed.copy_stream.synchronize()
+            h2d.append(time.perf_counter() - t0h)
+            feed.swap_in()
+        torch.cuda.synchronize()
+        h2d_ms = sorted(h2d)[len(h2d) // 2] * 1e3
         host_fed = {"value": round(clips * world * a.steps / dtf, 2), "unit": "utterances/s",
+                    "h2d_alone_ms": round(h2d_ms, 3), "h2d_alone_GBps": round(feed.nbytes / h2d_ms / 1e6, 1),
                     "ms_per_step": round(dtf / a.steps * 1e3, 3), "vs_resident": round(dt / dtf, 4),
                     "host_bytes_per_step_per_gpu": feed.nbytes,
                     "how": "two pinned host batches alternate: ONE H2D transfer per batch on a copy stream, enqueued right "

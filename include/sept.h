@@ -308,6 +308,17 @@ int sept_conv5x5_dgrad_bnapply(const void* pre, const void* gpool, const float* 
                                const float* ep_invstd, const float* ep_gamma, const float* ep_beta,
                                const float* ep_dropscale, float* partials, int B, int H, int W, int cin, int cout,
                                void* stream);
+/* Forward conv behind a block in pool-first form (sept_conv1_forward_pool) with that block's activation pass in the conv's
+ * tile loader (baseline_models.py:173-178: BatchNorm2d + ReLU + MaxPool2d + Dropout2d of block 1 feeding conv.5): ext
+ * (B, H, W, cin) bf16 = the block's window extrema; the conv's input is dropscale * relu(bn(ext)), bit for bit what
+ * sept_bn_relu_ext_forward stores, formed on the way into the LDS tile -- that tensor is neither written nor read (for a
+ * network whose conv.5 needs no weight gradient nothing else consumes it).  stats (nullable): the statistics partials of
+ * sept_conv5x5_forward_stats, [2 cout][sept_conv5x5_act_parts(..., 1)].  sept_conv5x5_act_parts: columns of `stats`
+ * (want_stats != 0) or 1 when the shape has this form at this width, else 0. */
+int sept_conv5x5_act_parts(int B, int H, int W, int cin, int cout, int want_stats);
+int sept_conv5x5_forward_act(const void* ext, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                             const float* dropscale, const void* wt, const float* bias, void* y, float* stats, int B, int H,
+                             int W, int cin, int cout, void* stream);
 /* Which tile shape a launch at image width W takes (host-only, no GPU needed): out[6] = pixel blocks per wave, waves over
  * pixels, waves over output channels, taps per barrier (0 / negative: double-buffered), input-channel slices, LDS bytes.
  * Returns 0, or SEPT_ERR_UNSUPPORTED when the channel pair (or its statistics form, want_stats != 0) has no kernel. */

@@ -34,6 +34,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) float f32x8;
 
 constexpr int kTaps = 25;
 constexpr int kRowPad = 192;   // bytes appended to every staged input row (see the header comment)
@@ -65,6 +66,9 @@ struct ConvArgs {
   //   l_drop [B][CIN] or null
   // exactly the arithmetic of sept_bn_bwd_apply_kernel<CPP, 2> (same expressions, same bf16 rounding), so the
   // [B][H][W][CIN] gradient tensor is neither written nor read.
+  // LACT kernels (forward launches behind a pool-first block): x = that block's ext [B][H][W][CIN]; the loader forms the
+  // block's activation l_drop * relu(ext * gamma * invstd + beta - mean * gamma * invstd) on the way into the tile
+  // (sept_bn_relu_ext_fwd_kernel's expression), so the activation tensor is neither written nor read.
   const bf16* lg;
   const float *l_sums, *l_mean, *l_invstd, *l_gamma, *l_beta, *l_drop;
   float l_inv_n;
@@ -99,10 +103,12 @@ __host__ __device__ constexpr size_t conv_stats_smem(int mt, int cout, int nthr)
 // (Second launch bound = waves per SIMD: the statistics form of an 8-wave shape that lives with two workgroups
 // per CU is held to the 128 VGPRs its plain form uses; shapes whose plain form needs more carry no cap.)
 enum { kEpiPlain = 0, kEpiStats = 1, kEpiBwSums = 2 };
-template <int CINF, int COUT, int PB, int WP, int WN, int TGP, int CS, int EPI = kEpiPlain, bool LBN = false>
+enum { kLdPlain = 0, kLdBnApply = 1, kLdAct = 2 };
+template <int CINF, int COUT, int PB, int WP, int WN, int TGP, int CS, int EPI = kEpiPlain, int LD = kLdPlain>
 __global__ __launch_bounds__(64 * WP * WN,
-                             ((EPI != kEpiPlain || LBN) && WP * WN == 8 && !(TGP <= 0 && CINF >= 64 && (CS == 1 || CINF == 128))) ? 4 : 1)
+                             ((EPI != kEpiPlain || LD != kLdPlain) && WP * WN == 8 && !(TGP <= 0 && CINF >= 64 && (CS == 1 || CINF == 128))) ? 4 : 1)
 void sept_conv5x5_mfma_kernel(ConvArgs a) {
+  constexpr bool LBN = LD == kLdBnApply, LACT = LD == kLdAct;
   constexpr bool STATS = EPI != kEpiPlain;   // the output tile goes through the LDS for per-channel column sums
   constexpr bool DBUF = TGP <= 0;                               // TGP <= 0: double-buffered groups of max(1, -TGP) taps
   constexpr int TG = TGP == 0 ? 1 : (TGP < 0 ? -TGP : TGP);
@@ -275,6 +281,18 @@ void sept_conv5x5_mfma_kernel(ConvArgs a) {
     const bf16* xb = a.x + size_t(b) * HW * CINF + c0;
     const int total = NR * W4 * CPP;
     constexpr int SB = (PB * NB >= 4 && CS > 1) ? 2 : 4;   // 64 accumulator registers are live while slice 2 is staged: stay under 128
+    f32x8 asc, ash, adr;   // LACT: this thread's channel chunk is fixed (NTHR % CPP == 0)
+    if constexpr (LACT) {
+      static_assert(NTHR % CPP == 0, "a thread keeps its channel chunk");
+      const int ch = c0 + (tid % CPP) * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float ga = a.l_gamma[ch + e], is = a.l_invstd[ch + e];
+        asc[e] = ga * is;
+        ash[e] = a.l_beta[ch + e] - a.l_mean[ch + e] * ga * is;
+        adr[e] = a.l_drop ? a.l_drop[size_t(b) * CINF + ch + e] : 1.f;
+      }
+    }
     for (int i0 = tid; i0 < total; i0 += NTHR * SB) {
       uint4 v[SB];
       int dst[SB];
@@ -286,12 +304,26 @@ void sept_conv5x5_mfma_kernel(ConvArgs a) {
         const int h = h_first - 2 + row, w = col - 2;
         const bool in = h >= 0 && h < H && w >= 0 && w < W;
         v[j] = *reinterpret_cast<const uint4*>(xb + (size_t(min(max(h, 0), H - 1)) * W + min(max(w, 0), W - 1)) * CINF + c * 8);
-        if (!in) v[j] = make_uint4(0, 0, 0, 0);
-        dst[j] = row * RP + col * PS + c * 16;
+        if (!LACT && !in) v[j] = make_uint4(0, 0, 0, 0);
+        dst[j] = (LACT && !in) ? -1 - (row * RP + col * PS + c * 16) : row * RP + col * PS + c * 16;
       }
 #pragma unroll
-      for (int j = 0; j < SB; ++j)
-        if (i0 + j * NTHR < total) *reinterpret_cast<uint4*>(tile + dst[j]) = v[j];
+      for (int j = 0; j < SB; ++j) {
+        if constexpr (LACT) {   // the padding is zeros of the ACTIVATION: applied to the pixels inside the image only
+          const bool in = dst[j] >= 0;
+          const int d = in ? dst[j] : -1 - dst[j];
+          bf16x8 xr;
+          __builtin_memcpy(&xr, &v[j], 16);
+          const f32x8 t = __builtin_convertvector(xr, f32x8) * asc + ash;
+          f32x8 m;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) m[e] = in ? fmaxf(t[e], 0.f) : 0.f;
+          if (a.l_drop) m *= adr;
+          if (i0 + j * NTHR < total) *reinterpret_cast<bf16x8*>(tile + d) = __builtin_convertvector(m, bf16x8);
+        } else {
+          if (i0 + j * NTHR < total) *reinterpret_cast<uint4*>(tile + dst[j]) = v[j];
+        }
+      }
     }
   }
   {
@@ -499,18 +531,26 @@ struct ConvVariant {
                           // sums epilogue (data-gradient shapes, cin > cout)
   const void* fn_lbn;        // data-gradient shapes: the input gradient formed in the tile loader (LBN), plain epilogue
   const void* fn_lbn_stats;  // ... with the BatchNorm backward sums epilogue
+  const void* fn_act;        // forward shapes behind a pool-first block: its activation formed in the tile loader (LACT)
+  const void* fn_act_stats;  // ... with the statistics epilogue
 };
 #define SEPT_CONV_VARIANT(ci, co, pb, wp, wn, tg, cs) \
   { ci, co, pb, wp, wn, tg, cs, reinterpret_cast<const void*>(&sept_conv5x5_mfma_kernel<ci, co, pb, wp, wn, tg, cs>), \
     reinterpret_cast<const void*>(&sept_conv5x5_mfma_kernel<ci, co, pb, wp, wn, tg, cs, (ci <= co) ? kEpiStats : kEpiBwSums>), \
-    nullptr, nullptr }
+    nullptr, nullptr, nullptr, nullptr }
 // ... a data-gradient shape that also exists with the loader form (LBN): the ones whose loader fits the 128 registers that
 // keep two workgroups on a CU (the 512-pixel / four-slice form of 128 -> 64 does not: 184)
 #define SEPT_CONV_VARIANT_L(ci, co, pb, wp, wn, tg, cs) \
   { ci, co, pb, wp, wn, tg, cs, reinterpret_cast<const void*>(&sept_conv5x5_mfma_kernel<ci, co, pb, wp, wn, tg, cs>), \
     reinterpret_cast<const void*>(&sept_conv5x5_mfma_kernel<ci, co, pb, wp, wn, tg, cs, kEpiBwSums>), \
-    reinterpret_cast<const void*>(&sept_conv5x5_mfma_kernel<ci, co, pb, wp, wn, tg, cs, kEpiPlain, true>), \
-    reinterpret_cast<const void*>(&sept_conv5x5_mfma_kernel<ci, co, pb, wp, wn, tg, cs, kEpiBwSums, true>) }
+    reinterpret_cast<const void*>(&sept_conv5x5_mfma_kernel<ci, co, pb, wp, wn, tg, cs, kEpiPlain, kLdBnApply>), \
+    reinterpret_cast<const void*>(&sept_conv5x5_mfma_kernel<ci, co, pb, wp, wn, tg, cs, kEpiBwSums, kLdBnApply>), nullptr, nullptr }
+// ... a forward shape that also exists with the activation loader (LACT): 32 -> 64, the conv behind a pool-first block 1
+#define SEPT_CONV_VARIANT_A(ci, co, pb, wp, wn, tg, cs) \
+  { ci, co, pb, wp, wn, tg, cs, reinterpret_cast<const void*>(&sept_conv5x5_mfma_kernel<ci, co, pb, wp, wn, tg, cs>), \
+    reinterpret_cast<const void*>(&sept_conv5x5_mfma_kernel<ci, co, pb, wp, wn, tg, cs, kEpiStats>), nullptr, nullptr, \
+    reinterpret_cast<const void*>(&sept_conv5x5_mfma_kernel<ci, co, pb, wp, wn, tg, cs, kEpiPlain, kLdAct>), \
+    reinterpret_cast<const void*>(&sept_conv5x5_mfma_kernel<ci, co, pb, wp, wn, tg, cs, kEpiStats, kLdAct>) }
 // Order = measured preference of tile shapes at the training shapes (tools/sweep_conv.py): the
 // 8-wave 256-pixel tiles first, smaller tiles for wide images.  Within the first tile shape that
 // fits, the dispatcher scores the buffering (TG 0 double / TG 1 single) and channel-slice (CS)
@@ -522,8 +562,8 @@ const ConvVariant kConvVariants[] = {
     // 512-pixel tiles, every wave all output channels (WN = 1: two 32-channel blocks per wave, one LDS read per MFMA):
     // 32 -> 64 91 us where the 256-pixel / two-channel-halves form takes 104-108, 128 -> 64 (four channel slices) 94.5
     // against 103-105 (same call, round 2); pairs of taps per barrier were slower here (111 us)
-    SEPT_CONV_VARIANT(32, 64, 2, 8, 1, 0, 1),
-    SEPT_CONV_VARIANT(32, 64, 2, 4, 2, 0, 1),   SEPT_CONV_VARIANT(32, 64, 2, 4, 2, 1, 1),   SEPT_CONV_VARIANT(32, 64, 1, 4, 1, 1, 1),
+    SEPT_CONV_VARIANT_A(32, 64, 2, 8, 1, 0, 1),
+    SEPT_CONV_VARIANT_A(32, 64, 2, 4, 2, 0, 1),   SEPT_CONV_VARIANT_A(32, 64, 2, 4, 2, 1, 1),   SEPT_CONV_VARIANT_A(32, 64, 1, 4, 1, 1, 1),
     SEPT_CONV_VARIANT(64, 128, 1, 4, 2, 1, 1),  SEPT_CONV_VARIANT(64, 128, 2, 4, 2, 0, 2),  SEPT_CONV_VARIANT(64, 128, 2, 4, 2, 1, 2),
     // 64 -> 32 (data gradient of conv2): one 32-channel output block per wave, so a 256-pixel tile is only 2 MFMAs per
     // wave, tap and channel slice; 512-pixel tiles (two pixel blocks per wave) with pairs of taps per barrier measured
@@ -554,7 +594,7 @@ extern "C" int sept_conv5x5_prep_weights(const float* w_oihw, int cout, int cin,
 
 namespace {
 // The kernel for a shape; with want_stats only if its statistics form keeps the same number of workgroups per CU.
-const ConvVariant* conv_pick(int W, int cin, int cout, bool want_stats, size_t* smem_out, bool want_lbn = false) {
+const ConvVariant* conv_pick(int W, int cin, int cout, bool want_stats, size_t* smem_out, int want_lbn = 0) {
   const int force_pb = getenv("SEPT_CONV_PB") ? atoi(getenv("SEPT_CONV_PB")) : 0;  // tuning aids
   const int force_ns = getenv("SEPT_CONV_NS") ? atoi(getenv("SEPT_CONV_NS")) : 0;
   const int force_tg = getenv("SEPT_CONV_TG") ? atoi(getenv("SEPT_CONV_TG")) : 0;
@@ -570,13 +610,13 @@ const ConvVariant* conv_pick(int W, int cin, int cout, bool want_stats, size_t* 
   int best_score = -1;
   const ConvVariant* shape_best = nullptr;  // best form of the shape currently scanned (table entries of a shape need not be adjacent)
   for (const ConvVariant& lead : kConvVariants) {
-    if (lead.cin != cin || lead.cout != cout || (want_lbn && !lead.fn_lbn)) continue;
+    if (lead.cin != cin || lead.cout != cout || (want_lbn == 1 && !lead.fn_lbn) || (want_lbn == 2 && !lead.fn_act)) continue;
     if (best && best_score >= 20) break;
     // scan every form of lead's shape once (at the shape's first table entry)
     bool first_of_shape = true;
     for (const ConvVariant& u : kConvVariants) {
       if (&u == &lead) break;
-      if (u.cin == cin && u.cout == cout && u.pb == lead.pb && u.wp == lead.wp && u.wn == lead.wn && !(want_lbn && !u.fn_lbn))
+      if (u.cin == cin && u.cout == cout && u.pb == lead.pb && u.wp == lead.wp && u.wn == lead.wn && !((want_lbn == 1 && !u.fn_lbn) || (want_lbn == 2 && !u.fn_act)))
         first_of_shape = false;
     }
     if (!first_of_shape) continue;
@@ -585,7 +625,7 @@ const ConvVariant* conv_pick(int W, int cin, int cout, bool want_stats, size_t* 
     int shape_score = -1;
     for (const ConvVariant& v : kConvVariants) {
       if (v.cin != cin || v.cout != cout || v.pb != lead.pb || v.wp != lead.wp || v.wn != lead.wn) continue;
-      if (want_lbn && !v.fn_lbn) continue;
+      if ((want_lbn == 1 && !v.fn_lbn) || (want_lbn == 2 && !v.fn_act)) continue;
       if (force_pb && v.pb != force_pb) continue;
       if (force_ns && v.wp * v.wn != 4 * force_ns) continue;
       if (force_wn && v.wn != force_wn) continue;
@@ -623,8 +663,8 @@ const ConvVariant* conv_pick(int W, int cin, int cout, bool want_stats, size_t* 
   return best;
 }
 
-struct ConvLbn {   // the BatchNorm block whose backward apply pass runs in the tile loader (ConvArgs: LBN kernels)
-  const void* g;
+struct ConvLbn {   // the BatchNorm block whose backward apply pass (LBN; g, sums set) or forward activation (LACT; g, sums
+  const void* g;   // null) runs in the tile loader
   const float *sums, *mean, *invstd, *gamma, *beta, *drop;
 };
 
@@ -637,18 +677,20 @@ int conv_launch(const char* who, const void* x, const void* wt, const float* bia
   SEPT_REQUIRE(x && wt && y, SEPT_ERR_INVALID, "%s: null argument", who);
   SEPT_REQUIRE(B <= 65528, SEPT_ERR_UNSUPPORTED, "%s: B=%d exceeds grid.y", who, B);
   size_t best_smem = 0;
-  const ConvVariant* best = conv_pick(W, cin, cout, stats != nullptr, &best_smem, lbn != nullptr);
+  const ConvVariant* best = conv_pick(W, cin, cout, stats != nullptr, &best_smem, lbn ? (lbn->g ? 1 : 2) : 0);
   SEPT_REQUIRE(best, SEPT_ERR_UNSUPPORTED,
                "%s: no kernel for cin=%d cout=%d W=%d (supported channel pairs: 32->64, "
                "64->128, 64->32, 128->64, 128->128; statistics form: see sept_conv5x5_stats_parts)", who, cin, cout, W);
-  const void* fn = lbn ? (stats ? best->fn_lbn_stats : best->fn_lbn) : (stats ? best->fn_stats : best->fn);
+  const bool act = lbn && !lbn->g;
+  const void* fn = act ? (stats ? best->fn_act_stats : best->fn_act)
+                       : lbn ? (stats ? best->fn_lbn_stats : best->fn_lbn) : (stats ? best->fn_stats : best->fn);
   SEPT_REQUIRE(fn, SEPT_ERR_UNSUPPORTED, "%s: no kernel form for cin=%d cout=%d", who, cin, cout);
   ConvArgs a;
   a.lg = nullptr;
   a.l_sums = a.l_mean = a.l_invstd = a.l_gamma = a.l_beta = a.l_drop = nullptr;
   a.l_inv_n = 0.f;
   if (lbn) {
-    SEPT_REQUIRE(H % 2 == 0 && W % 2 == 0, SEPT_ERR_UNSUPPORTED, "%s: H=%d W=%d (the loader form needs whole 2x2 windows)", who, H, W);
+    SEPT_REQUIRE(act || (H % 2 == 0 && W % 2 == 0), SEPT_ERR_UNSUPPORTED, "%s: H=%d W=%d (the loader form needs whole 2x2 windows)", who, H, W);
     a.lg = static_cast<const bf16*>(lbn->g);
     a.l_sums = lbn->sums; a.l_mean = lbn->mean; a.l_invstd = lbn->invstd; a.l_gamma = lbn->gamma; a.l_beta = lbn->beta;
     a.l_drop = lbn->drop;
@@ -700,7 +742,7 @@ int conv_epilogue_parts(int B, int H, int W, int cin, int cout) {
 extern "C" int sept_conv5x5_bnapply_parts(int B, int H, int W, int cin, int cout, int want_sums) {
   if (cin <= cout || B <= 0 || H <= 0 || W <= 0 || H % 2 || W % 2) return 0;
   size_t smem = 0;
-  const ConvVariant* v = conv_pick(W, cin, cout, want_sums != 0, &smem, true);
+  const ConvVariant* v = conv_pick(W, cin, cout, want_sums != 0, &smem, 1);
   if (!v) return 0;
   if (!want_sums) return 1;
   const int mt = 32 * v->pb * v->wp;
@@ -786,4 +828,29 @@ extern "C" int sept_conv5x5_dgrad_bnapply(const void* pre, const void* gpool, co
   const ConvLbn l{gpool, sums, mean, invstd, gamma, beta, dropscale};
   return conv_launch("sept_conv5x5_dgrad_bnapply", pre, wt, nullptr, dx_out, partials, B, H, W, cin, cout, stream, ep_ypool,
                      ep_gamma, ep_beta, ep_dropscale, ep_mean, ep_invstd, &l);
+}
+
+// Forward conv behind a block in pool-first form (sept_conv1_forward_pool) with that block's activation pass in the tile
+// loader: ext (B, H, W, cin) bf16 = the block's window extrema; the conv's input is dropscale * relu(bn(ext)) -- what
+// sept_bn_relu_ext_forward would have stored -- formed on the way into the LDS tile, so that (B, H, W, cin) tensor is neither
+// written nor read.  stats (nullable): the statistics partials of sept_conv5x5_forward_stats.
+// sept_conv5x5_act_parts: columns of `stats` (want_stats != 0) or 1 when the shape has this form at this width, else 0.
+extern "C" int sept_conv5x5_act_parts(int B, int H, int W, int cin, int cout, int want_stats) {
+  if (cin > cout || B <= 0 || H <= 0 || W <= 0) return 0;
+  size_t smem = 0;
+  const ConvVariant* v = conv_pick(W, cin, cout, want_stats != 0, &smem, 2);
+  if (!v) return 0;
+  if (!want_stats) return 1;
+  const int mt = 32 * v->pb * v->wp;
+  return B * ((H * W + mt - 1) / mt);
+}
+
+extern "C" int sept_conv5x5_forward_act(const void* ext, const float* mean, const float* invstd, const float* gamma,
+                                        const float* beta, const float* dropscale, const void* wt, const float* bias,
+                                        void* y, float* stats, int B, int H, int W, int cin, int cout, void* stream) {
+  SEPT_REQUIRE(ext && mean && invstd && gamma && beta && B > 0 && cin <= cout, SEPT_ERR_INVALID,
+               "sept_conv5x5_forward_act: null argument / empty batch / not a forward shape (cin=%d cout=%d)", cin, cout);
+  const ConvLbn l{nullptr, nullptr, mean, invstd, gamma, beta, dropscale};
+  return conv_launch("sept_conv5x5_forward_act", ext, wt, bias, y, stats, B, H, W, cin, cout, stream, nullptr, nullptr, nullptr,
+                     nullptr, nullptr, nullptr, &l);
 }

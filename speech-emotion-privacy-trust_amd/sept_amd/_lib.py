@@ -134,6 +134,8 @@ SIGNATURES = {
     "sept_conv5x5_bwsums_parts": (c_int, [c_int] * 5),
     "sept_conv5x5_variant": (c_int, [c_int] * 4 + [POINTER(c_int)]),
     "sept_conv5x5_bnapply_parts": (c_int, [c_int] * 6),
+    "sept_conv5x5_act_parts": (c_int, [c_int] * 6),
+    "sept_conv5x5_forward_act": (c_int, [c_void_p] * 10 + [c_int] * 5 + [c_void_p]),
     "sept_conv5x5_dgrad_bnapply": (c_int, [c_void_p] * 17 + [c_int] * 5 + [c_void_p]),
     "sept_conv5x5_dgrad_bnsums": (c_int, [c_void_p] * 8 + [c_int] * 5 + [c_void_p]),
     "sept_bn_relu_pool_backward_presummed": (c_int, [c_void_p] * 8 + [c_int, c_void_p, c_void_p, c_void_p, c_void_p] +

@@ -261,7 +261,10 @@ def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None, gfeat=Non
             if train and (P.drop_ps[li] > 0 or "drop2d" in inj):
                 d2 = inj.get("drop2d")
                 drop = d2[li] if d2 is not None else masks[("c", li)]
-            out = ops.bn_relu_ext_forward(ext, None, mean, invstd, bn.weight, bn.bias, drop)   # idx stays pure positions
+            # the activation pass: inside the NEXT conv's tile loader when nothing else reads the activation tensor (that conv
+            # needs no weight gradient: the frozen network) -- resolved when that conv is reached; else a quarter-size pass now
+            defer = BN_ACT_IN_CONV and li + 1 < len(P.convs) and not P.convs[li + 1].weight.requires_grad
+            out = None if defer else ops.bn_relu_ext_forward(ext, None, mean, invstd, bn.weight, bn.bias, drop)   # idx stays pure positions
             S.blocks.append(SimpleNamespace(inp=None, pre=None, ext=ext, out=out, mean=mean, invstd=invstd, drop=drop, pool=pool,
                                             h=h, w=w, bn_train=True, sync=False, l1_fused=False, idx=idx))
             act = out
@@ -278,13 +281,29 @@ def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None, gfeat=Non
         else:
             wt = _cached("convfwd", cv.weight, lambda: ops.conv5x5_prep_weights(cv.weight, 0))
             res = None
-            if CONV_FUSED_STATS and bn.training and not _SYNC_BN["on"]:   # statistics in the conv's epilogue
+            prevb = S.blocks[li - 1]
+            if prevb.out is None:   # a pool-first block whose activation pass was deferred into this conv's loader
+                pbn = P.bns[li - 1]
+                want = CONV_FUSED_STATS and bn.training and not _SYNC_BN["on"]
+                r = ops.conv5x5_forward_act(prevb.ext, prevb.mean, prevb.invstd, pbn.weight, pbn.bias, prevb.drop, wt, cv.bias,
+                                            want, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                            bn.momentum if bn.momentum is not None else 0.1, bn.eps)
+                if r is None:       # no such kernel form for this shape: the activation tensor after all
+                    prevb.out = act = ops.bn_relu_ext_forward(prevb.ext, None, prevb.mean, prevb.invstd, pbn.weight, pbn.bias,
+                                                              prevb.drop)
+                elif want:
+                    res = r
+                else:
+                    res = (r, None, None)
+            if res is not None:
+                pass
+            elif CONV_FUSED_STATS and bn.training and not _SYNC_BN["on"]:   # statistics in the conv's epilogue
                 res = ops.conv5x5_forward_stats(act, wt, cv.bias, bn.running_mean, bn.running_var,
                                                 bn.num_batches_tracked,
                                                 bn.momentum if bn.momentum is not None else 0.1, bn.eps)
             if res is not None:
                 pre, mean, invstd = res
-                fused_stats = True
+                fused_stats = mean is not None
             else:
                 pre = ops.conv5x5(act, wt, cv.bias)
         if fused_stats:
@@ -572,6 +591,10 @@ L1_DX_SUM = os.environ.get("SEPT_L1_DX_SUM", "1") != "0"
 # pass inside the tile loader of the data-gradient conv behind it (ops.conv5x5_dgrad_bnapply) -- the (B, H, W, C) gradient of
 # the pre-activations is neither written nor read (0.34 GB per step at 224 windows).  SEPT_BN_APPLY_CONV=0: separate pass
 BN_APPLY_IN_CONV = os.environ.get("SEPT_BN_APPLY_CONV", "1") != "0"
+# ... and, forward, a pool-first block 1's activation pass inside the tile loader of the conv behind it, when that conv needs
+# no weight gradient (ops.conv5x5_forward_act): the (B, H/2, W/2, 32) activation is neither written nor read.
+# SEPT_BN_ACT_CONV=0: the quarter-size elementwise pass
+BN_ACT_IN_CONV = os.environ.get("SEPT_BN_ACT_CONV", "1") != "0"
 
 
 def batch_sum_pair(dx1, dx2):

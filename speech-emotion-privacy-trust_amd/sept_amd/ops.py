@@ -100,6 +100,40 @@ def conv5x5_forward_stats(x, wt, bias, bn_running_mean=None, bn_running_var=None
     return out, mean, invstd
 
 
+def conv5x5_forward_act(ext, mean_in, invstd_in, gamma_in, beta_in, dropscale, wt, bias, want_stats=False, bn_running_mean=None,
+                        bn_running_var=None, bn_num_batches_tracked=None, momentum=0.1, eps=1e-5):
+    """conv5x5 forward behind a pool-first block whose activation pass runs in the conv's tile loader: the conv's input is
+    dropscale * relu(bn(ext)) (bn = mean_in / invstd_in / gamma_in / beta_in), bit for bit what bn_relu_ext_forward stores,
+    without that tensor.  -> y, or with want_stats (y, mean, invstd) of the OUTPUT as conv5x5_forward_stats; None when the
+    shape has no such kernel form."""
+    require_cuda(ext, wt)
+    B, H, W, cin = ext.shape
+    cout = wt.shape[1]
+    nparts = lib.sept_conv5x5_act_parts(B, H, W, cin, cout, 1 if want_stats else 0)
+    if nparts <= 0 or ext.dtype != torch.bfloat16 or not ext.is_contiguous():
+        return None
+    if min(mean_in.numel(), invstd_in.numel(), gamma_in.numel(), beta_in.numel()) != cin:
+        raise SeptError("conv5x5_forward_act: per-channel arguments must have cin elements")
+    if dropscale is not None and tuple(dropscale.shape) != (B, cin):
+        raise SeptError(f"conv5x5_forward_act: dropscale {tuple(dropscale.shape)} for a batch of {B} x {cin} channels")
+    out = torch.empty((B, H, W, cout), dtype=torch.bfloat16, device=ext.device)
+    parts = workspace(f"conv5x5_stats{cout}", nparts * 2 * cout, ext.device) if want_stats else None
+    h = TIMER.start(f"conv5x5_mfma<{cin},{cout}>") if TIMER is not None else None
+    check(lib.sept_conv5x5_forward_act(ext.data_ptr(), mean_in.data_ptr(), invstd_in.data_ptr(), gamma_in.data_ptr(),
+                                       beta_in.data_ptr(), _p(dropscale), wt.data_ptr(), _p(bias), out.data_ptr(), _p(parts),
+                                       B, H, W, cin, cout, _s(ext)), "sept_conv5x5_forward_act")
+    if h is not None:
+        TIMER.stop(h)
+    if not want_stats:
+        return out
+    mean = torch.empty(cout, dtype=torch.float32, device=ext.device)
+    invstd = torch.empty_like(mean)
+    check(lib.sept_bn_stats_from_partials(parts.data_ptr(), nparts, B * H * W, cout, mean.data_ptr(), invstd.data_ptr(),
+                                          _p(bn_running_mean), _p(bn_running_var), _p(bn_num_batches_tracked),
+                                          float(momentum), float(eps), _s(ext)), "sept_bn_stats_from_partials")
+    return out, mean, invstd
+
+
 def _p(t):
     return 0 if t is None else t.data_ptr()
 

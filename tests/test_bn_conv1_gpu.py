@@ -501,3 +501,34 @@ def test_dgrad_with_the_batchnorm_apply_pass_in_its_loader(B, H, W, cin, cout, e
         wconv = wfull.view(5, 5, cout, cin).permute(2, 3, 0, 1).contiguous()
         ref = torch.nn.functional.conv2d(d, wconv, padding=2).permute(0, 2, 3, 1)
         assert float((g32 - ref).norm() / ref.norm()) < 6e-3
+
+
+@pytest.mark.parametrize("B,H,W,stats,drop", [(3, 100, 40, True, True), (2, 100, 64, True, False), (5, 50, 20, False, True),
+                                              (2, 26, 12, True, True), (1, 7, 5, False, False)])
+def test_forward_conv_with_the_pool_first_activation_in_its_loader(B, H, W, stats, drop):
+    """sept_conv5x5_forward_act (conv.5 behind a pool-first block 1 of a network without conv weight gradients): the
+    activation dropscale * relu(bn(ext)) formed in the conv's tile loader, against sept_bn_relu_ext_forward followed by the
+    conv on the stored activation (baseline_models.py:173-178) -- same bits, including the zero padding of the ACTIVATION
+    (not of ext) at the image border and the statistics of the output."""
+    from sept_amd import ops
+    cin, cout = 32, 64
+    g = torch.Generator().manual_seed(H * 7 + W)
+    ext = (torch.randn(B, H, W, cin, generator=g) * 1.5).bfloat16().cuda()
+    mean, invstd = (0.2 * torch.randn(cin, generator=g)).cuda(), (0.5 + torch.rand(cin, generator=g)).cuda()
+    gamma, beta = (1 + 0.3 * torch.randn(cin, generator=g)).cuda(), (0.5 + 0.2 * torch.randn(cin, generator=g)).cuda()
+    gamma[5] = -0.8
+    dmask = ((torch.rand(B, cin, generator=g) > 0.2).float() * 1.25).cuda() if drop else None
+    wt = ops.conv5x5_prep_weights((torch.randn(cout, cin, 5, 5, generator=g) * 0.05).cuda(), 0)
+    bias = (0.1 * torch.randn(cout, generator=g)).cuda()
+    act = ops.bn_relu_ext_forward(ext, None, mean, invstd, gamma, beta, dmask)
+    assert float((act[:, 0] != 0).float().mean()) > 0.3          # the border rows carry non-zero activations: padding matters
+    if stats:
+        want = ops.conv5x5_forward_stats(act, wt, bias)
+        got = ops.conv5x5_forward_act(ext, mean, invstd, gamma, beta, dmask, wt, bias, True)
+        assert want is not None and got is not None
+        for a_, b_ in zip(got, want):
+            assert torch.equal(a_, b_)
+    else:
+        want = ops.conv5x5(act, wt, bias)
+        got = ops.conv5x5_forward_act(ext, mean, invstd, gamma, beta, dmask, wt, bias, False)
+        assert got is not None and torch.equal(got, want)
