@@ -564,17 +564,17 @@ const ConvVariant kConvVariants[] = {
     // against 103-105 (same call, round 2); pairs of taps per barrier were slower here (111 us)
     SEPT_CONV_VARIANT_A(32, 64, 2, 8, 1, 0, 1),
     SEPT_CONV_VARIANT_A(32, 64, 2, 4, 2, 0, 1),   SEPT_CONV_VARIANT_A(32, 64, 2, 4, 2, 1, 1),   SEPT_CONV_VARIANT_A(32, 64, 1, 4, 1, 1, 1),
-    SEPT_CONV_VARIANT(64, 128, 1, 4, 2, 1, 1),  SEPT_CONV_VARIANT(64, 128, 2, 4, 2, 0, 2),  SEPT_CONV_VARIANT(64, 128, 2, 4, 2, 1, 2),
+    SEPT_CONV_VARIANT(64, 128, 2, 4, 2, 0, 2),  SEPT_CONV_VARIANT(64, 128, 2, 4, 2, 1, 2),  SEPT_CONV_VARIANT(64, 128, 1, 4, 2, 1, 1),
     // 64 -> 32 (data gradient of conv2): one 32-channel output block per wave, so a 256-pixel tile is only 2 MFMAs per
     // wave, tap and channel slice; 512-pixel tiles (two pixel blocks per wave) with pairs of taps per barrier measured
     // 109 us where the 256-pixel form takes 131 (same call, round 2)
-    SEPT_CONV_VARIANT_L(64, 32, 2, 8, 1, -2, 2),  SEPT_CONV_VARIANT(64, 32, 2, 8, 1, 0, 2),   SEPT_CONV_VARIANT_L(64, 32, 1, 4, 1, 1, 1),
+    SEPT_CONV_VARIANT_L(64, 32, 2, 8, 1, -2, 2),  SEPT_CONV_VARIANT(64, 32, 2, 8, 1, 0, 2),
     SEPT_CONV_VARIANT(64, 32, 1, 8, 1, 0, 2),   SEPT_CONV_VARIANT_L(64, 32, 1, 8, 1, 1, 2),
     // 64 -> 32 in two channel slices is only 2 MFMAs per wave and tap: pairs of taps per barrier (-2) measured
     // 115-120 us where one tap per barrier takes 123-130 (round 2 sweeps, gpurun_out/r2i, r2j); for the other shapes
     // groups of 2 / 3 / 5 taps, 128-pixel tiles with 3-4 workgroups per CU and four channel slices were all equal
     // or slower (more LDS or more registers cost the second workgroup per CU, which is worth 2x)
-    SEPT_CONV_VARIANT_L(64, 32, 1, 8, 1, -2, 2),
+    SEPT_CONV_VARIANT_L(64, 32, 1, 8, 1, -2, 2),  SEPT_CONV_VARIANT_L(64, 32, 1, 4, 1, 1, 1),
     SEPT_CONV_VARIANT(128, 64, 2, 8, 1, 0, 4),  SEPT_CONV_VARIANT(128, 64, 2, 4, 2, 0, 2),  SEPT_CONV_VARIANT_L(128, 64, 2, 4, 2, 1, 2),
     SEPT_CONV_VARIANT(128, 128, 2, 4, 2, 0, 2), SEPT_CONV_VARIANT(128, 128, 2, 4, 2, 1, 2),
 };

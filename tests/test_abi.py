@@ -51,3 +51,27 @@ def test_no_cpu_fallback():
         from feature_extraction.audio_feature_extraction import mel_spectrogram
         with pytest.raises(RuntimeError):
             mel_spectrogram(torch.zeros(1, 16000), n_fft=800, feature_len=80)
+
+
+def test_conv_tile_shapes_at_the_training_widths():
+    """The dispatcher's choice of conv tile shape is host-only logic over a table whose ORDER matters: pin the measured
+    choices at the widths the two input sizes produce -- 80 mels: 40 / 20 columns, 128 mels: 64 / 32 --
+    so that a table edit cannot silently move a training shape to a slower kernel.  (pb, wp, wn, taps per barrier, slices)"""
+    from sept_amd import _lib
+    want = {
+        (32, 64, 40): (2, 8, 1, 0, 1), (64, 128, 20): (2, 4, 2, 0, 2), (64, 32, 40): (2, 8, 1, -2, 2), (128, 64, 20): (2, 8, 1, 0, 4),
+        (32, 64, 64): (2, 4, 2, 0, 1), (64, 128, 32): (2, 4, 2, 0, 2), (64, 32, 64): (2, 8, 1, 0, 2), (128, 64, 32): (2, 8, 1, 0, 4),
+        (128, 128, 20): (2, 4, 2, 0, 2),
+    }
+    for (cin, cout, W), shape in want.items():
+        for stats in (0, 1):
+            out = (ctypes.c_int * 6)()
+            assert _lib.lib.sept_conv5x5_variant(W, cin, cout, stats, out) == 0, (cin, cout, W, stats)
+            assert tuple(out[:5]) == shape, (cin, cout, W, stats, tuple(out[:5]))
+            assert cin == cout or 2 * out[5] <= 160 * 1024            # two workgroups per CU (not the deep model's 128 -> 128)
+    out = (ctypes.c_int * 6)()
+    assert _lib.lib.sept_conv5x5_variant(20, 48, 64, 0, out) < 0 and b"no kernel" in _lib.lib.sept_last_error()
+    # the loader forms exist where the hand-scheduled step uses them
+    assert _lib.lib.sept_conv5x5_bnapply_parts(224, 100, 40, 64, 32, 1) > 0 and _lib.lib.sept_conv5x5_bnapply_parts(224, 50, 20, 128, 64, 1) > 0
+    assert _lib.lib.sept_conv5x5_act_parts(224, 100, 40, 32, 64, 1) > 0 and _lib.lib.sept_conv5x5_act_parts(224, 100, 40, 64, 128, 1) == 0
+    assert _lib.lib.sept_conv5x5_bnapply_parts(224, 99, 40, 64, 32, 1) == 0          # odd height: no whole 2x2 windows
