@@ -57,7 +57,7 @@ def synth(clips, F, device, rank):
 
 def conv_flops(tag, Bw, F):
     """algorithmic FLOPs of one launch of the tagged conv kernel at Bw windows."""
-    name, dims = tag.split("<")
+    name, dims = tag.split("+")[0].split("<")      # "+act" / "+bnapply": the same conv with a loader form (same FLOPs)
     a, b = [int(v) for v in dims.rstrip(">").split(",")]
     cin, cout = a, b
     lo = min(cin, cout)                      # 32<->64 live at 100 x F/2, 64<->128 at 50 x F/4

@@ -118,7 +118,7 @@ def conv5x5_forward_act(ext, mean_in, invstd_in, gamma_in, beta_in, dropscale, w
         raise SeptError(f"conv5x5_forward_act: dropscale {tuple(dropscale.shape)} for a batch of {B} x {cin} channels")
     out = torch.empty((B, H, W, cout), dtype=torch.bfloat16, device=ext.device)
     parts = workspace(f"conv5x5_stats{cout}", nparts * 2 * cout, ext.device) if want_stats else None
-    h = TIMER.start(f"conv5x5_mfma<{cin},{cout}>") if TIMER is not None else None
+    h = TIMER.start(f"conv5x5_mfma<{cin},{cout}>+act") if TIMER is not None else None
     check(lib.sept_conv5x5_forward_act(ext.data_ptr(), mean_in.data_ptr(), invstd_in.data_ptr(), gamma_in.data_ptr(),
                                        beta_in.data_ptr(), _p(dropscale), wt.data_ptr(), _p(bias), out.data_ptr(), _p(parts),
                                        B, H, W, cin, cout, _s(ext)), "sept_conv5x5_forward_act")
@@ -626,7 +626,7 @@ def conv5x5_dgrad_bnapply(pre, gpool, sums, mean, invstd, gamma, beta, dropscale
         if tuple(e_y.shape) != (B, H, W, cout) or e_y.dtype != torch.bfloat16 or not e_y.is_contiguous():
             raise SeptError(f"conv5x5_dgrad_bnapply: epilogue tensor {tuple(e_y.shape)} for an output of {(B, H, W, cout)}")
         parts = workspace(f"conv5x5_bwsums{cout}", nparts * 2 * cout, pre.device)
-    h = TIMER.start(f"conv5x5_mfma<{cin},{cout}>") if TIMER is not None else None
+    h = TIMER.start(f"conv5x5_mfma<{cin},{cout}>+bnapply") if TIMER is not None else None
     check(lib.sept_conv5x5_dgrad_bnapply(pre.data_ptr(), gpool.data_ptr(), sums.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
                                          gamma.data_ptr(), beta.data_ptr(), _p(dropscale), wtd.data_ptr(), dx.data_ptr(),
                                          _p(e_y), _p(e_mean), _p(e_invstd), _p(e_gamma), _p(e_beta), _p(e_drop), _p(parts),

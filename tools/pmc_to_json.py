@@ -16,9 +16,11 @@ from collections import defaultdict
 
 
 def tag_of(name):
-    m = re.search(r"sept_conv5x5_mfma_kernel<(\d+), (\d+)", name)
-    if m:
-        return f"conv5x5_mfma<{m.group(1)},{m.group(2)}>"
+    m = re.search(r"sept_conv5x5_mfma_kernel<(\d+), (\d+)((?:, -?\d+)*)>", name)
+    if m:   # ninth template argument = loader form (1: BatchNorm backward apply, 2: pool-first activation): ops.py's tags
+        rest = [v.strip() for v in m.group(3).split(",") if v.strip()]
+        ld = {"1": "+bnapply", "2": "+act"}.get(rest[6], "") if len(rest) >= 7 else ""
+        return f"conv5x5_mfma<{m.group(1)},{m.group(2)}>{ld}"
     m = re.search(r"sept_conv5x5_wgrad_kernel<(\d+), (\d+)", name)
     if m:
         return f"conv5x5_wgrad<{m.group(1)},{m.group(2)}>"
