@@ -594,7 +594,7 @@ extern "C" int sept_conv5x5_prep_weights(const float* w_oihw, int cout, int cin,
 
 namespace {
 // The kernel for a shape; with want_stats only if its statistics form keeps the same number of workgroups per CU.
-const ConvVariant* conv_pick(int W, int cin, int cout, bool want_stats, size_t* smem_out, int want_lbn = 0) {
+const ConvVariant* conv_pick(int W, int cin, int cout, bool want_stats, size_t* smem_out, int want_lbn = 0, int max_mt = 1 << 30) {
   const int force_pb = getenv("SEPT_CONV_PB") ? atoi(getenv("SEPT_CONV_PB")) : 0;  // tuning aids
   const int force_ns = getenv("SEPT_CONV_NS") ? atoi(getenv("SEPT_CONV_NS")) : 0;
   const int force_tg = getenv("SEPT_CONV_TG") ? atoi(getenv("SEPT_CONV_TG")) : 0;
@@ -611,6 +611,7 @@ const ConvVariant* conv_pick(int W, int cin, int cout, bool want_stats, size_t* 
   const ConvVariant* shape_best = nullptr;  // best form of the shape currently scanned (table entries of a shape need not be adjacent)
   for (const ConvVariant& lead : kConvVariants) {
     if (lead.cin != cin || lead.cout != cout || (want_lbn == 1 && !lead.fn_lbn) || (want_lbn == 2 && !lead.fn_act)) continue;
+    if (32 * lead.pb * lead.wp > max_mt) continue;
     if (best && best_score >= 20) break;
     // scan every form of lead's shape once (at the shape's first table entry)
     bool first_of_shape = true;
@@ -626,6 +627,7 @@ const ConvVariant* conv_pick(int W, int cin, int cout, bool want_stats, size_t* 
     for (const ConvVariant& v : kConvVariants) {
       if (v.cin != cin || v.cout != cout || v.pb != lead.pb || v.wp != lead.wp || v.wn != lead.wn) continue;
       if ((want_lbn == 1 && !v.fn_lbn) || (want_lbn == 2 && !v.fn_act)) continue;
+      if (32 * v.pb * v.wp > max_mt) continue;
       if (force_pb && v.pb != force_pb) continue;
       if (force_ns && v.wp * v.wn != 4 * force_ns) continue;
       if (force_wn && v.wn != force_wn) continue;
@@ -663,6 +665,24 @@ const ConvVariant* conv_pick(int W, int cin, int cout, bool want_stats, size_t* 
   return best;
 }
 
+// The choice for a LAUNCH: the width's choice, except that a launch whose 512-pixel tiles would leave most CUs without a
+// workgroup (the reference's batch of 32 windows: 128 -> 64 at 50 x 20 is 64 workgroups, each 55 us long) takes the 256-pixel
+// shape -- twice the workgroups at about half the time each.  (Measured at 35 windows; choosing smaller tiles for EVERY
+// shape below 200 workgroups was slower: 0.81 against 0.77 ms per step.)
+constexpr long kSmallLaunch = 192;
+const ConvVariant* conv_pick_launch(int B, int H, int W, int cin, int cout, bool want_stats, size_t* smem_out, int want_lbn = 0) {
+  const ConvVariant* v = conv_pick(W, cin, cout, want_stats, smem_out, want_lbn);
+  if (v && 32 * v->pb * v->wp == 512 && long(B) * ((long(H) * W + 511) / 512) < kSmallLaunch && !getenv("SEPT_CONV_NO_SMALL")) {
+    size_t s2 = 0;
+    const ConvVariant* u = conv_pick(W, cin, cout, want_stats, &s2, want_lbn, 256);
+    if (u) {
+      v = u;
+      *smem_out = s2;
+    }
+  }
+  return v;
+}
+
 struct ConvLbn {   // the BatchNorm block whose backward apply pass (LBN; g, sums set) or forward activation (LACT; g, sums
   const void* g;   // null) runs in the tile loader
   const float *sums, *mean, *invstd, *gamma, *beta, *drop;
@@ -677,7 +697,7 @@ int conv_launch(const char* who, const void* x, const void* wt, const float* bia
   SEPT_REQUIRE(x && wt && y, SEPT_ERR_INVALID, "%s: null argument", who);
   SEPT_REQUIRE(B <= 65528, SEPT_ERR_UNSUPPORTED, "%s: B=%d exceeds grid.y", who, B);
   size_t best_smem = 0;
-  const ConvVariant* best = conv_pick(W, cin, cout, stats != nullptr, &best_smem, lbn ? (lbn->g ? 1 : 2) : 0);
+  const ConvVariant* best = conv_pick_launch(B, H, W, cin, cout, stats != nullptr, &best_smem, lbn ? (lbn->g ? 1 : 2) : 0);
   SEPT_REQUIRE(best, SEPT_ERR_UNSUPPORTED,
                "%s: no kernel for cin=%d cout=%d W=%d (supported channel pairs: 32->64, "
                "64->128, 64->32, 128->64, 128->128; statistics form: see sept_conv5x5_stats_parts)", who, cin, cout, W);
@@ -730,7 +750,7 @@ extern "C" int sept_conv5x5_forward(const void* x, const void* wt, const float* 
 namespace {
 int conv_epilogue_parts(int B, int H, int W, int cin, int cout) {
   size_t smem = 0;
-  const ConvVariant* v = (B > 0 && H > 0 && W > 0) ? conv_pick(W, cin, cout, true, &smem) : nullptr;
+  const ConvVariant* v = (B > 0 && H > 0 && W > 0) ? conv_pick_launch(B, H, W, cin, cout, true, &smem) : nullptr;
   if (!v) return 0;
   const int mt = 32 * v->pb * v->wp;
   return B * ((H * W + mt - 1) / mt);
@@ -742,7 +762,7 @@ int conv_epilogue_parts(int B, int H, int W, int cin, int cout) {
 extern "C" int sept_conv5x5_bnapply_parts(int B, int H, int W, int cin, int cout, int want_sums) {
   if (cin <= cout || B <= 0 || H <= 0 || W <= 0 || H % 2 || W % 2) return 0;
   size_t smem = 0;
-  const ConvVariant* v = conv_pick(W, cin, cout, want_sums != 0, &smem, 1);
+  const ConvVariant* v = conv_pick_launch(B, H, W, cin, cout, want_sums != 0, &smem, 1);
   if (!v) return 0;
   if (!want_sums) return 1;
   const int mt = 32 * v->pb * v->wp;
@@ -766,7 +786,7 @@ extern "C" int sept_conv5x5_variant(int W, int cin, int cout, int want_stats, in
 extern "C" int sept_conv5x5_stats_parts(int B, int H, int W, int cin, int cout) {
   if (cin > cout) return 0;   // forward shapes only: the epilogue of a data-gradient shape forms BatchNorm BACKWARD sums
   size_t smem = 0;
-  const ConvVariant* v = (B > 0 && H > 0 && W > 0) ? conv_pick(W, cin, cout, true, &smem) : nullptr;
+  const ConvVariant* v = (B > 0 && H > 0 && W > 0) ? conv_pick_launch(B, H, W, cin, cout, true, &smem) : nullptr;
   if (!v) return 0;   // no statistics form for this shape
   const int mt = 32 * v->pb * v->wp;
   return B * ((H * W + mt - 1) / mt);
@@ -838,7 +858,7 @@ extern "C" int sept_conv5x5_dgrad_bnapply(const void* pre, const void* gpool, co
 extern "C" int sept_conv5x5_act_parts(int B, int H, int W, int cin, int cout, int want_stats) {
   if (cin > cout || B <= 0 || H <= 0 || W <= 0) return 0;
   size_t smem = 0;
-  const ConvVariant* v = conv_pick(W, cin, cout, want_stats != 0, &smem, 2);
+  const ConvVariant* v = conv_pick_launch(B, H, W, cin, cout, want_stats != 0, &smem, 2);
   if (!v) return 0;
   if (!want_stats) return 1;
   const int mt = 32 * v->pb * v->wp;
