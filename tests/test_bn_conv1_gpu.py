@@ -436,7 +436,8 @@ def test_dgrad_epilogue_sums_for_a_pool_first_block(B, H, W, cin, cout):
 
 @pytest.mark.parametrize("B,H,W,cin,cout,ep,drop", [
     (3, 100, 40, 64, 32, "ext", True), (2, 100, 40, 64, 32, None, False), (5, 50, 20, 128, 64, "pool", True),
-    (3, 50, 32, 128, 64, None, True), (2, 26, 12, 64, 32, "pool", False), (4, 100, 64, 64, 32, "ext", False)])
+    (3, 50, 32, 128, 64, None, True), (2, 26, 12, 64, 32, "pool", False), (4, 100, 64, 64, 32, "ext", False),
+    (26, 100, 40, 64, 32, "ext", True), (100, 50, 20, 128, 64, "pool", False)])   # (the last two: launches of >= 192 workgroups)
 def test_dgrad_with_the_batchnorm_apply_pass_in_its_loader(B, H, W, cin, cout, ep, drop):
     """sept_conv5x5_dgrad_bnapply (blocks 2 / 3 of a network without conv weight gradients): the data-gradient conv that forms
     the gradient of a BatchNorm + ReLU + MaxPool block's pre-activations in its tile loader, against the apply pass
@@ -504,7 +505,7 @@ def test_dgrad_with_the_batchnorm_apply_pass_in_its_loader(B, H, W, cin, cout, e
 
 
 @pytest.mark.parametrize("B,H,W,stats,drop", [(3, 100, 40, True, True), (2, 100, 64, True, False), (5, 50, 20, False, True),
-                                              (2, 26, 12, True, True), (1, 7, 5, False, False)])
+                                              (2, 26, 12, True, True), (1, 7, 5, False, False), (26, 100, 40, True, True)])
 def test_forward_conv_with_the_pool_first_activation_in_its_loader(B, H, W, stats, drop):
     """sept_conv5x5_forward_act (conv.5 behind a pool-first block 1 of a network without conv weight gradients): the
     activation dropscale * relu(bn(ext)) formed in the conv's tile loader, against sept_bn_relu_ext_forward followed by the

@@ -16,6 +16,8 @@ SHAPES = [  # (B, H, W, cin, cout)
     (2, 25, 10, 128, 128),   # deep model 4th conv
     (1, 7, 9, 32, 64),       # ragged: tile tail + tiny image
     (2, 33, 5, 64, 128),
+    # launches of >= 192 workgroups: the 512-pixel tile shapes the training step runs (smaller launches take half-size tiles)
+    (26, 100, 40, 32, 64), (100, 50, 20, 64, 128),
 ]
 
 
@@ -103,7 +105,8 @@ def test_conv_weight_gradient(B, H, W, cin, cout):
     assert torch.equal(dw, ops.conv5x5_backward_weight(x.cuda(), dy.cuda()).cpu())
 
 
-@pytest.mark.parametrize("B,H,W,cin,cout", [(9, 100, 40, 64, 32), (9, 50, 20, 128, 64), (3, 100, 64, 64, 32), (2, 51, 21, 128, 64)])
+@pytest.mark.parametrize("B,H,W,cin,cout", [(9, 100, 40, 64, 32), (9, 50, 20, 128, 64), (3, 100, 64, 64, 32), (2, 51, 21, 128, 64),
+                                           (26, 100, 40, 64, 32), (100, 50, 20, 128, 64)])   # (the last two: 512-pixel tiles)
 @pytest.mark.parametrize("drop", [False, True])
 def test_dgrad_conv_with_batchnorm_backward_sums(B, H, W, cin, cout, drop):
     """sept_conv5x5_dgrad_bnsums + sept_bn_relu_pool_backward_presummed against the separate data-gradient conv and
