@@ -486,6 +486,13 @@ def main():
         mel = {"kernel": plan.kernel_name, "batch": 256, "us_per_launch": round(us, 1), "bound": "hbm",
                "achieved_GBps": round(byts / us / 1e3, 1), "peak_GBps": HBM_PEAK / 1e9,
                "frac": round(byts / (us * 1e-6) / HBM_PEAK, 4), "algorithmic_bytes_per_clip": byts // 256}
+        # SURVEY.md section 8d's caveat, reported beside it: the kernel sits at the fp32 ridge (22 FLOP/B), so also its fp32
+        # rate -- FFT 5 (N/2) log2 N per frame + the sparse filterbank 2 nnz per frame -- against the 157.3 TF vector peak
+        import math
+        nnz = {80: 784, 128: 1581}.get(F, 10 * F)
+        fl = 256 * (1 + CLIP_L // HOP) * (5 * 400 * math.log2(800) + 2 * nnz)
+        mel.update({"algorithmic_fp32_flops_per_clip": round(fl / 256), "achieved_fp32_TFLOPs": round(fl / us / 1e6, 2),
+                    "fp32_frac_of_157.3TF": round(fl / (us * 1e-6) / 157.3e12, 4)})
 
     # the reference's own batch: 32 windows per step (training_cloak_with_grl.py:212) through the same captured
     # step -- BatchNorm statistics over 32 windows as in the reference, where the headline batches 7x more
