@@ -698,6 +698,9 @@ int conv_launch(const char* who, const void* x, const void* wt, const float* bia
   SEPT_REQUIRE(B <= 65528, SEPT_ERR_UNSUPPORTED, "%s: B=%d exceeds grid.y", who, B);
   size_t best_smem = 0;
   const ConvVariant* best = conv_pick_launch(B, H, W, cin, cout, stats != nullptr, &best_smem, lbn ? (lbn->g ? 1 : 2) : 0);
+  SEPT_REQUIRE(best || !lbn, SEPT_ERR_UNSUPPORTED,
+               "%s: no kernel form with this loader for cin=%d cout=%d at W=%d (sept_conv5x5_act_parts / sept_conv5x5_bnapply_parts "
+               "answer 0 for such shapes)", who, cin, cout, W);
   SEPT_REQUIRE(best, SEPT_ERR_UNSUPPORTED,
                "%s: no kernel for cin=%d cout=%d W=%d (supported channel pairs: 32->64, "
                "64->128, 64->32, 128->64, 128->128; statistics form: see sept_conv5x5_stats_parts)", who, cin, cout, W);

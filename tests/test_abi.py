@@ -75,3 +75,40 @@ def test_conv_tile_shapes_at_the_training_widths():
     assert _lib.lib.sept_conv5x5_bnapply_parts(224, 100, 40, 64, 32, 1) > 0 and _lib.lib.sept_conv5x5_bnapply_parts(224, 50, 20, 128, 64, 1) > 0
     assert _lib.lib.sept_conv5x5_act_parts(224, 100, 40, 32, 64, 1) > 0 and _lib.lib.sept_conv5x5_act_parts(224, 100, 40, 64, 128, 1) == 0
     assert _lib.lib.sept_conv5x5_bnapply_parts(224, 99, 40, 64, 32, 1) == 0          # odd height: no whole 2x2 windows
+
+
+def test_round3_entry_points_refuse_bad_arguments_without_a_gpu():
+    """Argument errors of the entry points added in round 3 come back as negative status + text before anything is launched
+    (no GPU here): null pointers, forward / data-gradient shapes mixed up, inconsistent epilogue arguments, odd heights."""
+    from sept_amd import _lib
+    L = _lib.lib
+    one = ctypes.c_void_p(16)      # a non-null pointer value that is never dereferenced on these paths
+    fz = ctypes.cast(one, ctypes.POINTER(ctypes.c_float)) if False else one
+    # sept_conv5x5_dgrad_bnapply: null argument
+    st = L.sept_conv5x5_dgrad_bnapply(None, one, one, one, one, one, one, None, one, one, None, None, None, None, None, None, None,
+                                      2, 100, 40, 64, 32, None)
+    assert st < 0 and b"sept_conv5x5_dgrad_bnapply" in L.sept_last_error()
+    # ... a forward shape (cin <= cout) is not a data-gradient launch
+    st = L.sept_conv5x5_dgrad_bnapply(one, one, one, one, one, one, one, None, one, one, None, None, None, None, None, None, None,
+                                      2, 100, 40, 32, 64, None)
+    assert st < 0 and b"data-gradient" in L.sept_last_error()
+    # ... an epilogue tensor without its partials buffer
+    st = L.sept_conv5x5_dgrad_bnapply(one, one, one, one, one, one, one, None, one, one, one, None, None, one, one, None, None,
+                                      2, 100, 40, 64, 32, None)
+    assert st < 0 and b"epilogue" in L.sept_last_error()
+    # ... an odd height has no whole 2x2 windows
+    st = L.sept_conv5x5_dgrad_bnapply(one, one, one, one, one, one, one, None, one, one, None, None, None, None, None, None, None,
+                                      2, 99, 40, 64, 32, None)
+    assert st < 0 and b"2x2" in L.sept_last_error()
+    # sept_conv5x5_forward_act: a data-gradient shape is refused; so is a null BatchNorm
+    st = L.sept_conv5x5_forward_act(one, one, one, one, one, None, one, None, one, None, 2, 100, 40, 64, 32, None)
+    assert st < 0 and b"forward" in L.sept_last_error()
+    st = L.sept_conv5x5_forward_act(one, None, one, one, one, None, one, None, one, None, 2, 100, 40, 32, 64, None)
+    assert st < 0 and b"null" in L.sept_last_error()
+    # the activation form exists for the conv behind block 1 only
+    st = L.sept_conv5x5_forward_act(one, one, one, one, one, None, one, None, one, None, 2, 50, 20, 64, 128, None)
+    assert st < 0 and b"no kernel form with this loader" in L.sept_last_error()
+    # size queries of shapes without a form answer 0 instead of failing
+    assert L.sept_conv5x5_act_parts(0, 100, 40, 32, 64, 1) == 0 and L.sept_conv5x5_bnapply_parts(2, 100, 40, 32, 64, 1) == 0
+    out = (ctypes.c_int * 6)()
+    assert L.sept_conv5x5_variant(0, 32, 64, 0, out) < 0 and L.sept_conv5x5_variant(40, 32, 64, 0, None) < 0
