@@ -16,9 +16,17 @@ closed-form weights into them and records their outputs/gradients; tests/test_or
 checks this restatement against those vectors.
 
 Differences from the reference that are deliberate and test-only:
-  * dropout masks and the cloak epsilon can be injected (``eps=``, ``drop=``) so that train
-    mode is reproducible across implementations; with nothing injected the modules behave
-    like the reference (torch RNG).
+  * the cloak epsilon can be injected (``cloak_noise.eps``) and so can every dropout mask of a
+    two_d_cnn_lstm-style network (``model.drop = {'drop2d': [(B, C) per conv block], 'rnn': (B, T, 2H),
+    'dense': (B, 128)}`` -- SCALE masks: 0 or 1 / (1 - p), i.e. what nn.Dropout multiplies by), so that train mode
+    is reproducible across implementations.  Dropout2d drops whole channels of a sample (mask (B, C));
+    nn.GRU / nn.LSTM apply their dropout to the output of every layer but the last (ATen RNN.cpp,
+    apply_layer_stack), so with an 'rnn' mask the two-layer module is run as two one-layer calls on the same
+    weights with the mask in between (`_rnn_layers`).  With nothing injected the modules behave like the
+    reference (torch RNG).  tests/golden/model_golden_step.npz pins this hook: tools/make_goldens_step.py
+    reads the masks the REFERENCE drew in a train-mode step (forward hooks on its Dropout modules; the
+    recurrent mask by replaying the generator state in front of its nn.GRU call) and records the reference's
+    outputs and gradients under them.
   * ``sim_bf16`` (set by ``simulate_bf16(model)``): the conv stack rounds to bf16 exactly where the HIP path
     stores bf16 -- conv weights of the 5x5 MFMA layers, the pre-BatchNorm conv outputs and the pooled block
     outputs in the forward pass, and the gradients of those two activation tensors in the backward pass -- so
@@ -148,6 +156,7 @@ class _TwoDBase(nn.Module):
         self.pred, self.att = pred, att
         self.deep = deep
         self.sim_bf16 = False
+        self.drop = None   # test hook: explicit dropout scale masks (see the header)
         self.rnn_input_size = int(128 * input_spec_size / 8)
         self.rnn_cell = _rnn_cell(rnn_cell)
         self.dropout = nn.Dropout(p=self.dropout_p)
@@ -177,29 +186,55 @@ class _TwoDBase(nn.Module):
         # nothing: weights stay at torch default init.
 
     # the trunk shared with the cloak wrappers (cloak_models.py:165-193)
-    def _conv_sim_bf16(self, x):
-        """self.conv with the HIP path's bf16 storage points (conv1 runs on split-bf16 operands ~ fp32)."""
+    def _injected(self, key):
+        return self.drop.get(key) if (self.training and self.drop is not None) else None
+
+    def _conv_blocks(self, x):
+        """self.conv block by block: with `sim_bf16` the HIP path's bf16 storage points (conv1 runs on split-bf16
+        operands ~ fp32); with an injected 'drop2d' list the Dropout2d modules are replaced by the given (B, C) masks."""
         mods = list(self.conv)
         if mods and isinstance(mods[0], GradientReversal):      # Sequential(GradientReversal, conv) of the GRL wrapper
             x, mods = mods[0](x), list(mods[1])
-        i, first = 0, True
+        sim, d2 = self.sim_bf16, self._injected("drop2d")
+        i, blk = 0, 0
         while i < len(mods):
             conv, bn, j = mods[i], mods[i + 1], i + 3           # Conv2d, BatchNorm2d, ReLU
-            w = conv.weight if first else _round_weight(conv.weight)
-            pre = _RoundBF16.apply(F.conv2d(x, w, conv.bias, padding=2))
-            y = F.relu(bn(pre))
+            w = _round_weight(conv.weight) if (sim and blk > 0) else conv.weight
+            pre = F.conv2d(x, w, conv.bias, padding=2)
+            y = F.relu(bn(_RoundBF16.apply(pre) if sim else pre))
             if isinstance(mods[j], nn.MaxPool2d):
                 y, j = mods[j](y), j + 1
-            x = _RoundBF16.apply(mods[j](y))                      # Dropout2d, then the stored block output
-            i, first = j + 1, False
+            y = mods[j](y) if d2 is None else y * d2[blk].to(y.dtype)[:, :, None, None]     # Dropout2d
+            x = _RoundBF16.apply(y) if sim else y               # the stored block output
+            i, blk = j + 1, blk + 1
+        return x
+
+    def _rnn_layers(self, x):
+        """self.rnn(x)[0]; with an injected 'rnn' mask: layer 0, the mask, layer 1 (what ATen does with its own draw)."""
+        m = self._injected("rnn")
+        if m is None:
+            return self.rnn(x)[0]
+        r = self.rnn
+        assert r.num_layers == 2 and r.bidirectional and r.batch_first
+        lstm = isinstance(r, nn.LSTM)
+        for layer in range(2):
+            flat = [getattr(r, f"{n}_l{layer}{sfx}") for sfx in ("", "_reverse")
+                    for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+            h0 = x.new_zeros(2, x.shape[0], r.hidden_size)
+            if lstm:
+                x = torch._VF.lstm(x, (h0, h0), flat, True, 1, 0.0, self.training, True, True)[0]
+            else:
+                x = torch._VF.gru(x, h0, flat, True, 1, 0.0, self.training, True, True)[0]
+            if layer == 0:
+                x = x * m.to(x.dtype)
         return x
 
     def features(self, x, global_feature=None, pooling="model"):
-        x = self._conv_sim_bf16(x.float()) if self.sim_bf16 else self.conv(x.float())
+        x = self._conv_blocks(x.float()) if (self.sim_bf16 or self._injected("drop2d") is not None) else self.conv(x.float())
         x = x.transpose(1, 2).contiguous()
         s = x.size()
         x = x.reshape(-1, s[1], s[2] * s[3])
-        x, _ = self.rnn(x)
+        x = self._rnn_layers(x)
         if self.att is None:
             flatten = self.deep if pooling == "model" else (pooling is None)
             z = x.reshape(-1, x.size(1) * x.size(2)) if flatten else torch.mean(x, dim=1)
@@ -208,7 +243,9 @@ class _TwoDBase(nn.Module):
             z = torch.mean(torch.matmul(torch.softmax(a, dim=2), x), dim=1)
         if global_feature is not None:
             z = torch.cat((z, global_feature), 1)
-        return self.dropout(self.dense_relu1(self.dense1(z)))
+        z = self.dense_relu1(self.dense1(z))
+        dm = self._injected("dense")
+        return self.dropout(z) if dm is None else z * dm.to(z.dtype)
 
     def head(self, z):
         if self.pred == "multitask":
@@ -339,6 +376,20 @@ def grl_step_loss(preds, preds_grl, labels_emo, labels_gen, weights, gender_lamb
     ce_g = F.cross_entropy(preds_grl, labels_gen.view(-1), reduction="none")
     w = weights if training else torch.ones_like(ce_e)
     total = (ce_e * w).sum() / B + float(gender_lambda) * (ce_g * w).sum() / B
+    if not suppression:
+        total = total - float(scale_lamda) * torch.log(torch.mean(cloak_model.intermed.scales()))
+    return total
+
+
+def syn_step_loss(preds, labels, weights, scale_lamda, cloak_model, training=True, suppression=False, combine=True):
+    """The loss of training_cloak.py:137-149 for two_d_cnn_lstm_syn.  `combine` (the args.dataset 'combine*' branch,
+    :138-147): sum_i w_i CE_i / B (w dropped in validate mode) - scale_lamda * log(mean(scales)) unless suppressing;
+    otherwise (:149) the plain mean cross-entropy of the batch."""
+    if not combine:
+        return F.cross_entropy(preds, labels.view(-1))
+    ce = F.cross_entropy(preds, labels.view(-1), reduction="none")
+    w = weights if (training and weights is not None) else torch.ones_like(ce)
+    total = (ce * w).sum() / preds.shape[0]
     if not suppression:
         total = total - float(scale_lamda) * torch.log(torch.mean(cloak_model.intermed.scales()))
     return total

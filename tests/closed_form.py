@@ -95,3 +95,21 @@ def closed_form_gfeat(B: int, n: int = 88) -> torch.Tensor:
 def closed_form_labels(B: int):
     i = torch.arange(B)
     return ((i * 3 + 1) % 4).view(B, 1), ((i * 5 + i // 3) % 2).view(B, 1), (1.0 + 0.25 * (i % 3)).float()
+
+
+def golden_masks(G, key: str, p: float = 0.2, device="cpu") -> dict:
+    """The dropout masks the REFERENCE drew in a recorded train-mode step (tools/make_goldens_step.py, bit-packed
+    under `key`, e.g. 'f80_grl_emo_') as the SCALE masks both the oracle (`model.drop`) and the HIP path
+    (`injected=`) take: {'drop2d': [(B, C)] per conv block, 'rnn': (B, T, 2H), 'dense': (B, 128)}, values 0 or 1/(1-p)."""
+    import numpy as np
+
+    def one(name):
+        shape = tuple(int(v) for v in G[key + name + "_shape"])
+        bits = np.unpackbits(G[key + name])[:int(np.prod(shape))].reshape(shape)
+        return (torch.from_numpy(bits.astype(np.float32)) / (1.0 - p)).to(device)
+
+    d2, i = [], 0
+    while f"{key}drop2d_{i}" in G:
+        d2.append(one(f"drop2d_{i}"))
+        i += 1
+    return {"drop2d": d2, "rnn": one("rnn"), "dense": one("dense")}

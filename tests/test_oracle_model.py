@@ -191,3 +191,96 @@ def test_oracle_attention_global_feature_multitask_vs_reference(GA):
         want = GA["grl_att_grad_" + name]
         np.testing.assert_allclose(g.reshape(-1)[:want.size].double().numpy(), want, rtol=2e-3,
                                    atol=2e-3 * float(GA["grl_att_gradnorm_" + name]) / want.size ** 0.5)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# train-mode steps with the reference's dropout ACTIVE (tests/golden/model_golden_step.npz, tools/make_goldens_step.py):
+# the masks the reference drew are read back from it and injected here (`model.drop`)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def GS(golden_dir):
+    return np.load(os.path.join(golden_dir, "model_golden_step.npz"))
+
+
+def _check_grads(GS, k, model):
+    np.testing.assert_allclose(model.intermed.locs.grad.reshape(-1)[:256].numpy(), GS[k + "grad_locs"], rtol=2e-3, atol=1e-8)
+    assert model.intermed.locs.grad.double().norm().item() == pytest.approx(float(GS[k + "grad_locs_norm"]), rel=1e-4)
+    np.testing.assert_allclose(model.intermed.rhos.grad.reshape(-1)[:256].numpy(), GS[k + "grad_rhos"], rtol=2e-3, atol=1e-9)
+    assert model.intermed.rhos.grad.double().norm().item() == pytest.approx(float(GS[k + "grad_rhos_norm"]), rel=1e-4)
+    if hasattr(model, "gender_model"):
+        sd = dict(model.gender_model.named_parameters())
+        n = 0
+        for key in GS.files:
+            if key.startswith(k + "gradnorm_"):
+                name = key[len(k + "gradnorm_"):]
+                assert sd[name].grad.double().norm().item() == pytest.approx(float(GS[key]), rel=1e-3), name
+                np.testing.assert_allclose(sd[name].grad.reshape(-1)[:128].numpy(), GS[k + "grad_" + name],
+                                           rtol=5e-3, atol=1e-6 * float(GS[key]) + 1e-9)
+                n += 1
+        assert n >= 20
+    assert all(p.grad is None for p in model.original_model.parameters())
+
+
+@pytest.mark.parametrize("F", [80, 128])
+def test_grl_train_step_with_the_reference_dropout_masks(F, GS):
+    """p = 0.2 in all five dropout sites of BOTH networks (the step the reference actually trains with): logits,
+    loss, gradients and BatchNorm running statistics of the oracle under the reference's own masks."""
+    from tests.closed_form import golden_masks
+    x = closed_form_input(B, W, F)
+    le, lg, wts = closed_form_labels(B)
+    grl = build_grl(F).train()
+    k = f"f{F}_grl_"
+    grl.original_model.drop = golden_masks(GS, k + "emo_")
+    grl.gender_model.drop = golden_masks(GS, k + "gen_")
+    assert abs(float(grl.gender_model.drop["rnn"].mean()) - 1.0) < 0.05           # ~ 80 % kept x 1.25
+    p1, p2, _ = grl(x, mask=None, grl=False, pooling="mean")
+    loss = mo.grl_step_loss(p1, p2, le, lg, wts, 0.1, 0.05, grl)
+    loss.backward()
+    np.testing.assert_allclose(p1.detach().numpy(), GS[k + "emo"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(p2.detach().numpy(), GS[k + "gen"], rtol=1e-4, atol=1e-5)
+    assert loss.item() == pytest.approx(float(GS[k + "loss"]), rel=1e-5)
+    _check_grads(GS, k, grl)
+    np.testing.assert_allclose(grl.original_model.conv[1].running_mean.numpy(), GS[k + "emo_bn1_running_mean"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(grl.original_model.conv[11].running_var.numpy(), GS[k + "emo_bn3_running_var"], rtol=1e-5)
+    np.testing.assert_allclose(grl.gender_model.conv[1][6].running_var.numpy(), GS[k + "gen_bn2_running_var"], rtol=1e-5)
+    # the hook has teeth: leaving ONE mask out moves the logits far outside the tolerance
+    grl.gender_model.drop = dict(grl.gender_model.drop, rnn=torch.full_like(grl.gender_model.drop["rnn"], 1.0))
+    with torch.no_grad():
+        _, q2, _ = grl(x, mask=None, grl=False, pooling="mean")
+    assert float((q2 - torch.from_numpy(GS[k + "gen"])).abs().max()) > 1e-2
+
+
+@pytest.mark.parametrize("F", [80, 128])
+@pytest.mark.parametrize("drop", [False, True])
+def test_syn_train_step(F, drop, GS):
+    """two_d_cnn_lstm_syn under the loss of training_cloak.py:139-147 (weighted CE - scale_lamda log mean scales):
+    predictions, loss, dL/dlocs, dL/drhos through the FROZEN emotion network, its BatchNorm running statistics."""
+    from tests.closed_form import golden_masks
+    x = closed_form_input(B, W, F)
+    le, lg, wts = closed_form_labels(B)
+    noise = mo.cloak_noise(torch.zeros(1, W, F), torch.ones(1, W, F), torch.tensor(0.01), torch.tensor(10.0), "cpu")
+    noise.load_state_dict(closed_form_state(noise, prefix="noise."))
+    noise.eps = closed_form_eps(W, F)
+    syn = mo.two_d_cnn_lstm_syn(mk(F, "emotion"), noise).train()
+    k = f"f{F}_syn_" if drop else f"f{F}_syn0_"
+    if drop:
+        syn.original_model.drop = golden_masks(GS, k + "emo_")
+    else:
+        zero_dropout(syn)
+    preds, noisy = syn(x, mask=None, pooling="mean")
+    loss = mo.syn_step_loss(preds, le, wts, 0.05, syn)
+    loss.backward()
+    np.testing.assert_allclose(preds.detach().numpy(), GS[k + "preds"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(noisy.reshape(-1)[:64].numpy(), GS[k + "noisy_slice"], rtol=1e-6)
+    assert loss.item() == pytest.approx(float(GS[k + "loss"]), rel=1e-5)
+    _check_grads(GS, k, syn)
+    np.testing.assert_allclose(syn.original_model.conv[1].running_mean.numpy(), GS[k + "emo_bn1_running_mean"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(syn.original_model.conv[6].running_var.numpy(), GS[k + "emo_bn2_running_var"], rtol=1e-5)
+    if not drop:    # the non-'combine' branch (:149): plain mean cross-entropy, no scale term
+        syn.zero_grad()
+        syn.original_model.load_state_dict(closed_form_state(syn.original_model, prefix="emotion."))
+        preds, _ = syn(x, mask=None, pooling="mean")
+        plain = mo.syn_step_loss(preds, le, None, 0.0, syn, combine=False)
+        plain.backward()
+        assert plain.item() == pytest.approx(float(GS[k + "plain_loss"]), rel=1e-5)
+        _check_grads(GS, k + "plain_", syn)
