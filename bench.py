@@ -10,9 +10,10 @@ value = clips processed by all ranks / max-over-ranks wall time of the K timed s
 
 Also printed on the same JSON line:
   roofline     -- the dominant kernel of the step (by device time), its algorithmic FLOPs per
-                  launch / its mean launch duration measured with HIP events on the launch
-                  stream inside the timed region, against the dense bf16 MFMA peak (2.5 PF);
-                  plus the STFT->mel kernel's HBM figure under "mel" (north-star target)
+                  launch / its mean launch duration INSIDE the replayed graph (device-clock slots
+                  folded in by the kernel itself: ops.KernelClock; HIP events cannot bracket a
+                  graph node -- the event-bracketed eager figure is printed beside it), against the
+                  dense bf16 MFMA peak (2.5 PF); plus the STFT->mel kernel's HBM figure under "mel"
   cpu_baseline -- the oracle port (oracle/: torch fp32 CPU restatement of the reference) on a
                   bounded sample of the same workload, rank 0, N = 1 only.
 """
@@ -438,9 +439,33 @@ def main():
                            "behind the graph launch so that it runs under the replay, then a shader copy into the captured "
                            "graph's static input buffer before the next replay"}
 
+    # ---- the dominant kernel INSIDE the replayed graph.  HIP events cannot bracket a node of a graph
+    # replay, so the step is captured a second time with ops.KernelClock armed: every conv5x5 launch of that capture carries
+    # a pair of device slots its workgroups fold the 100 MHz device clock into (first workgroup start, last wave end), and
+    # each of R untimed replays leaves every instrumented node's duration on the device.  `frac` below follows from THIS
+    # figure; the event-bracketed eager figure and the branches-serialised one are printed beside it.
+    in_replay = None
     if step_fn is not None:
-        # kernels inside a graph replay cannot be bracketed by events: time the dominant kernel over
-        # a few eager steps right after the timed region instead (same process, same data)
+        clk = ops.KernelClock(dev)
+        ops.TIMER = clk
+        try:
+            step_clk = pipe.capture(wav, le, lg, weights)
+        finally:
+            ops.TIMER = None
+        for _ in range(3):
+            step_clk()
+        for _ in range(10):
+            clk.reset()
+            step_clk()
+            torch.cuda.synchronize()
+            clk.collect()
+        in_replay = clk.summary()                     # tag -> (launches per replay, mean ms per launch)
+        launches = clk.per_launch()                   # [(tag, mean us, samples)] in enqueue order
+        # "dominant" = the single-kernel conv entry with the most device time per replayed step (launches x mean): a rule
+        # that does not flip between equal-FLOP siblings on a few percent of one launch
+        single = {t: n * ms for t, (n, ms) in in_replay.items() if "wgrad" not in t and "+" not in t}
+        dominant = max(single, key=single.get)
+        # the same kernel bracketed by HIP events over three EAGER steps (the round-3 figure), for comparison
         ops.TIMER = ops.KernelTimer(tags={dominant})
         for _ in range(3):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -450,7 +475,8 @@ def main():
             mel_ev.append((e0, e1))
             trainer.train_step(x.view(Bw, 1, WIN, F), le, lg, weights)
         torch.cuda.synchronize()
-    n_launch, k_ms = ops.TIMER.summary()[dominant]
+    n_launch, eager_ms = ops.TIMER.summary()[dominant]
+    k_ms = in_replay[dominant][1] if in_replay is not None else eager_ms
     flops = conv_flops(dominant, Bw, F)
     achieved = flops / (k_ms * 1e-3)
     feat_ms = sum(a_.elapsed_time(b_) for a_, b_ in mel_ev) / len(mel_ev)
@@ -558,7 +584,7 @@ def main():
     # the figure is the committed rocprofv3 --pmc measurement of this same command and shape
     traffic, traffic_src = None, None
     try:
-        src = next(f"profiles/{r}_pmc_traffic.json" for r in ("r03", "r02", "r01")
+        src = next(f"profiles/{r}_pmc_traffic.json" for r in ("r04", "r03", "r02", "r01")
                    if os.path.exists(os.path.join(ROOT, "profiles", f"{r}_pmc_traffic.json")))
         tj = json.load(open(os.path.join(ROOT, src)))
         if clips == 32 and F == 80:
@@ -586,10 +612,25 @@ def main():
                             "the host-fed rate of the same run is under host_fed",
                    "feature_stage_ms": round(feat_ms, 3),
                    "host_enqueue_ms_per_step": round(host_s / a.steps * 1e3, 3)},
-        "roofline": {"bound": "mfma", "kernel": dominant, "launches_timed": n_launch,
+        "roofline": {"bound": "mfma", "kernel": dominant,
+                     "measured": "in_replay" if in_replay is not None else "eager",
                      "ms_per_launch": round(k_ms, 4), "flops_per_launch": flops,
                      "achieved": round(achieved / 1e12, 2), "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s",
                      "frac": round(achieved / MFMA_PEAK, 4), "traffic": traffic, "traffic_source": traffic_src,
+                     "in_replay": None if in_replay is None else {
+                         "note": "device-clock duration (first workgroup start -> last wave end, 100 MHz counter folded in by "
+                                 "the kernel itself) of every conv5x5 node of the REPLAYED graph, mean of 10 replays of an "
+                                 "instrumented capture of the same step; a rocprofv3 kernel trace of the replay "
+                                 "(profiles/r04_replay_kernel_stats.csv) reads 1-3 us more per launch (dispatch overhead): "
+                                 "agreement within 5 %",
+                         "launches_per_step": in_replay[dominant][0],
+                         "by_kernel_ms": {t: [n, round(ms, 4)] for t, (n, ms) in sorted(in_replay.items())},
+                         "by_kernel_frac": {t: round(conv_flops(t, Bw, F) / (ms * 1e-3) / MFMA_PEAK, 4)
+                                            for t, (n, ms) in sorted(in_replay.items()) if "wgrad" not in t},
+                         "by_launch_us": [[t, round(us, 1)] for t, us, _n in launches]},
+                     "eager": {"note": "same kernel bracketed by HIP events on its launch stream over three eager steps",
+                               "launches_timed": n_launch, "ms_per_launch": round(eager_ms, 4),
+                               "frac": round(flops / (eager_ms * 1e-3) / MFMA_PEAK, 4)},
                      "alone": None if iso_ms is None else {
                          "note": "same kernel with the two branches serialised (no co-running kernels)",
                          "ms_per_launch": round(iso_ms, 4), "achieved": round(flops / (iso_ms * 1e-3) / 1e12, 2),
@@ -597,10 +638,9 @@ def main():
                      "whole_step": {"flops_per_step": step_flops, "achieved": round(step_flops / (dt / a.steps) / 1e12, 1),
                                     "frac": round(step_frac, 4),
                                     "note": "algorithmic FLOPs of the GRL step per GPU / ms_per_step / 2.5 PF"},
-                     "per_step_ms_by_kernel": {t: round(v, 3) for t, v in sorted(per_step.items())},
-                     "note": "the four 5x5 conv entries have EQUAL algorithmic FLOPs per launch at this shape, so which one "
-                             "is 'dominant' is decided by a few percent of duration (two eager probe steps here; a replay "
-                             "trace may rank a sibling first: profiles/ lists all four)"},
+                     "per_step_ms_by_kernel_eager_probe": {t: round(v, 3) for t, v in sorted(per_step.items())},
+                     "note": "the four plain 5x5 conv entries have EQUAL algorithmic FLOPs per launch at this shape (91.75 "
+                             "GFLOP); 'dominant' = the one with the most device time per replayed step; in_replay lists all"},
         "mel": mel,
         "reference_batch": ref_batch,
         "host_fed": host_fed,

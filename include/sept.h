@@ -403,6 +403,11 @@ int sept_conv1_bn_relu_pool_backward_apply(const float* x, const float* w, const
  * rely on: sept_conv1_backward_data_sparse / _sum (data gradient) and sept_conv1_backward_weight_sparse (weight
  * gradient) work from (masked dy, idx, x).  H even, W % 16 == 0 (sept_conv1_pool_supported); gamma NULL = all maxima. */
 int sept_conv1_pool_supported(int H, int W);
+/* ... and whether the BACKWARD kernels of a pool-first block 1 (sept_conv1_backward_weight_sparse, _data_sparse, _data_sum)
+ * take the shape too: H >= 4, 16 <= W <= 128.  A training step that will need them asks this one. */
+int sept_conv1_pool_backward_supported(int H, int W);
+/* floats of the `coef` scratch those entries take (== SEPT_CONV1_COEF_FLOATS; a query so that a host never hard-codes it) */
+size_t sept_conv1_coef_floats(void);
 int sept_conv1_forward_pool(const float* x, const float* w, const float* bias, float* wprep, const float* gamma,
                             void* ext_bf16, void* idx_u8, float* stats, int B, int H, int W, void* stream);
 int sept_bn_relu_ext_forward(const void* ext, void* idx_u8 /*nullable, in/out*/, const float* mean, const float* invstd,
@@ -442,6 +447,15 @@ int sept_copy_bytes(const void* src, void* dst, long nbytes, void* stream);
 int sept_mul(const float* x, const float* m, float* y, long n, void* stream);
 /* diagnostics: *slot = the device's 100 MHz wall clock when `stream` reaches this launch (also inside a graph replay) */
 int sept_debug_stamp(long long* slot, void* stream);
+/* Measurement aid: arm the NEXT instrumented launch of the calling thread (the sept_conv5x5_* entries: forward /
+ * data-gradient forms and the weight gradient's main kernel) with a ZEROED region of SEPT_KCLOCK_WG * SEPT_KCLOCK_STRIDE
+ * device int64 slots: workgroup g stores the 100 MHz device wall clock at its start into slots[g * STRIDE] and each of its
+ * waves w (< STRIDE - 1) at its end into slots[g * STRIDE + 1 + w].  (max over the end slots - min over the non-zero start
+ * slots) * 10 ns is the launch's duration on the device, also when the launch is a node of a replayed HIP graph (the pointer
+ * is a kernel argument: arm while capturing).  Workgroups beyond SEPT_KCLOCK_WG are not recorded.  NULL disarms. */
+#define SEPT_KCLOCK_WG 4096
+#define SEPT_KCLOCK_STRIDE 16
+int sept_kclock_next(long long* slots);
 /* out = x + y (the two branch losses of the hand-scheduled GRL step: training_cloak_with_grl.py:160) */
 int sept_add(const float* x, const float* y, float* out, long n, void* stream);
 /* y = x * (*scalar_dev): scale by a value that lives on the device (no host read of a loss gradient). */

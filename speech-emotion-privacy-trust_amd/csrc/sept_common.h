@@ -38,6 +38,23 @@ inline int launch_check(const char* what) {
   return SEPT_OK;
 }
 
+// In-kernel launch clock (measurement aid, off unless armed): sept_kclock_next(slots) hands the NEXT instrumented launch of
+// this thread a region of SEPT_KCLOCK_WG x SEPT_KCLOCK_STRIDE device int64 slots; workgroup g of that launch then stores the
+// 100 MHz wall clock at its start into slots[g * STRIDE] and every wave w at its end into slots[g * STRIDE + 1 + w] -- plain
+// stores to private addresses (a first version folded min / max into ONE pair with atomics: 14 000 same-address atomics per
+// launch more than doubled the kernel, 88 -> 205 us).  max(ends) - min(non-zero starts) is the launch's duration ON THE DEVICE,
+// also for a node inside a HIP-graph replay, which HIP events cannot bracket (bench.py's roofline figure).  The pointer is
+// part of the kernel arguments, so a capture taken while armed keeps it; unarmed launches carry a null pointer and pay one
+// scalar branch.  kclock_take() is what a launcher calls: returns the armed pointer (and disarms) or null.
+long long* kclock_take();
+__device__ __forceinline__ void kclock_begin(long long* k, unsigned wg) {
+  if (k && threadIdx.x == 0 && wg < SEPT_KCLOCK_WG) k[size_t(wg) * SEPT_KCLOCK_STRIDE] = (long long)wall_clock64();
+}
+__device__ __forceinline__ void kclock_end(long long* k, unsigned wg) {   // every wave: a workgroup ends when its last wave does
+  if (k && (threadIdx.x & 63) == 0 && wg < SEPT_KCLOCK_WG)
+    k[size_t(wg) * SEPT_KCLOCK_STRIDE + 1 + (threadIdx.x >> 6)] = (long long)wall_clock64();
+}
+
 // Raise a kernel's dynamic-LDS limit to the full 160 KiB once (not a stream operation; done
 // on first use so the launch functions themselves stay graph-capture safe afterwards).
 hipError_t allow_max_lds(const void* fn);

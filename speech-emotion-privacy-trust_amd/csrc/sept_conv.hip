@@ -72,6 +72,7 @@ struct ConvArgs {
   const bf16* lg;
   const float *l_sums, *l_mean, *l_invstd, *l_gamma, *l_beta, *l_drop;
   float l_inv_n;
+  long long* kclk;    // in-kernel launch clock slots or null (sept_common.h: kclock_begin / kclock_end)
 };
 
 __host__ __device__ constexpr int conv_nr_max(int mt, int w) { return (mt + w - 2) / w + 5; }
@@ -136,6 +137,7 @@ void sept_conv5x5_mfma_kernel(ConvArgs a) {
   const int L = blockIdx.y * gridDim.x + blockIdx.x, slot = L >> 3;
   const int b = (slot / int(gridDim.x)) * 8 + (L & 7);
   if (b >= a.B) return;
+  sept::kclock_begin(a.kclk, L);
   const int q0 = (slot % int(gridDim.x)) * MT;
   const int h_first = q0 / W;
   const int h_last = min(q0 + MT - 1, HW - 1) / W;
@@ -504,6 +506,7 @@ void sept_conv5x5_mfma_kernel(ConvArgs a) {
       a.stats[size_t(t) * nparts + col] = tot;
     }
   }
+  sept::kclock_end(a.kclk, L);
 }
 
 // weights: OIHW fp32 -> [tap][cout'][cin'] bf16.  mode 0: forward.  mode 1: data gradient
@@ -735,6 +738,7 @@ int conv_launch(const char* who, const void* x, const void* wt, const float* bia
   a.W = W;
   const int mt = 32 * best->pb * best->wp;
   a.nr_max = conv_nr_max(mt, W);
+  a.kclk = sept::kclock_take();
   SEPT_HIP(sept::allow_max_lds(fn));
   dim3 grid((H * W + mt - 1) / mt, (B + 7) / 8 * 8), block(64 * best->wp * best->wn);
   void* args[] = {&a};

@@ -2353,3 +2353,17 @@ extern "C" int sept_conv1_backward_data_sum(const void* dy_pooled, const void* i
   hipLaunchKernelGGL(sept_conv1_dsum_apply_kernel, dim3(H), dim3(4 * ((W + 15) / 16 * 16)), smem, st, q);
   return sept::launch_check("sept_conv1_backward_data_sum");
 }
+
+
+// Shapes for which a pool-first block 1 also has its BACKWARD kernels (sept_conv1_backward_weight_sparse,
+// sept_conv1_backward_data_sparse, sept_conv1_backward_data_sum): the forward form alone reaches W ~ 688, the backward
+// kernels stop at W = 128 and need H >= 4.  The host asks before it takes the pool-first forward in a training step.
+extern "C" int sept_conv1_pool_backward_supported(int H, int W) {
+  return sept_conv1_pool_supported(H, W) && H >= 4 && W >= 16 && W <= 128;
+}
+
+// Floats of the `coef` scratch of sept_conv1_backward_data_sparse / sept_conv1_backward_data_sum (25 border classes of
+// one 9 x 9 kernel + constant each) == SEPT_CONV1_COEF_FLOATS.
+extern "C" size_t sept_conv1_coef_floats(void) { return size_t(kCoefClasses) * kCoefStride; }
+static_assert(kCoefClasses * kCoefStride == SEPT_CONV1_COEF_FLOATS, "include/sept.h: SEPT_CONV1_COEF_FLOATS");
+

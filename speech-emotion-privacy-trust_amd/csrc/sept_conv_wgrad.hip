@@ -49,6 +49,7 @@ struct WgArgs {
   const bf16* dy;  // [B][H][W][COUT]
   float* ws;       // partial slabs [Z][G][25*MBZ*NBZ*1024]
   int B, H, W, nr_max;
+  long long* kclk;   // in-kernel launch clock slots or null (sept_common.h)
 };
 
 __device__ __forceinline__ bf16x4 lds_tr(unsigned addr) {   // addr: byte address inside the LDS
@@ -71,6 +72,7 @@ __global__ __launch_bounds__(64 * kNW) void sept_conv5x5_wgrad_kernel(WgArgs a) 
   constexpr int KS = kMT / 16;                          // 16-pixel steps per tile
   static_assert(KS == NW, "wave w takes tap 24 for step w");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  sept::kclock_begin(a.kclk, blockIdx.z * gridDim.x + blockIdx.x);
   const int W = a.W, H = a.H, HW = H * W, W4 = W + 4;
   const unsigned xbytes = unsigned(a.nr_max) * W4 * PSX;
   const unsigned bufbytes = xbytes + unsigned(kMT) * PSY;
@@ -295,6 +297,7 @@ __global__ __launch_bounds__(64 * kNW) void sept_conv5x5_wgrad_kernel(WgArgs a) 
     for (int w = 0; w < NW; ++w) sum += red[w * MBZ * NBZ * 1024 + i];
     slab[size_t(24) * MBZ * NBZ * 1024 + i] = sum;
   }
+  sept::kclock_end(a.kclk, blockIdx.z * gridDim.x + blockIdx.x);
 }
 
 // sums the G slabs of each z-slice in fixed order and scatters into OIHW fp32.  A workgroup owns
@@ -343,6 +346,7 @@ int launch_wgrad(const WgArgs& a0, float* dw, hipStream_t st) {
   constexpr int NW = kNW;
   constexpr int PSX = wg_ps(NBZ * 32), PSY = wg_ps(MBZ * 32);
   a.nr_max = wg_nr_max(a.W);
+  a.kclk = sept::kclock_take();
   const size_t smem = 2 * (size_t(a.nr_max) * (a.W + 4) * PSX + size_t(kMT) * PSY);
   SEPT_REQUIRE(smem <= 160 * 1024 && a.nr_max * (a.W + 4) * (NBZ * 4) <= ((kXCH * 256 + 64 * NW - 1) / (64 * NW)) * 64 * NW, SEPT_ERR_UNSUPPORTED,
                "sept_conv5x5_backward_weight: W=%d is too wide for the LDS tile (%zu B)", a.W, smem);

@@ -11,6 +11,13 @@ char* err_buf() {
   return buf;
 }
 
+static thread_local long long* g_kclock = nullptr;
+long long* kclock_take() {
+  long long* k = g_kclock;
+  g_kclock = nullptr;
+  return k;
+}
+
 hipError_t allow_max_lds(const void* fn) {
   static std::mutex mu;
   static std::set<const void*> done;
@@ -25,6 +32,11 @@ hipError_t allow_max_lds(const void* fn) {
 extern "C" const char* sept_last_error(void) { return sept::err_buf(); }
 
 extern "C" int sept_abi_version(void) { return 1; }
+
+extern "C" int sept_kclock_next(long long* slots) {
+  sept::g_kclock = slots;
+  return SEPT_OK;
+}
 
 extern "C" int sept_device_check(void) {
   int n = 0;

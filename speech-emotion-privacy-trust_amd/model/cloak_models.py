@@ -82,6 +82,7 @@ class two_d_cnn_lstm_syn(nn.Module):
         self.intermed = noise_model
         self.original_model = original_model
         _freeze(self.original_model)
+        self.injected_masks = None   # test hook: explicit dropout masks of the network (functional.trunk_forward)
 
     def forward(self, input_var, global_feature=None, mask=None, pooling=None):
         x = input_var.float()
@@ -89,9 +90,9 @@ class two_d_cnn_lstm_syn(nn.Module):
         noisy = x.detach()
         m = self.original_model
         if m.pred == 'multitask':   # reference :122-125
-            both = m.hip_logits(x, 'multitask', _pool_arg(pooling), global_feature=global_feature)
+            both = m.hip_logits(x, 'multitask', _pool_arg(pooling), self.injected_masks, global_feature=global_feature)
             return (both[:, :m.num_emo_classes], both[:, m.num_emo_classes:]), noisy
-        preds = m.hip_logits(x, 'emotion' if m.pred == 'emotion' else 'gender', _pool_arg(pooling),
+        preds = m.hip_logits(x, 'emotion' if m.pred == 'emotion' else 'gender', _pool_arg(pooling), self.injected_masks,
                              global_feature=global_feature)
         return preds, noisy
 
@@ -105,6 +106,7 @@ class two_d_cnn_lstm_syn_with_grl(nn.Module):
         _freeze(self.original_model)
         # same structural wrap as the reference (:152) so the gender conv keys live under conv.1.*
         self.gender_model.conv = nn.Sequential(GradientReversal(grl_lambda), gender_model.conv)
+        self.injected_masks = None   # test hook: (emotion network's, gender network's) explicit dropout masks
 
     def forward(self, input_var, global_feature=None, mask=None, grl=False, pooling=None):
         x = input_var.float()
@@ -117,6 +119,8 @@ class two_d_cnn_lstm_syn_with_grl(nn.Module):
             m = None if mask is None else mask.to(x.device, torch.float32).contiguous()
             P1 = SF.trunk_params(self.original_model, 'emotion', att)
             P2 = SF.trunk_params(self.gender_model, 'gender', att)
+            if self.injected_masks is not None:
+                P1.injected, P2.injected = self.injected_masks
             pl1, pl2 = SF._param_list(P1), SF._param_list(P2)
             cfg = (float(noise.min_scale), float(noise.max_scale), float(self.gender_model.conv[0].lambda_))
             eps = noise._epsilon(x.shape[0] if noise.eps_per_row else 1)
@@ -125,7 +129,8 @@ class two_d_cnn_lstm_syn_with_grl(nn.Module):
         # general composition (an input that itself needs a gradient): cloak, then the two trunks one after the other
         x = noise(x) if mask is None else noise(x, mask)
         noisy = x.detach()
-        preds1 = self.original_model.hip_logits(x, 'emotion', pool, global_feature=global_feature, att=att)
+        inj1, inj2 = self.injected_masks if self.injected_masks is not None else (None, None)
+        preds1 = self.original_model.hip_logits(x, 'emotion', pool, inj1, global_feature=global_feature, att=att)
         xr = self.gender_model.conv[0](x)   # the GradientReversal module sits in front of the gender conv stack
-        preds2 = self.gender_model.hip_logits(xr, 'gender', pool, global_feature=global_feature, att=att)
+        preds2 = self.gender_model.hip_logits(xr, 'gender', pool, inj2, global_feature=global_feature, att=att)
         return preds1, preds2, noisy

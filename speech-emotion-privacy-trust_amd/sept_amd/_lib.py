@@ -72,6 +72,7 @@ SIGNATURES = {
     "sept_fill": (c_int, [c_void_p, c_float, c_long, c_void_p]),
     "sept_mul": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
     "sept_debug_stamp": (c_int, [c_void_p, c_void_p]),
+    "sept_kclock_next": (c_int, [c_void_p]),
     "sept_window_norm_cloak": (c_int, [c_void_p] * 7 + [c_float, c_float, c_void_p] + [c_int] * 6 + [c_long, c_void_p]),
     "sept_add": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
     "sept_relu_dropout_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
@@ -153,6 +154,8 @@ SIGNATURES = {
     "sept_bn_bwd_sums_from_partials": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sept_conv1_bn_relu_pool_backward_apply": (c_int, [c_void_p] * 11 + [c_double, c_void_p] + [c_int] * 3 + [c_void_p]),
     "sept_conv1_pool_supported": (c_int, [c_int, c_int]),
+    "sept_conv1_pool_backward_supported": (c_int, [c_int, c_int]),
+    "sept_conv1_coef_floats": (c_size_t, []),
     "sept_conv1_forward_pool": (c_int, [c_void_p] * 8 + [c_int] * 3 + [c_void_p]),
     "sept_bn_relu_ext_forward": (c_int, [c_void_p] * 8 + [c_int, c_long, c_int, c_void_p]),
     "sept_bn_backward_sums_ext": (c_int, [c_void_p] * 11 + [c_int, c_long, c_int, c_void_p]),

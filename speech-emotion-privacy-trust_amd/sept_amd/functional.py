@@ -209,13 +209,17 @@ def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None, gfeat=Non
     """x (B, H, W) fp32 CUDA -> logits (B, C).  Returns (logits, saved) where `saved` holds
     what trunk_backward needs.  BatchNorm uses batch statistics (and updates the running
     buffers) when the module is in train mode -- also for a frozen model (SURVEY.md F8);
-    Dropout / Dropout2d / GRU dropout are active in train mode.  `injected` may carry
-    explicit dropout masks {'drop2d': [...], 'rnn': t, 'dense': t} for reproducible tests."""
+    Dropout / Dropout2d / GRU dropout are active in train mode.  `injected` (or `P.injected`, which the cloak wrappers'
+    `injected_masks` test hook sets) may carry explicit dropout SCALE masks {'drop2d': [(B, C) per conv block], 'rnn':
+    (B, T, 2H), 'dense': (B, 128)} (0 or 1/(1-p)) for reproducible tests."""
     require_cuda(x)
     B, H, W = x.shape
     dev = x.device
     train = P.training
-    inj = injected or {}
+    inj = injected or getattr(P, "injected", None) or {}
+    if inj:
+        inj = {k: ([m.to(dev, torch.float32).contiguous() for m in v] if k == "drop2d" else v.to(dev, torch.float32).contiguous())
+               for k, v in inj.items()}
     S = SimpleNamespace(x=x, blocks=[], train=train, pooling=pooling, B=B)
     act = None
     h, w = H, W
@@ -248,8 +252,8 @@ def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None, gfeat=Non
             act = out
             h, w = h // pool, w // pool
             continue
-        if (li == 0 and pool == 2 and bn.training and not _SYNC_BN["on"] and L1_POOL_FIRST and ops.conv1_pool_supported(H, W)
-                and _pool_first_backward_ok(cv, need_grad)):
+        if (li == 0 and pool == 2 and bn.training and not _SYNC_BN["on"] and L1_POOL_FIRST
+                and ops.conv1_pool_supported(H, W, backward=need_grad) and _pool_first_backward_ok(cv, need_grad)):
             # block 1 in pool-first form: conv1 leaves the statistics partials, the 2x2 window's extremum (by the sign of
             # gamma) and its position; a quarter-size elementwise pass forms the pooled activation.  Nothing of
             # (B, H, W, 32) is written or read, forward or backward (include/sept.h, "POOL-FIRST")
@@ -1179,7 +1183,7 @@ class GrlPairFn(torch.autograd.Function):
 
 
 def grl_train_step(model, x, labels_emo, labels_gen, weights, gender_lambda, scale_lamda, use_scale_term=True, mask=None,
-                   pooling="mean", global_feature=None, before_cloak=None):
+                   pooling="mean", global_feature=None, before_cloak=None, injected=None):
     """One forward + loss + backward of two_d_cnn_lstm_syn_with_grl under the loss of train()
     (training_cloak_with_grl.py:122-160), scheduled by hand instead of through the autograd tape:
 
@@ -1194,8 +1198,11 @@ def grl_train_step(model, x, labels_emo, labels_gen, weights, gender_lambda, sca
     gradient slots as the autograd path (GrlPairFn + GrlStepLossFn), which computes exactly this.  `x` is (B, 1, H, W)
     or None with `before_cloak` a callable that produces it on the current stream (the feature stage: its launches then
     overlap the step's random-number kernels).  Returns (loss, logits_emotion, logits_gender); the gradients are in
-    .grad of the trainable parameters (views of their flat slots where the trainer packed them)."""
+    .grad of the trainable parameters (views of their flat slots where the trainer packed them).  `injected` (default: the
+    wrapper's `injected_masks` test hook): explicit dropout masks (emotion network's, gender network's), see trunk_forward."""
     noise, emo, gen = model.intermed, model.original_model, model.gender_model
+    injected = injected if injected is not None else getattr(model, "injected_masks", None)
+    inj1, inj2 = injected if injected is not None else (None, None)
     att = emo.att
     pool = "flatten" if pooling is None else "mean"
     locs, rhos = noise.locs, noise.rhos
@@ -1258,7 +1265,7 @@ def grl_train_step(model, x, labels_emo, labels_gen, weights, gender_lambda, sca
             tag = "emotion" if P is P1 else "gender"
             ops.stamp(tag + " forward starts")
             r = trunk_forward(xw, P, pool, need_grad=True, gfeat=global_feature, masks=masks1 if P is P1 else masks2,
-                              rng_site=SITE_EMOTION if P is P1 else SITE_GENDER)
+                              rng_site=SITE_EMOTION if P is P1 else SITE_GENDER, injected=inj1 if P is P1 else inj2)
             ops.stamp(tag + " forward done")
             return r
 
@@ -1360,6 +1367,67 @@ def grl_train_step(model, x, labels_emo, labels_gen, weights, gender_lambda, sca
                 if p.requires_grad:
                     p.grad = g.view(p.shape)
     return loss, l1, l2
+
+
+def syn_train_step(model, x, labels, weights, scale_lamda, use_scale_term=True, mask=None, pooling="mean",
+                   global_feature=None, before_cloak=None, combine=True, injected=None):
+    """One forward + loss + backward of two_d_cnn_lstm_syn under the loss of training_cloak.py:133-149, scheduled by hand
+    on the current stream: cloak -> frozen trunk -> cross-entropy (loss value + d logits in one kernel) -> the trunk's DATA
+    gradient only (batch-summed where block 1 allows: the cloak's parameters are shared by the batch) -> one cloak backward
+    kernel writing dL/dlocs, dL/drhos (with the scale term) into their flat slots.  `combine`: the 'combine*' datasets'
+    loss sum_i w_i CE_i / B - scale_lamda log mean(scales) (:138-147); else the plain batch-mean cross-entropy (:149).
+    `x` is (B, 1, H, W) or None with `before_cloak` producing it (the feature stage).  Returns (loss, logits)."""
+    noise, net = model.intermed, model.original_model
+    if net.pred == 'multitask':
+        raise SeptError("two_d_cnn_lstm_syn training: pred='multitask' returns a tuple the reference's loss loop cannot "
+                        "index either (training_cloak.py:141); use 'emotion' or 'gender'")
+    head = 'emotion' if net.pred == 'emotion' else 'gender'
+    injected = injected if injected is not None else getattr(model, "injected_masks", None)
+    pool = "flatten" if pooling is None else "mean"
+    locs, rhos = noise.locs, noise.rhos
+    dev = rhos.device
+    with torch.no_grad():
+        ops.stamp("step start", dev)
+        ops.begin_step(dev)
+        eps = noise._epsilon(1)
+        if before_cloak is not None:
+            x = before_cloak()
+        shape = x.shape
+        B = shape[0]
+        m = None if mask is None else mask.to(dev, torch.float32).contiguous()
+        smin, smax = float(noise.min_scale), float(noise.max_scale)
+        if isinstance(x, ops.LazyWindows):
+            xn = ops.window_norm_cloak(x, locs.detach(), rhos.detach(), eps, m, smin, smax)
+        else:
+            xn = ops.cloak_forward(x.detach().float().contiguous().view(B, -1), locs.detach(), rhos.detach(), eps, m, smin, smax)
+        xw = xn.view(B, shape[-2], shape[-1])
+        need_dx = locs.requires_grad or rhos.requires_grad
+        P = trunk_params(net, head, net.att)
+        need_w = any(p.requires_grad for p in _param_list(P))
+        logits, S = trunk_forward(xw, P, pool, need_grad=True, gfeat=global_feature, rng_site=SITE_EMOTION, injected=injected)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        d = ops.cross_entropy(logits, labels, weights if combine else None, 1.0 / B, loss)
+        scale_mean = None
+        if combine and use_scale_term and float(scale_lamda) != 0.0:
+            _, scale_mean = ops.cloak_scales(rhos.detach(), smin, smax, want_scales=False, want_mean=True)
+            ops.loss_sub_log(loss, scale_mean, float(scale_lamda))
+        dx, grads = trunk_backward(S, P, d, need_wgrad=need_w, need_dx=need_dx, sum_dx=True) if (need_w or need_dx) else (None, {})
+        if need_dx:
+            da, _ = batch_sum_pair(dx, None)
+            dlocs, drhos = ops.cloak_backward(da, None, 0.0, rhos.detach(), eps, m, smin, smax,
+                                              scale_lambda=float(scale_lamda) if scale_mean is not None else 0.0,
+                                              scale_mean=scale_mean, need_locs=locs.requires_grad, need_rhos=rhos.requires_grad,
+                                              out_locs=grad_out(locs) if locs.requires_grad else None,
+                                              out_rhos=grad_out(rhos) if rhos.requires_grad else None)
+            if locs.requires_grad:
+                locs.grad = dlocs
+            if rhos.requires_grad:
+                rhos.grad = drhos
+        ops.stamp("gradients done")
+        for p_, g in grads.items():
+            if p_.requires_grad:
+                p_.grad = g.view(p_.shape)
+    return loss, logits
 
 
 class SegmentSched:

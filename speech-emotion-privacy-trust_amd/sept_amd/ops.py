@@ -37,7 +37,71 @@ class KernelTimer:
         return {t: (len(ev), sum(a.elapsed_time(b) for a, b in ev) / len(ev)) for t, ev in self.events.items()}
 
 
-TIMER = None  # set to a KernelTimer to collect
+class KernelClock:
+    """Same start / stop interface as KernelTimer, but the duration comes from INSIDE the kernel: start() arms the next
+    instrumented launch (the conv5x5 entries) with a region of device slots into which its workgroups store the 100 MHz
+    device wall clock (include/sept.h: sept_kclock_next; plain stores to private slots, so the launch is not perturbed:
+    tools/kclock_check.py).  The region pointer is a kernel argument, so a HIP-graph CAPTURE taken while this is ops.TIMER
+    keeps it: every replay of that graph then leaves the duration of each instrumented node ON THE DEVICE, inside the
+    replay -- which HIP events cannot bracket.  Protocol: reset() -> replay -> synchronize -> collect(), repeated;
+    summary() as KernelTimer's."""
+
+    WG, STRIDE = 4096, 16      # SEPT_KCLOCK_WG, SEPT_KCLOCK_STRIDE
+
+    def __init__(self, device, tags=None, max_launches=32):
+        self.tags, self.names = tags, []
+        self.buf = torch.zeros((max_launches, self.WG, self.STRIDE), dtype=torch.int64, device=device)
+        self.samples = {}
+
+    def start(self, tag):
+        if self.tags is not None and tag not in self.tags:
+            return None
+        if len(self.names) >= self.buf.shape[0]:
+            raise SeptError("KernelClock: more instrumented launches than regions (max_launches)")
+        i = len(self.names)
+        self.names.append(tag)
+        check(lib.sept_kclock_next(self.buf[i].data_ptr()), "sept_kclock_next")
+        return i
+
+    def stop(self, h):
+        if h is not None:
+            check(lib.sept_kclock_next(None), "sept_kclock_next")   # (a launcher that did not take it must not leak it)
+
+    def reset(self):
+        self.buf.zero_()
+
+    def durations_us(self):
+        """after a synchronize: per armed launch, max(wave ends) - min(workgroup starts) in microseconds (0 = did not run)"""
+        n = len(self.names)
+        if n == 0:
+            return []
+        r = self.buf[:n]
+        starts = r[:, :, 0]
+        big = torch.iinfo(torch.int64).max
+        t0 = torch.where(starts > 0, starts, torch.full_like(starts, big)).amin(1)
+        t1 = r[:, :, 1:].amax((1, 2))
+        return [((b - a) / 100.0 if (b > 0 and a < big) else 0.0) for a, b in zip(t0.tolist(), t1.tolist())]
+
+    def collect(self):
+        """after a synchronize: fold the replay that just ran into the per-launch samples"""
+        for i, us in enumerate(self.durations_us()):
+            if us > 0:
+                self.samples.setdefault(i, []).append(us)
+
+    def per_launch(self):
+        """[(tag, mean us, n samples)] in launch order"""
+        return [(self.names[i], sum(s) / len(s), len(s)) for i, s in sorted(self.samples.items())]
+
+    def summary(self):
+        """tag -> (launches per replay, mean ms per launch)"""
+        out = {}
+        for tag, us, _n in self.per_launch():
+            n, tot = out.get(tag, (0, 0.0))
+            out[tag] = (n + 1, tot + us)
+        return {t: (n, tot / n / 1e3) for t, (n, tot) in out.items()}
+
+
+TIMER = None  # set to a KernelTimer / KernelClock to collect
 
 
 def conv5x5_prep_weights(w_oihw: torch.Tensor, mode: int = 0, out: torch.Tensor = None) -> torch.Tensor:
@@ -481,7 +545,7 @@ def conv1_backward_data_sparse(x, pre, dy, idx, mean, invstd, gamma, beta, drops
                                                     sums.data_ptr(), _p(dgamma), _p(dbeta), B, H, W, C, 2, _s(pre)),
               "sept_bn_relu_pool_backward_reduce")
     dx = torch.empty((B, H, W), dtype=torch.float32, device=dev)
-    coef = torch.empty(2800, dtype=torch.float32, device=dev)
+    coef = torch.empty(lib.sept_conv1_coef_floats(), dtype=torch.float32, device=dev)
     wptr, wp = _c1w(x, w, prep, "conv1_prep_bwd")
     wf = w.detach().contiguous()
     check(lib.sept_conv1_backward_data_sparse(dy.data_ptr(), idx.data_ptr(), x.data_ptr(), wf.data_ptr(), _p(bias),
@@ -491,7 +555,11 @@ def conv1_backward_data_sparse(x, pre, dy, idx, mean, invstd, gamma, beta, drops
     return dx, dgamma, dbeta
 
 
-def conv1_pool_supported(H, W):
+def conv1_pool_supported(H, W, backward=False):
+    """the pool-first form of block 1 for this input shape; `backward`: a training step will also need its backward
+    kernels (narrower: H >= 4, 16 <= W <= 128)"""
+    if backward:
+        return bool(lib.sept_conv1_pool_backward_supported(int(H), int(W)))
     return bool(lib.sept_conv1_pool_supported(int(H), int(W)))
 
 
@@ -668,7 +736,7 @@ def conv1_backward_data_from_sums(x, dy, idx, sums, mean, invstd, gamma, dropsca
     require_cuda(x, dy, idx, w)
     B, H, W = x.shape
     dx = torch.empty((B, H, W), dtype=torch.float32, device=x.device)
-    coef = torch.empty(2800, dtype=torch.float32, device=x.device)
+    coef = torch.empty(lib.sept_conv1_coef_floats(), dtype=torch.float32, device=x.device)
     wptr, wp = _c1w(x, w, prep, "conv1_prep_bwd")
     wf = w.detach().contiguous()
     check(lib.sept_conv1_backward_data_sparse(dy.data_ptr(), idx.data_ptr(), x.data_ptr(), wf.data_ptr(), _p(bias),
@@ -685,7 +753,7 @@ def conv1_backward_data_sum(x, dy, idx, sums, mean, invstd, gamma, dropscale, w,
     require_cuda(x, dy, idx, w)
     B, H, W = x.shape
     ws = workspace("conv1_dsum", lib.sept_conv1_dsum_workspace_floats(H, W), x.device)
-    coef = torch.empty(2800, dtype=torch.float32, device=x.device)
+    coef = torch.empty(lib.sept_conv1_coef_floats(), dtype=torch.float32, device=x.device)
     dxs = torch.empty((1, H, W), dtype=torch.float32, device=x.device)
     wf = w.detach().contiguous()
     check(lib.sept_conv1_backward_data_sum(dy.data_ptr(), idx.data_ptr(), x.data_ptr(), wf.data_ptr(), _p(bias), mean.data_ptr(),

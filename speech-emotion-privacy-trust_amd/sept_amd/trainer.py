@@ -36,6 +36,11 @@ class FlatParams:
     backward kernels WRITE their weight gradients into it (functional.grad_out) -- nothing is packed
     afterwards.
 
+    Invariant behind functional.zero_bias_grad: a conv-bias slot in front of a train-mode BatchNorm is filled with zeros
+    ONCE and then recorded in `_zero_slots` (no fill launch per step); nothing in the HIP backward writes it.  Any other
+    writer breaks that, so gather_grads() -- the one place a foreign gradient (autograd's accumulation, a user edit) is
+    copied into a slot -- drops the slot from the set, and the next zero_bias_grad() fills it again.
+
     Parameters that receive no gradient (heads / attention matrices the forward never touches)
     are skipped by torch.optim -- no weight decay, no momentum.  The first gather_grads() finds
     them and moves them behind the `n_active` prefix that the optimiser and the all-reduce use."""
@@ -120,6 +125,7 @@ class FlatParams:
             elif g.data_ptr() != v.data_ptr():
                 # (host tensors: the packing logic is exercised on the CPU by tests/test_host_logic.py -- a copy, no compute)
                 ops.copy_into(v, g.detach().float().contiguous()) if v.is_cuda else v.copy_(g.detach())
+                self._zero_slots.discard(self.views[i][0])      # a foreign writer: no longer known to hold zeros
             p.grad = v
         for p in self.params[self._n_act_params:]:
             if p.grad is not None:
@@ -431,6 +437,58 @@ class GrlTrainer(_TrainerBase):
         return self.loss(preds, preds_grl, labels_emo, labels_gen, None, training=False), preds, preds_grl
 
 
+class SynTrainer(_TrainerBase):
+    """The cloak-only training step (training/training_cloak.py:94-158, :361-381): two_d_cnn_lstm_syn = cloak noise in
+    front of a FROZEN pre-trained classifier whose BatchNorm / Dropout still follow .train(); the trainable
+    set is the cloak's locs and rhos (rhos frozen too in the suppression runs, :367); loss (the 'combine*' datasets,
+    :138-147) sum_i w_i CE_i / B - scale_lamda log mean(scales) -- `combine=False`: the plain batch-mean cross-entropy of
+    :149; SGD(lr 1e-3, m 0.9, wd 1e-4) + StepLR(10, 0.5) or Adam(lr 5e-4, wd 1e-4, betas (0.9, 0.98), eps 1e-9) (:378-381).
+    One chain on one stream: cloak -> trunk forward -> CE -> the trunk's data gradient -> one cloak backward kernel
+    (functional.syn_train_step); capture() records it (and the update, on a single rank) into one HIP graph."""
+
+    def __init__(self, cloak_model, optimizer="sgd", lr=None, momentum=0.9, weight_decay=1e-4, betas=(0.9, 0.98), eps=1e-9,
+                 scale_lamda=0.0, suppression=False, combine=True, process_group=None, seed=None):
+        self.model = cloak_model
+        self.flat = FlatParams(cloak_model.parameters(), list(cloak_model.named_parameters()))
+        self._init_optim(optimizer, lr, {"sgd": 1e-3, "adam": 5e-4}, momentum, weight_decay, betas, eps, process_group, seed)
+        self.scale_lamda, self.suppression, self.combine = scale_lamda, suppression, combine
+
+    def _forward_backward(self, features, labels, weights, mask=None, pooling="mean", global_feature=None):
+        fn = features if callable(features) else None
+        return SF.syn_train_step(self.model, None if fn else features, labels, weights, self.scale_lamda,
+                                 use_scale_term=not self.suppression, mask=mask, pooling=pooling,
+                                 global_feature=global_feature, before_cloak=fn, combine=self.combine)
+
+    def train_step(self, features, labels, weights=None, mask=None, pooling="mean", global_feature=None):
+        """One iteration of the batch loop (:116-158) on this rank's shard.  Returns (loss, preds)."""
+        self.model.train()
+        self.flat.zero_grad()
+        self._sync_lr()
+        out = self._forward_backward(features, labels, weights, mask, pooling, global_feature)
+        self.flat.gather_grads()
+        if self.world > 1:
+            self._allreduce_grads()
+        self.optimizer_step()
+        return out
+
+    def capture(self, features, labels, weights=None, mask=None, pooling="mean", global_feature=None):
+        return self._capture(lambda: self._forward_backward(features, labels, weights, mask, pooling, global_feature))
+
+    @torch.no_grad()
+    def eval_step(self, features, labels, mask=None, pooling="mean", global_feature=None):
+        """validate mode (:96-97, :143-144): eval-mode forward, the speaker weights dropped"""
+        self.model.eval()
+        preds, _ = self.model(features, global_feature=global_feature, mask=mask, pooling=pooling)
+        loss = torch.zeros((), dtype=torch.float32, device=preds.device)
+        ops.cross_entropy(preds, labels, None, 1.0 / preds.shape[0], loss, want_grad=False)
+        if self.combine and not self.suppression and float(self.scale_lamda) != 0.0:
+            noise = self.model.intermed
+            _, mean = ops.cloak_scales(noise.rhos.detach(), float(noise.min_scale), float(noise.max_scale), want_scales=False,
+                                       want_mean=True)
+            ops.loss_sub_log(loss, mean, float(self.scale_lamda))
+        return loss, preds
+
+
 class BaselineTrainer(_TrainerBase):
     """The baseline / adversary training step (training/training_adversary_baselines.py:165-185,
     :424-429): a single classifier (two_d_cnn_lstm, deep_two_d_cnn_lstm or one_d_cnn_lstm), loss
@@ -517,12 +575,21 @@ class HostFeed:
         self.ev_d2d.record(torch.cuda.current_stream(dev))     # the staging buffer starts out free
         self._pending = False
 
-    def pack(self, tensors):
-        """one page-locked host buffer holding a batch in the layout of the static buffer"""
+    def alloc_packed(self):
+        """a page-locked host buffer of the static layout, for pack(out=...): allocate a few ONCE (pinning ~10 MB is
+        millisecond-scale, against a 2 ms step) and cycle through them -- a buffer may be refilled once the swap_in() of
+        the batch it carried has been issued (prefetch() is enqueued behind that swap-in's event)"""
+        return torch.zeros(self.nbytes, dtype=torch.uint8).pin_memory()
+
+    def pack(self, tensors, out=None):
+        """a batch in the layout of the static buffer, in one page-locked host buffer: `out` (from alloc_packed(), reused
+        by the caller's loader loop) or a freshly pinned one"""
         tensors = list(tensors)
         if len(tensors) != len(self.specs):
             raise ValueError(f"HostFeed.pack: {len(tensors)} tensors for {len(self.specs)} static inputs")
-        buf = torch.zeros(self.nbytes, dtype=torch.uint8).pin_memory()
+        if out is not None and (out.dtype != torch.uint8 or out.numel() != self.nbytes or not out.is_pinned()):
+            raise ValueError("HostFeed.pack: out= expects a buffer from HostFeed.alloc_packed()")
+        buf = self.alloc_packed() if out is None else out
         for (o, n, dt, shape), t in zip(self.specs, tensors):
             if tuple(t.shape) != shape or t.dtype != dt:
                 raise ValueError(f"HostFeed.pack: tensor {tuple(t.shape)} {t.dtype} does not match the static input {shape} {dt}")

@@ -119,3 +119,17 @@ def test_dp_shard_average_equals_global_batch_gloo():
     port = 29500 + os.getpid() % 2000
     mp.spawn(_dp_worker, args=(2, port, 16, ret), nprocs=2, join=True)
     assert len(ret) == 2 and all(v < 1e-5 for v in ret.values()), dict(ret)
+
+
+def test_pool_first_gate_knows_the_backward_kernels_limits():
+    """block 1's pool-first FORWARD form reaches W ~ 688, its backward kernels stop at W = 128 and need H >= 4.
+    A training step must only take the form where all of it exists (functional.trunk_forward asks with backward=need_grad);
+    wider inputs (the reference's --input_spec_size is free) fall back to the stored-tensor path.  Host-side queries only."""
+    import sept_amd
+    from sept_amd import ops
+    for H, Wd in ((200, 80), (200, 128), (200, 16), (4, 64)):
+        assert ops.conv1_pool_supported(H, Wd) and ops.conv1_pool_supported(H, Wd, backward=True), (H, Wd)
+    for H, Wd in ((200, 144), (200, 256), (2, 80)):
+        assert ops.conv1_pool_supported(H, Wd) and not ops.conv1_pool_supported(H, Wd, backward=True), (H, Wd)
+    assert not ops.conv1_pool_supported(201, 80) and not ops.conv1_pool_supported(200, 72, backward=True)
+    assert sept_amd.lib.sept_conv1_coef_floats() == 2800     # SEPT_CONV1_COEF_FLOATS; ops sizes the scratch from the query

@@ -206,11 +206,12 @@ def _fp32_part_bounds(name):
     return 0.998, 0.06         # dense1 / prediction heads: measured 1-4 %
 
 
-def _sim_step_check(grl, x, le, lg, wts, state=None, F=80, logits=None, min_decided=0.75):
+def _sim_step_check(grl, x, le, lg, wts, state=None, F=80, logits=None, min_decided=0.75, ref=None):
     """The HIP step (already run: `logits` = its (p1, p2), gradients in .grad) against the oracle with the HIP
     path's bf16 storage points simulated: same max-pool decisions on both sides, so logits are held to SIM_RTOL
-    and every gradient -- conv stack, cloak locs / rhos included -- to cosine > 0.995 and 10 % of its norm (CONV_COS, CONV_REL; measured values beside them)."""
-    ref = _oracle_grl(F, state, sim=True)
+    and every gradient -- conv stack, cloak locs / rhos included -- to cosine > 0.995 and 10 % of its norm (CONV_COS, CONV_REL; measured values beside them).
+    `ref`: a prepared oracle (e.g. with dropout masks injected) instead of the dropout-free one."""
+    ref = _oracle_grl(F, state, sim=True) if ref is None else ref
     q1, q2, _ = ref(x.cpu(), mask=None, grl=False, pooling="mean")
     mo.grl_step_loss(q1, q2, le, lg, wts, 0.1, 0.05, ref).backward()
     close_logits(logits[0], q1.detach().numpy(), rtol=SIM_RTOL, min_decided=min_decided)
@@ -289,11 +290,12 @@ def test_grl_train_step_rough_data():
     _sim_step_check(grl, x, le, lg, wts, sd, F, (p1, p2), min_decided=0.5)
 
 
-@pytest.mark.parametrize("Bn,F", [(1, 80), (3, 40), (13, 80), (37, 128)])
+@pytest.mark.parametrize("Bn,F", [(1, 80), (3, 40), (13, 80), (37, 128), (5, 144)])
 def test_grl_train_step_ragged_batches(Bn, F):
     """The last batch of an epoch is ragged (DataLoader without drop_last, training scripts :401-415 of the
     reference's cloak training): batch sizes that are not multiples of any tile, down to a single window,
-    and the feature sizes the reference extracts (40 / 80 / 128).  Seeded random data; fp32 oracle for the logits,
+    and the feature sizes the reference extracts (40 / 80 / 128) plus one beyond the pool-first backward kernels' 128 columns
+    (144: block 1 then takes the stored-tensor path).  Seeded random data; fp32 oracle for the logits,
     simulated-bf16 oracle for the gradients.  (A batch of ONE window has degenerate BatchNorm statistics in the
     last block -- 25 x F/8 values per channel -- so its bounds are the looser ones.)"""
     from sept_amd import functional as SF
