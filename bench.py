@@ -76,11 +76,12 @@ def _cpu_threads():
     return max(1, min(avail, 16))
 
 
-def cpu_baseline(F, seconds_budget=24.0):
+def cpu_baseline(F, seconds_budget=30.0):
     """oracle port on the host cores: mel one clip at a time (as the reference loops) + GRL steps at the
     reference batch size of 32 windows; utterances/s over the same per-clip work.  Protocol:
-    all the box's threads for this GPU -- 2 warm-up steps, MEDIAN of up to 10 -- and a 1-thread line (1 warm-up,
-    median of up to 3), each leg bounded to its share of `seconds_budget`."""
+    all the box's threads for this GPU -- 3 warm-up steps, MEDIAN of 10 (BASELINE.md's protocol; the leg stops early
+    only if it overruns `seconds_budget`, and says how many steps it took) -- and a 1-thread line (1 warm-up, median
+    of up to 2)."""
     import statistics
     from oracle import mel_oracle, model_oracle as mo
     ncores = _cpu_threads()
@@ -120,12 +121,12 @@ def cpu_baseline(F, seconds_budget=24.0):
         t_step = statistics.median(steps)
         return 1.0 / (t_mel + t_step * 7.0 / Bw), t_mel, t_step, len(steps)
 
-    v, t_mel, t_step, n = leg(ncores, 2, 10, seconds_budget * 0.4)
-    v1, t_mel1, t_step1, n1 = leg(1, 1, 3, seconds_budget * 0.6)
+    v, t_mel, t_step, n = leg(ncores, 3, 10, seconds_budget)
+    v1, t_mel1, t_step1, n1 = leg(1, 1, 2, seconds_budget * 0.4)
     torch.set_num_threads(ncores)
     return {"value": v, "unit": "utterances/s", "cores": ncores, "kind": "port",
             "sample": f"oracle (torch fp32 CPU): 8 clips mel one at a time + median of {n} GRL steps of 32 windows "
-                      f"(fwd+bwd+SGD) after 2 warm-up steps, {ncores} threads; mel {t_mel*1e3:.2f} ms/clip, "
+                      f"(fwd+bwd+SGD) after 3 warm-up steps, {ncores} threads; mel {t_mel*1e3:.2f} ms/clip, "
                       f"step {t_step:.3f} s",
             "one_thread": {"value": v1, "unit": "utterances/s", "cores": 1,
                            "sample": f"same work on 1 thread: median of {n1} steps; mel {t_mel1*1e3:.2f} ms/clip, "

@@ -273,16 +273,12 @@ int sept_cloak_backward(const float* dxa, const float* dxb, float gscale_b, cons
                         const float* scale_mean, float* dlocs, float* drhos, int B, long n_per, void* stream);
 
 /* ------------------------------------------------------------------------------------
- * Layer 1 WITHOUT its pre-activation tensor (baseline_models.py:172-176: Conv2d(1, 32, 5, padding 2) ->
- * BatchNorm2d -> ReLU -> MaxPool2d(2) -> Dropout2d).  conv1's output is 16x its input, so these entry points
- * recompute it from x wherever it is needed instead of storing / re-reading it (H even, W % 16 == 0:
- * sept_conv1_fused_supported; other shapes use the separate conv1 / BatchNorm entry points above).
- *   sept_conv1_stats_only                  : BatchNorm statistics partials (as sept_conv1_forward_stats, no y)
- *   sept_conv1_bn_relu_pool_forward        : y_pooled (B, H/2, W/2, 32) bf16 from x, with given mean / invstd
- *   sept_conv1_bn_relu_pool_backward_reduce: partials[64][sept_conv1_stats_parts(B, H)] of (sum g, sum g * xhat)
- *   sept_bn_bwd_sums_from_partials         : -> sums[2C] (+ dgamma, dbeta); all-reducible for sync-BN
- *   sept_conv1_bn_relu_pool_backward_apply : dpre (B, H, W, 32) bf16, the gradient sept_conv1_backward_* consume
- * wprep: sept_conv1_prep_floats() floats of scratch, as for sept_conv1_forward. */
+ * Layer 1 in ONE pass with given statistics (inference; baseline_models.py:172-176: Conv2d(1, 32, 5, padding 2) ->
+ * BatchNorm2d (running statistics) -> ReLU -> MaxPool2d(2) -> Dropout2d scale): conv1's output is 16x its input, so
+ * sept_conv1_bn_relu_pool_forward keeps it in registers and writes only y_pooled (B, H/2, W/2, 32) bf16 (H even,
+ * W % 16 == 0: sept_conv1_fused_supported; other shapes use the separate conv1 / BatchNorm entry points above).
+ * Training uses the pool-first form below.  wprep: sept_conv1_prep_floats() floats of scratch, as for sept_conv1_forward.
+ * (sept_bn_bwd_sums_from_partials: partials[2C][nparts] -> sums[2C] (+ dgamma, dbeta); all-reducible for sync-BN.) */
 /* BatchNorm backward sums in the epilogue of the data-gradient conv that PRODUCES dy (baseline_models.py:172-188,
  * backward): sept_conv5x5_dgrad_bnsums = sept_conv5x5_forward on data-gradient operands (wt from
  * sept_conv5x5_prep_weights mode 1, cin > cout) that also leaves partials[2*cout][sept_conv5x5_stats_parts(B, H, W,
@@ -331,28 +327,19 @@ int sept_bn_relu_pool_backward_presummed(const void* dy, const void* x, const fl
                                          const float* partials, int nparts, float* ws, void* dx, float* dgamma,
                                          float* dbeta, int B, int H, int W, int C, int pool, void* stream);
 
-/* conv1's data gradient straight from the BatchNorm-backward inputs -- the gradient of conv1's output (dpre, 64 bytes
- * per pixel) is formed in the kernel's row loader from conv1's stored output `pre`, the gradient of the pooled
- * activation and the two channel sums, and is never written for a network without weight gradients (dpre_out NULL:
- * the frozen emotion model, cloak_models.py:142-144) or written once for conv1's weight gradient.  sums[2*32] as
- * left by sept_bn_relu_pool_backward_reduce or sept_bn_backward_sums_presummed (= finalize of a producer's partials,
- * tiny-|gamma| chunks re-summed from the windows; also yields dgamma / dbeta); n_total = elements per channel. */
+/* Finish of a producer's partial BatchNorm backward sums: sums[2*C] from the partials a data-gradient conv's epilogue left
+ * (tiny-|gamma| chunks re-summed from the windows; also yields dgamma / dbeta); n_total = elements per channel. */
 int sept_bn_backward_sums_presummed(const void* dy, const void* x, const float* mean, const float* invstd,
                                     const float* gamma, const float* beta, const float* dropscale, const float* partials,
                                     int nparts, float* ws, float* sums_out, float* dgamma, float* dbeta, int B, int H,
                                     int W, int C, int pool, void* stream);
-int sept_conv1_backward_data_bn(const void* pre, const void* dy_pooled, const float* mean, const float* invstd,
-                                const float* gamma, const float* beta, const float* dropscale, const float* sums,
-                                double n_total, const float* w, float* wprep, float* dx, void* dpre_out, int B, int H,
-                                int W, void* stream);
-
 /* Block 1's data gradient WITHOUT a pre-activation-sized tensor (baseline_models.py:172-176 + autograd).  BatchNorm's
  * input gradient is scd_c g (at the window maxima) + c0_c + c1_c v with v = conv1(x) + bias; conv1 has one input
  * channel, so the data gradient of the dense part is a fixed linear map of x (a 9 x 9 filter away from the border, the
  * exact tap-by-tap form on the two-pixel ring) and only the sparse part goes through the MFMA data-gradient kernel,
  * whose loader expands it from the POOLED gradient and the window positions recorded by
  * sept_bn_relu_pool_forward_argmax (one byte per pooled element; pool * pool = the ReLU cut it).  w_f32 / bias: conv1's
- * weights (32, 1, 5, 5) and bias; sums / n_total as for sept_conv1_backward_data_bn; coef: SEPT_CONV1_COEF_FLOATS floats
+ * weights (32, 1, 5, 5) and bias; sums[64] = (sum g, sum g * xhat) over n_total elements per channel; coef: SEPT_CONV1_COEF_FLOATS floats
  * of scratch.  H even, W a multiple of 4 and <= 128. */
 #define SEPT_CONV1_COEF_FLOATS 2800
 int sept_bn_relu_pool_forward_argmax(const void* x, const float* mean, const float* invstd, const float* gamma,
@@ -367,22 +354,11 @@ int sept_conv1_backward_data_sparse(const void* dy_pooled, const void* idx_u8, c
  * with w == NULL ("wprep is current"); sept_conv1_prep builds it explicitly so a caller can keep it across calls. */
 int sept_conv1_prep(const float* w, const float* bias, float* wprep, void* stream);
 int sept_conv1_fused_supported(int H, int W);
-int sept_conv1_stats_only(const float* x, const float* w, const float* bias, float* wprep, float* stats, int B, int H,
-                          int W, void* stream);
 int sept_conv1_bn_relu_pool_forward(const float* x, const float* w, const float* bias, float* wprep, const float* mean,
                                     const float* invstd, const float* gamma, const float* beta, const float* dropscale,
                                     void* y_pooled, int B, int H, int W, void* stream);
-int sept_conv1_bn_relu_pool_backward_reduce(const float* x, const float* w, const float* bias, float* wprep,
-                                            const void* dy_pooled, const float* mean, const float* invstd,
-                                            const float* gamma, const float* beta, const float* dropscale,
-                                            float* partials, int B, int H, int W, void* stream);
 int sept_bn_bwd_sums_from_partials(const float* partials, int nparts, int C, float* sums_out, float* dgamma,
                                    float* dbeta, void* stream);
-int sept_conv1_bn_relu_pool_backward_apply(const float* x, const float* w, const float* bias, float* wprep,
-                                           const void* dy_pooled, const float* mean, const float* invstd,
-                                           const float* gamma, const float* beta, const float* dropscale,
-                                           const float* sums, double n_total, void* dpre, int B, int H, int W,
-                                           void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Block 1 in POOL-FIRST form (round 3; baseline_models.py:172-176 forward + autograd backward, no 64-byte-per-pixel

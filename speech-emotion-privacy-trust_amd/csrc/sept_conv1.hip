@@ -140,7 +140,7 @@ constexpr int kStatLd = 33;   // floats per lane in the statistics exchange (odd
 // outputs in stats[workgroup][64] -- the BatchNorm that follows (baseline_models.py:173) then needs
 // no pass of its own over the 64 B/pixel tensor.  Each lane keeps running sums of its 16 channels
 // over its blocks; they meet once per workgroup in LDS, added in a fixed order.
-template <bool STATS, bool WRITE = true>
+template <bool STATS>
 __global__ __launch_bounds__(256) void sept_conv1_fwd_mfma_kernel(const float* __restrict__ x,
                                                                   const float* __restrict__ wprep,
                                                                   bf16* __restrict__ y, float* __restrict__ stats,
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void sept_conv1_fwd_mfma_kernel(const float* _
       const auto r1 = __builtin_amdgcn_permlane32_swap(pk[u][1], pk[u + 2][1], false, false);
       out[u] = make_uint4(r0[0], r1[0], r0[1], r1[1]);
     }
-    if (WRITE && q < npx) {
+    if (q < npx) {
       uint4* yp = reinterpret_cast<uint4*>(yb + size_t(q) * kC + 16 * half);
       yp[0] = out[0];
       yp[1] = out[1];
@@ -627,36 +627,28 @@ __global__ __launch_bounds__(256, 4) void sept_conv1_dgrad_stream2_kernel(const 
   }
 }
 
-// ---- data gradient with the BatchNorm backward "apply" pass folded into its row loader -----------------------------
-// sept_conv1_dgrad_stream2_kernel consumes the gradient of conv1's output (dpre, 64 B per pixel) row by row.  That
-// tensor is itself a pointwise function of conv1's stored output (pre), the gradient of the POOLED activation (dyp,
-// a quarter of the pixels) and two per-channel sums: dpre = sc * (ge - m1 - xhat * m2), ge = the pooled gradient
-// at the window's first maximum (sept_bn_bwd_apply_kernel).  Here the loader fetches pre rows in PAIRS (a 2x2 pooling
-// window is two rows x two neighbouring pixels: one thread fetches all four 16-byte chunks of its 8 channels)
-// plus the pooled gradient row, forms both dpre rows in registers and feeds them to the
-// same MFMA / gather pipeline -- so the 229 MB dpre tensor is neither written nor read for a network that needs no
-// weight gradient (the frozen emotion model), and written once (`dpre_out`) for one that does.
+// ---- block 1's data gradient, sparse part: the row loader EXPANDS the pooled gradient --------------------------------
+// sept_conv1_dgrad_stream2_kernel consumes the gradient of conv1's output (64 B per pixel) row by row.  For a pool-first /
+// arg-max-recording block 1 that tensor never exists: its sparse part -- scd * g_pooled at the window's recorded position,
+// zero elsewhere -- is formed here, in the loader, from the pooled gradient (a quarter of the pixels) and one position
+// byte per pooled element, and fed to the same MFMA / gather pipeline; the dense rest (c0 + c1 * v, v = conv1(x) + bias) is
+// linear in the one-channel input and is added by sept_conv1_dense_dgrad_kernel.  (Round 2 also had a dense form of this
+// loader that re-derived the arg-max from the stored pre-activations, sept_conv1_backward_data_bn: measured slower than
+// the separate passes, superseded by this one, removed in round 4.)
 struct C1BnArgs {
-  const bf16* pre;    // [B][H][W][32] conv1 output (pre-BatchNorm)
-  const bf16* dyp;    // [B][H/2][W/2][32] gradient of the pooled activation
-  const float *mean, *invstd, *gamma, *beta, *drop, *sums;   // drop [B][32] or null; sums [64] = sum g, sum g * xhat
-  float inv_n;
+  const bf16* dyp;    // [B][H/2][W/2][32] gradient of the pooled activation (masked: zero where the ReLU is inactive)
+  const float *invstd, *gamma, *drop;   // drop [B][32] or null
   const float* wprep;
   float* dx;          // [B][H][W]
-  bf16* dpre_out;     // [B][H][W][32] or null
   int B, H, W, rows_per_chunk;
-  const unsigned char* idx;   // SPARSE form: [B][H/2][W/2][32] window position of the maximum (4 = none), `pre` unused
+  const unsigned char* idx;   // [B][H/2][W/2][32] window position of the extremum (0..3; 4 = none)
 };
 
 __device__ __forceinline__ unsigned lane_xor4(unsigned v) {   // value of lane ^ 4 (ds_swizzle bit mode: and 0x1F, xor 4)
   return unsigned(__builtin_amdgcn_ds_swizzle(int(v), 0x101F));
 }
 
-// SPARSE: only the part of dpre that sits at the arg-max positions, scd * g_pooled, is formed -- from the pooled gradient
-// and the recorded positions, without reading `pre`; the dense rest (c0 + c1 * v, v = conv1(x) + bias) is linear in the
-// one-channel input and is added by sept_conv1_dense_dgrad_kernel.
-template <bool SPARSE>
-__global__ __launch_bounds__(256, SPARSE ? 4 : 3) void sept_conv1_dgrad_bnapply_kernel(C1BnArgs a) {
+__global__ __launch_bounds__(256, 4) void sept_conv1_dgrad_sparse_kernel(C1BnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int H = a.H, W = a.W, W4 = W + 4;
   const int NP = (W4 + 31) / 32 * 32;
@@ -665,10 +657,8 @@ __global__ __launch_bounds__(256, SPARSE ? 4 : 3) void sept_conv1_dgrad_bnapply_
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y;
   const int r0 = blockIdx.x * a.rows_per_chunk, r1 = min(H, r0 + a.rows_per_chunk);   // both even
-  const bf16* preb = SPARSE ? nullptr : a.pre + size_t(b) * H * W * kC;
   const bf16* dypb = a.dyp + size_t(b) * (H / 2) * (W / 2) * kC;
-  const unsigned char* idxb = SPARSE ? a.idx + size_t(b) * (H / 2) * (W / 2) * kC : nullptr;
-  bf16* outb = (!SPARSE && a.dpre_out) ? a.dpre_out + size_t(b) * H * W * kC : nullptr;
+  const unsigned char* idxb = a.idx + size_t(b) * (H / 2) * (W / 2) * kC;
 
   for (int i = tid; i < 2 * NP * (kDyPS / 16); i += 256) reinterpret_cast<uint4*>(dyrow)[i] = make_uint4(0, 0, 0, 0);
   const int tap = lane & 31;
@@ -683,87 +673,40 @@ __global__ __launch_bounds__(256, SPARSE ? 4 : 3) void sept_conv1_dgrad_bnapply_
     }
   }
   // A thread owns one pooling-window COLUMN and one group of 8 channels: thread t -> window column t >> 2 (pixels
-  // 2 * (t >> 2) and + 1 of both rows of a pair), channels 8 * (t & 3) .. + 7.  Each window is evaluated once, by
-  // one thread, from four 16-byte chunks of pre and one of the pooled gradient -- no lane exchange, no duplicated
-  // arithmetic.  BatchNorm constants in the form the apply pass needs:
-  //   relu test / arg-max : r = max(v * sc + sh, 0);   dpre = scd * g_pooled [winner] + (c0 + c1 * v)
-  //   with c1 = -sc * m2 * invstd, c0 = -sc * m1 - c1 * mean, scd = sc * dropscale  (= sc * (ge - m1 - xhat * m2))
+  // 2 * (t >> 2) and + 1 of both rows of a pair), channels 8 * (t & 3) .. + 7.  Each window is expanded once, by one
+  // thread, from 16 bytes of the pooled gradient and 8 position bytes: scd = gamma * invstd * dropscale at the recorded pixel.
   const int cg = tid & 3, wc = tid >> 2;
   const bool owner = wc < W / 2;
-  float sc[8], sh[8], scd[8], c0[8], c1[8];
+  float scd[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int ch = 8 * cg + e;
-    const float is = a.invstd[ch];
-    sc[e] = a.gamma[ch] * is;
-    scd[e] = sc[e] * (a.drop ? a.drop[size_t(b) * kC + ch] : 1.0f);
-    if constexpr (!SPARSE) {
-      const float mu = a.mean[ch];
-      sh[e] = __builtin_fmaf(-mu, sc[e], a.beta[ch]);
-      c1[e] = -sc[e] * (a.sums[kC + ch] * a.inv_n) * is;
-      c0[e] = -sc[e] * (a.sums[ch] * a.inv_n) - c1[e] * mu;
-    } else {
-      sh[e] = c1[e] = c0[e] = 0.f;
-    }
+    scd[e] = a.gamma[ch] * a.invstd[ch] * (a.drop ? a.drop[size_t(b) * kC + ch] : 1.0f);
   }
-  // raw data of one window column of a row pair: pre rows y (even) and y + 1, two pixels each; the pooled gradient
+  // raw data of one window column of a row pair: the pooled gradient and the position bytes
   struct Raw {
-    uint4 a0, a1, b0, b1, g;
+    uint4 g;
     uint2 ix;
   };
   const int wcc = min(wc, W / 2 - 1);      // idle threads re-read the last window (never stored)
   auto gload = [&](int y, Raw& r) {        // y even; clamped addresses (rows outside the image are zeroed at use)
     const int yc = min(max(y, 0), H - 2);
-    if constexpr (!SPARSE) {
-      const bf16* ra = preb + (size_t(yc) * W + 2 * wcc) * kC + cg * 8;
-      r.a0 = *reinterpret_cast<const uint4*>(ra);
-      r.a1 = *reinterpret_cast<const uint4*>(ra + kC);
-      r.b0 = *reinterpret_cast<const uint4*>(ra + size_t(W) * kC);
-      r.b1 = *reinterpret_cast<const uint4*>(ra + size_t(W) * kC + kC);
-    } else {
-      r.ix = *reinterpret_cast<const uint2*>(idxb + (size_t(yc >> 1) * (W / 2) + wcc) * kC + cg * 8);
-    }
+    r.ix = *reinterpret_cast<const uint2*>(idxb + (size_t(yc >> 1) * (W / 2) + wcc) * kC + cg * 8);
     r.g = *reinterpret_cast<const uint4*>(dypb + (size_t(yc >> 1) * (W / 2) + wcc) * kC + cg * 8);
   };
   // dpre chunks of the window's four pixels: row y (da[0], da[1]) and row y + 1 (db[0], db[1])
   auto apply = [&](int y, const Raw& r, uint4 (&da)[2], uint4 (&db)[2]) {
     const bool inside = y >= 0 && y < H;
-    if constexpr (SPARSE) {
-      const bf16x8 gq = __builtin_bit_cast(bf16x8, r.g);
-      bf16x8 o0, o1, o2, o3;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const unsigned k = ((e < 4 ? r.ix.x : r.ix.y) >> (8 * (e & 3))) & 0xffu;
-        const bf16 g = (bf16)(float(gq[e]) * scd[e]), z0 = (bf16)0.f;
-        o0[e] = k == 0 ? g : z0;
-        o1[e] = k == 1 ? g : z0;
-        o2[e] = k == 2 ? g : z0;
-        o3[e] = k == 3 ? g : z0;
-      }
-      const uint4 z = make_uint4(0, 0, 0, 0);
-      da[0] = inside ? __builtin_bit_cast(uint4, o0) : z;
-      da[1] = inside ? __builtin_bit_cast(uint4, o1) : z;
-      db[0] = inside ? __builtin_bit_cast(uint4, o2) : z;
-      db[1] = inside ? __builtin_bit_cast(uint4, o3) : z;
-      return;
-    }
-    const bf16x8 v0 = __builtin_bit_cast(bf16x8, r.a0), v1 = __builtin_bit_cast(bf16x8, r.a1);
-    const bf16x8 v2 = __builtin_bit_cast(bf16x8, r.b0), v3 = __builtin_bit_cast(bf16x8, r.b1);
     const bf16x8 gq = __builtin_bit_cast(bf16x8, r.g);
     bf16x8 o0, o1, o2, o3;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float x0 = float(v0[e]), x1 = float(v1[e]), x2 = float(v2[e]), x3 = float(v3[e]);
-      // scan order of the window: (y, even col), (y, odd col), (y + 1, even col), (y + 1, odd col); first maximum wins
-      const float q0 = fmaxf(__builtin_fmaf(x0, sc[e], sh[e]), 0.f), q1 = fmaxf(__builtin_fmaf(x1, sc[e], sh[e]), 0.f);
-      const float q2 = fmaxf(__builtin_fmaf(x2, sc[e], sh[e]), 0.f), q3 = fmaxf(__builtin_fmaf(x3, sc[e], sh[e]), 0.f);
-      const float best = fmaxf(fmaxf(q0, q1), fmaxf(q2, q3));
-      const float g = best > 0.f ? float(gq[e]) * scd[e] : 0.f;
-      const bool w0 = q0 == best, w1 = !w0 && q1 == best, w2 = !w0 && !w1 && q2 == best, w3 = !w0 && !w1 && !w2;
-      o0[e] = (bf16)((w0 ? g : 0.f) + __builtin_fmaf(c1[e], x0, c0[e]));
-      o1[e] = (bf16)((w1 ? g : 0.f) + __builtin_fmaf(c1[e], x1, c0[e]));
-      o2[e] = (bf16)((w2 ? g : 0.f) + __builtin_fmaf(c1[e], x2, c0[e]));
-      o3[e] = (bf16)((w3 ? g : 0.f) + __builtin_fmaf(c1[e], x3, c0[e]));
+      const unsigned k = ((e < 4 ? r.ix.x : r.ix.y) >> (8 * (e & 3))) & 0xffu;
+      const bf16 g = (bf16)(float(gq[e]) * scd[e]), z0 = (bf16)0.f;
+      o0[e] = k == 0 ? g : z0;
+      o1[e] = k == 1 ? g : z0;
+      o2[e] = k == 2 ? g : z0;
+      o3[e] = k == 3 ? g : z0;
     }
     const uint4 z = make_uint4(0, 0, 0, 0);
     da[0] = inside ? __builtin_bit_cast(uint4, o0) : z;
@@ -773,12 +716,10 @@ __global__ __launch_bounds__(256, SPARSE ? 4 : 3) void sept_conv1_dgrad_bnapply_
   };
   auto lstore = [&](int buf, int y, const uint4 (&d)[2]) {
     if (!owner) return;
-    const bool inside = y >= 0 && y < H;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int px = 2 * wc + j;
       *reinterpret_cast<uint4*>(dyrow + size_t(buf) * NP * kDyPS + size_t(px + 2) * kDyPS + cg * 16) = d[j];
-      if (outb && inside && y >= r0 && y < r1) *reinterpret_cast<uint4*>(outb + (size_t(y) * W + px) * kC + cg * 8) = d[j];
     }
   };
   Raw raw0, raw1;
@@ -1220,31 +1161,22 @@ __global__ __launch_bounds__(1024) void sept_conv1_wgrad_sparse_combine_kernel(c
                         // of the large terms that cancel -- callers that know the BatchNorm is in train mode store 0 instead
 }
 
-// ---- layer 1 without its pre-activation tensor ----------------------------------------------------
-// conv1's output is 16x larger than its input (32 bf16 channels per fp32 pixel): at 224 windows of 200 x 80 the
-// pre-BatchNorm tensor is 229 MB, and storing it made every pass around it an HBM stream (conv1 write, BatchNorm
-// read, backward read + gradient write: a third of the step's kernel time in round 1).  These kernels RECOMPUTE
-// conv1 from the 14 MB input wherever its output is needed (the same six MFMAs per 32 pixels, so the same bits):
-//   forward : a statistics-only pass (sept_conv1_fwd_mfma_kernel<true, false>: no store), then conv1 -> BatchNorm ->
-//             ReLU -> MaxPool 2x2 -> Dropout2d in registers, writing only the pooled tensor (1/4 of the pixels);
-//   backward: the two BatchNorm sums (sum g, sum g * xhat) by recomputation, then the gradient of the pre-activations
-//             (what conv1's weight / data gradients consume) from x, the pooled gradient and the sums.
+// ---- block 1 in ONE pass with given statistics (inference) ----------------------------------------------------------
+// conv1 -> BatchNorm (running statistics) -> ReLU -> MaxPool 2x2 -> Dropout2d scale in registers, writing only the pooled
+// tensor (1/4 of the pixels): the 64-byte-per-pixel pre-activation tensor (16x the input) is never stored.  Same six MFMAs
+// per 32 pixels as sept_conv1_fwd_mfma_kernel, so the same bits.  (Round 2 also ran this form in TRAINING -- a
+// statistics-only pass in front, conv1 recomputed twice more in the backward pass -- which lost to streaming the tensor
+// and then to the pool-first form below; those modes were removed in round 4.)
 // A 32-pixel MFMA block is a 2-row x 16-column PATCH here, so the four pixels of a pooling window sit in lanes
-// c, c^1 (next column) and c^16, c^17 (next row) of the same 32-lane half: the window maximum and the arg-max
-// decision are two lane exchanges (quad-perm DPP and v_permlane16_swap), no LDS.  Needs W % 16 == 0 and H even.
-enum { kL1Fwd = 0, kL1BwdReduce = 1, kL1BwdApply = 2 };
+// c, c^1 (next column) and c^16, c^17 (next row) of the same 32-lane half: the window maximum is two lane exchanges
+// (quad-perm DPP and v_permlane16_swap), no LDS.  Needs W % 16 == 0 and H even.
 
 struct L1Args {
   const float* x;       // [B][H][W]
   const float* wprep;   // sept_conv1_prep_kernel output
   const float *mean, *invstd, *gamma, *beta;   // [32]
   const float* drop;    // [B][32] Dropout2d scale (0 or 1/(1-p)) or null
-  bf16* y;              // forward: pooled output [B][H/2][W/2][32]
-  const bf16* dy;       // backward: gradient of the pooled output
-  bf16* dpre;           // backward apply: gradient of the conv output [B][H][W][32]
-  const float* sums;    // backward apply: [64] = sum g, sum g * xhat
-  float inv_n;          // backward apply: 1 / (elements per channel the sums cover)
-  float* parts;         // backward reduce: transposed partials [64][workgroups]
+  bf16* y;              // pooled output [B][H/2][W/2][32]
   int B, H, W;
 };
 
@@ -1257,7 +1189,6 @@ __device__ __forceinline__ float lane_xor16(float v) {  // value of lane ^ 16 (r
   return __builtin_bit_cast(float, ((threadIdx.x >> 4) & 1) ? r[0] : r[1]);
 }
 
-template <int MODE>
 __global__ __launch_bounds__(256) void sept_conv1_l1_kernel(L1Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* tile = reinterpret_cast<float*>(smem);
@@ -1281,35 +1212,16 @@ __global__ __launch_bounds__(256) void sept_conv1_l1_kernel(L1Args a) {
       tapoff[ks][j] = t < kTaps ? (t / 5) * W4 + t % 5 : 0;
     }
   // per-lane channel constants: register r <-> channel 8 * (r >> 2) + 4 * half + (r & 3)
-  float sc[16], sh[16], mu[16], is[16];
+  float sc[16], sh[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int ch = 8 * (r >> 2) + 4 * half + (r & 3);
-    mu[r] = a.mean[ch];
-    is[r] = a.invstd[ch];
-    sc[r] = a.gamma[ch] * is[r];
-    sh[r] = __builtin_fmaf(-mu[r], sc[r], a.beta[ch]);
-  }
-  float m1[MODE == kL1BwdApply ? 16 : 1], m2[MODE == kL1BwdApply ? 16 : 1];
-  if constexpr (MODE == kL1BwdApply) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ch = 8 * (r >> 2) + 4 * half + (r & 3);
-      m1[r] = a.sums[ch] * a.inv_n;
-      m2[r] = a.sums[kC + ch] * a.inv_n;
-    }
-  }
-  float s1[MODE == kL1BwdReduce ? 16 : 1], s2[MODE == kL1BwdReduce ? 16 : 1];
-  if constexpr (MODE == kL1BwdReduce) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s1[r] = s2[r] = 0.f;
+    sc[r] = a.gamma[ch] * a.invstd[ch];
+    sh[r] = __builtin_fmaf(-a.mean[ch], sc[r], a.beta[ch]);
   }
   float dr[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) dr[r] = a.drop ? a.drop[size_t(b) * kC + 8 * (r >> 2) + 4 * half + (r & 3)] : 1.0f;
-  // this lane's place in its pooling window: q = 2 * (row in the pair) + (column parity), scan order of max_pool2d
-  const int myq = 2 * ((c >> 4) & 1) + (c & 1);
-  const bool h_first = (myq ^ 1) < myq, v_first = (myq ^ 2) < myq, d_first = (myq ^ 3) < myq;
   __syncthreads();
   const int Ho = H / 2, Wo = W / 2;
   const int nblk = (nrows / 2) * PW;
@@ -1335,7 +1247,7 @@ __global__ __launch_bounds__(256) void sept_conv1_l1_kernel(L1Args a) {
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[ks], xhi, acc, 0, 0, 0);
     }
     const int ho = (h0 >> 1) + rp, wo = 8 * pc + ((c & 15) >> 1);
-    if constexpr (MODE == kL1Fwd) {
+    {
       unsigned pk[4][2];
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -1365,68 +1277,6 @@ __global__ __launch_bounds__(256) void sept_conv1_l1_kernel(L1Args a) {
         yp[0] = out[0];
         yp[1] = out[1];
       }
-    } else {
-      // pooled gradient of this lane's window: 4 x (4 channels = 8 bytes)
-      const bf16* dyp = a.dy + ((size_t(b) * Ho + ho) * Wo + wo) * kC + 4 * half;
-      bf16x4 gq[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) gq[j] = *reinterpret_cast<const bf16x4*>(dyp + 8 * j);
-      unsigned pk[4][2];
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int d = 0; d < 2; ++d) {
-          bf16x2 t;
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            const int r = 4 * j + 2 * d + e;
-            const float v = float((bf16)acc[r]);
-            const float rl = fmaxf(__builtin_fmaf(v, sc[r], sh[r]), 0.f);
-            // first maximum in window scan order wins (ATen max_pool2d), and only if the ReLU is active there
-            const float rh = lane_xor1(rl), rv = lane_xor16(rl), rd = lane_xor16(rh);
-            const bool win = rl > 0.f && (h_first ? rl > rh : rl >= rh) && (v_first ? rl > rv : rl >= rv) &&
-                             (d_first ? rl > rd : rl >= rd);
-            const float ge = win ? float(gq[j][2 * d + e]) * dr[r] : 0.f;
-            const float xhat = (v - mu[r]) * is[r];
-            if constexpr (MODE == kL1BwdReduce) {
-              s1[r] += ge;
-              s2[r] = __builtin_fmaf(ge, xhat, s2[r]);
-            } else {
-              t[e] = (bf16)(sc[r] * (ge - m1[r] - xhat * m2[r]));
-            }
-          }
-          if constexpr (MODE == kL1BwdApply) pk[j][d] = __builtin_bit_cast(unsigned, t);
-        }
-      if constexpr (MODE == kL1BwdApply) {
-        uint4 out[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const auto r0 = __builtin_amdgcn_permlane32_swap(pk[u][0], pk[u + 2][0], false, false);
-          const auto r1 = __builtin_amdgcn_permlane32_swap(pk[u][1], pk[u + 2][1], false, false);
-          out[u] = make_uint4(r0[0], r1[0], r0[1], r1[1]);
-        }
-        uint4* dp = reinterpret_cast<uint4*>(a.dpre + ((size_t(b) * H + h0 + hh) * W + ww) * kC + 16 * half);
-        dp[0] = out[0];
-        dp[1] = out[1];
-      }
-    }
-  }
-  if constexpr (MODE == kL1BwdReduce) {
-    __syncthreads();   // the staged rows are no longer needed: the exchange reuses their LDS
-    float* ex = reinterpret_cast<float*>(smem);   // [256 lanes][kStatLd]
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      ex[threadIdx.x * kStatLd + r] = s1[r];
-      ex[threadIdx.x * kStatLd + 16 + r] = s2[r];
-    }
-    __syncthreads();
-    if (threadIdx.x < 2 * kC) {
-      const int which = threadIdx.x / kC, ch = threadIdx.x % kC;
-      const int j = ch >> 3, hf = (ch >> 2) & 1, i = ch & 3;
-      float t = 0.f;
-      for (int w = 0; w < 4; ++w)
-        for (int l = 0; l < 32; ++l) t += ex[(w * 64 + hf * 32 + l) * kStatLd + which * 16 + 4 * j + i];
-      a.parts[size_t(threadIdx.x) * (size_t(gridDim.x) * gridDim.y) + size_t(blockIdx.y) * gridDim.x + blockIdx.x] = t;
     }
   }
 }
@@ -1754,20 +1604,6 @@ int l1_check(const char* who, int B, int H, int W) {
 }
 }  // namespace
 
-// BatchNorm statistics partials of conv1's (bf16-rounded) output WITHOUT writing it: stats[64][sept_conv1_stats_parts(B, H)]
-extern "C" int sept_conv1_stats_only(const float* x, const float* w, const float* bias, float* wprep, float* stats, int B,
-                                     int H, int W, void* stream) {
-  if (int e = conv1_check("sept_conv1_stats_only", B, H, W)) return e;
-  SEPT_REQUIRE(B > 0 && x && wprep && stats, SEPT_ERR_INVALID, "sept_conv1_stats_only: null argument / empty batch");
-  const size_t smem_m = std::max(sizeof(float) * size_t(kFwdRows + 4) * (W + 4), sizeof(float) * 256 * kStatLd);
-  SEPT_REQUIRE(smem_m <= 64 * 1024, SEPT_ERR_UNSUPPORTED, "sept_conv1_stats_only: W=%d is too wide", W);
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if (w) hipLaunchKernelGGL(sept_conv1_prep_kernel, dim3((kTaps * kC + 255) / 256), dim3(256), 0, st, w, bias, wprep);
-  hipLaunchKernelGGL((sept_conv1_fwd_mfma_kernel<true, false>), dim3((H + kFwdRows - 1) / kFwdRows, B), dim3(256), smem_m, st,
-                     x, static_cast<const float*>(wprep), static_cast<bf16*>(nullptr), stats, B, H, W);
-  return sept::launch_check("sept_conv1_fwd_mfma_kernel<stats only>");
-}
-
 extern "C" int sept_conv1_bn_relu_pool_forward(const float* x, const float* w, const float* bias, float* wprep,
                                                const float* mean, const float* invstd, const float* gamma,
                                                const float* beta, const float* dropscale, void* y_pooled, int B, int H,
@@ -1781,43 +1617,8 @@ extern "C" int sept_conv1_bn_relu_pool_forward(const float* x, const float* w, c
   L1Args a{};
   a.x = x; a.wprep = wprep; a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.beta = beta; a.drop = dropscale;
   a.y = static_cast<bf16*>(y_pooled); a.B = B; a.H = H; a.W = W;
-  hipLaunchKernelGGL(sept_conv1_l1_kernel<kL1Fwd>, dim3((H + kFwdRows - 1) / kFwdRows, B), dim3(256), l1_smem(W), st, a);
-  return sept::launch_check("sept_conv1_l1_kernel<forward>");
-}
-
-// partials[64][sept_conv1_stats_parts(B, H)] of (sum g, sum g * xhat), to be finished by sept_bn_bwd_sums_from_partials
-extern "C" int sept_conv1_bn_relu_pool_backward_reduce(const float* x, const float* w, const float* bias, float* wprep,
-                                                       const void* dy_pooled, const float* mean, const float* invstd,
-                                                       const float* gamma, const float* beta, const float* dropscale,
-                                                       float* partials, int B, int H, int W, void* stream) {
-  if (int e = l1_check("sept_conv1_bn_relu_pool_backward_reduce", B, H, W)) return e;
-  SEPT_REQUIRE(B > 0 && x && wprep && dy_pooled && mean && invstd && gamma && beta && partials, SEPT_ERR_INVALID,
-               "sept_conv1_bn_relu_pool_backward_reduce: null argument / empty batch");
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if (w) hipLaunchKernelGGL(sept_conv1_prep_kernel, dim3((kTaps * kC + 255) / 256), dim3(256), 0, st, w, bias, wprep);
-  L1Args a{};
-  a.x = x; a.wprep = wprep; a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.beta = beta; a.drop = dropscale;
-  a.dy = static_cast<const bf16*>(dy_pooled); a.parts = partials; a.B = B; a.H = H; a.W = W;
-  hipLaunchKernelGGL(sept_conv1_l1_kernel<kL1BwdReduce>, dim3((H + kFwdRows - 1) / kFwdRows, B), dim3(256), l1_smem(W), st, a);
-  return sept::launch_check("sept_conv1_l1_kernel<backward reduce>");
-}
-
-extern "C" int sept_conv1_bn_relu_pool_backward_apply(const float* x, const float* w, const float* bias, float* wprep,
-                                                      const void* dy_pooled, const float* mean, const float* invstd,
-                                                      const float* gamma, const float* beta, const float* dropscale,
-                                                      const float* sums, double n_total, void* dpre, int B, int H, int W,
-                                                      void* stream) {
-  if (int e = l1_check("sept_conv1_bn_relu_pool_backward_apply", B, H, W)) return e;
-  SEPT_REQUIRE(B > 0 && x && wprep && dy_pooled && mean && invstd && gamma && beta && sums && dpre && n_total > 0,
-               SEPT_ERR_INVALID, "sept_conv1_bn_relu_pool_backward_apply: null argument / empty batch");
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if (w) hipLaunchKernelGGL(sept_conv1_prep_kernel, dim3((kTaps * kC + 255) / 256), dim3(256), 0, st, w, bias, wprep);
-  L1Args a{};
-  a.x = x; a.wprep = wprep; a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.beta = beta; a.drop = dropscale;
-  a.dy = static_cast<const bf16*>(dy_pooled); a.dpre = static_cast<bf16*>(dpre); a.sums = sums;
-  a.inv_n = float(1.0 / n_total); a.B = B; a.H = H; a.W = W;
-  hipLaunchKernelGGL(sept_conv1_l1_kernel<kL1BwdApply>, dim3((H + kFwdRows - 1) / kFwdRows, B), dim3(256), l1_smem(W), st, a);
-  return sept::launch_check("sept_conv1_l1_kernel<backward apply>");
+  hipLaunchKernelGGL(sept_conv1_l1_kernel, dim3((H + kFwdRows - 1) / kFwdRows, B), dim3(256), l1_smem(W), st, a);
+  return sept::launch_check("sept_conv1_l1_kernel");
 }
 
 
@@ -1889,38 +1690,6 @@ extern "C" int sept_conv1_prep(const float* w, const float* bias, float* wprep, 
   hipLaunchKernelGGL(sept_conv1_prep_kernel, dim3((kTaps * kC + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), w,
                      bias, wprep);
   return sept::launch_check("sept_conv1_prep_kernel");
-}
-
-// Data gradient of conv1 straight from the BatchNorm backward inputs (no dpre tensor): see
-// sept_conv1_dgrad_bnapply_kernel.  sums[64] = (sum g, sum g * xhat) as sept_bn_relu_pool_backward_reduce /
-// sept_bn_bwd_sums_from_partials leave them; n_total = elements per channel they cover.  dpre_out (nullable)
-// receives the gradient of conv1's output for a weight-gradient launch.  H, W even, W <= 128.
-extern "C" int sept_conv1_backward_data_bn(const void* pre, const void* dy_pooled, const float* mean,
-                                           const float* invstd, const float* gamma, const float* beta,
-                                           const float* dropscale, const float* sums, double n_total, const float* w,
-                                           float* wprep, float* dx, void* dpre_out, int B, int H, int W, void* stream) {
-  if (int e = conv1_check("sept_conv1_backward_data_bn", B, H, W)) return e;
-  if (B == 0) return SEPT_OK;
-  SEPT_REQUIRE(pre && dy_pooled && mean && invstd && gamma && beta && sums && wprep && dx && n_total > 0, SEPT_ERR_INVALID,
-               "sept_conv1_backward_data_bn: null argument");
-  SEPT_REQUIRE(H % 2 == 0 && W % 2 == 0 && W * 4 <= 512 && H >= 2, SEPT_ERR_UNSUPPORTED,
-               "sept_conv1_backward_data_bn: H=%d W=%d (needs even H, even W <= 128)", H, W);
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if (w)
-    hipLaunchKernelGGL(sept_conv1_prep_kernel, dim3((kTaps * kC + 255) / 256), dim3(256), 0, st, w,
-                       static_cast<const float*>(nullptr), wprep);
-  const int NP = (W + 4 + 31) / 32 * 32;
-  const size_t smem_r = size_t(2) * NP * kDyPS + size_t(2) * NP * kZS * sizeof(float);
-  const int per_cu = int(std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / smem_r)));
-  int chunks = std::max(1, std::min((H + 15) / 16, 256 * per_cu / std::max(B, 1)));
-  int rows = (H + chunks - 1) / chunks;
-  rows += rows & 1;                                   // pooling windows must not straddle chunks
-  chunks = (H + rows - 1) / rows;
-  C1BnArgs a{static_cast<const bf16*>(pre), static_cast<const bf16*>(dy_pooled), mean, invstd, gamma, beta, dropscale, sums,
-             float(1.0 / n_total), wprep, dx, static_cast<bf16*>(dpre_out), B, H, W, rows, nullptr};
-  SEPT_HIP(sept::allow_max_lds(reinterpret_cast<const void*>(&sept_conv1_dgrad_bnapply_kernel<false>)));
-  hipLaunchKernelGGL(sept_conv1_dgrad_bnapply_kernel<false>, dim3(chunks, B), dim3(256), smem_r, st, a);
-  return sept::launch_check("sept_conv1_dgrad_bnapply_kernel");
 }
 
 // ---- block 1's data gradient without any pre-activation-sized tensor ------------------------------------------------------
@@ -2305,10 +2074,10 @@ extern "C" int sept_conv1_backward_data_sparse(const void* dy_pooled, const void
   int rows = (H + chunks - 1) / chunks;
   rows += rows & 1;                                   // pooling windows must not straddle chunks
   chunks = (H + rows - 1) / rows;
-  C1BnArgs a{nullptr, static_cast<const bf16*>(dy_pooled), mean, invstd, gamma, nullptr, dropscale, sums,
-             float(1.0 / n_total), wprep, dx, nullptr, B, H, W, rows, static_cast<const unsigned char*>(idx_u8)};
-  SEPT_HIP(sept::allow_max_lds(reinterpret_cast<const void*>(&sept_conv1_dgrad_bnapply_kernel<true>)));
-  hipLaunchKernelGGL(sept_conv1_dgrad_bnapply_kernel<true>, dim3(chunks, B), dim3(256), smem_r, st, a);
+  C1BnArgs a{static_cast<const bf16*>(dy_pooled), invstd, gamma, dropscale, wprep, dx, B, H, W, rows,
+             static_cast<const unsigned char*>(idx_u8)};
+  SEPT_HIP(sept::allow_max_lds(reinterpret_cast<const void*>(&sept_conv1_dgrad_sparse_kernel)));
+  hipLaunchKernelGGL(sept_conv1_dgrad_sparse_kernel, dim3(chunks, B), dim3(256), smem_r, st, a);
   // image rows per workgroup: one four-pixel group per thread, within what kDenseStage elements per thread can stage
   const int drows = std::max(1, std::min(256 / std::max(1, W / 4 - 2), 256 * kDenseStage / (W + 8) - 8));
   int pitch = W + 8;

@@ -143,16 +143,12 @@ SIGNATURES = {
                                              [c_int] * 5 + [c_void_p]),
     "sept_bn_backward_sums_presummed": (c_int, [c_void_p] * 8 + [c_int, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 5 +
                                         [c_void_p]),
-    "sept_conv1_backward_data_bn": (c_int, [c_void_p] * 8 + [c_double] + [c_void_p] * 4 + [c_int] * 3 + [c_void_p]),
     "sept_bn_relu_pool_forward_argmax": (c_int, [c_void_p] * 8 + [c_int] * 5 + [c_void_p]),
     "sept_conv1_backward_data_sparse": (c_int, [c_void_p] * 10 + [c_double] + [c_void_p] * 4 + [c_int] * 3 + [c_void_p]),
     "sept_conv1_prep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "sept_conv1_fused_supported": (c_int, [c_int, c_int]),
-    "sept_conv1_stats_only": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p]),
     "sept_conv1_bn_relu_pool_forward": (c_int, [c_void_p] * 10 + [c_int] * 3 + [c_void_p]),
-    "sept_conv1_bn_relu_pool_backward_reduce": (c_int, [c_void_p] * 11 + [c_int] * 3 + [c_void_p]),
     "sept_bn_bwd_sums_from_partials": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "sept_conv1_bn_relu_pool_backward_apply": (c_int, [c_void_p] * 11 + [c_double, c_void_p] + [c_int] * 3 + [c_void_p]),
     "sept_conv1_pool_supported": (c_int, [c_int, c_int]),
     "sept_conv1_pool_backward_supported": (c_int, [c_int, c_int]),
     "sept_conv1_coef_floats": (c_size_t, []),

@@ -125,28 +125,6 @@ def trunk_params(model, head: str, att="model"):
                            training=model.training)
 
 
-def prepare_operands(P, W_in):
-    """Build every derived operand of a network whose weights changed since the last build: conv1's operand block, the
-    bf16 conv operands in both orientations, the packed GRU input matrices (the cache entries trunk_forward /
-    trunk_backward look up).  They depend on the weights only, so a step can build them beside its feature stage instead
-    of in front of each consumer: nine 5 us launches that otherwise sit on the trainable branch's critical chain."""
-    for li, cv in enumerate(P.convs):
-        if li == 0:
-            _conv1_operand(cv)
-        else:
-            _cached("convfwd", cv.weight, lambda cv=cv: ops.conv5x5_prep_weights(cv.weight, 0))
-            _cached("convdgrad", cv.weight, lambda cv=cv: ops.conv5x5_prep_weights(cv.weight, 1))
-    w = W_in
-    for pool in P.pools:
-        w //= pool
-    C = P.convs[-1].weight.shape[0]
-    r = P.rnn
-    for layer in range(2):
-        wif, wir = getattr(r, f"weight_ih_l{layer}"), getattr(r, f"weight_ih_l{layer}_reverse")
-        bif, bir = getattr(r, f"bias_ih_l{layer}"), getattr(r, f"bias_ih_l{layer}_reverse")
-        _cached_pair(f"wih_cat{layer}", wif, wir, lambda: _gru_cat_weights(wif, wir, bif, bir, layer, C, w))
-
-
 def _drop_mask(shape, device, p=DROP_P):
     """0 / (1/(1-p)) scale mask from the device's Philox stream (one HIP launch)."""
     return ops.rng(device, "dropout").dropout_mask(shape, p)
@@ -190,8 +168,7 @@ def _drop_masks(device, specs, site=None):
 def step_masks(P, B, H, device, inj=None, site=None):
     """Every dropout mask one training-mode forward of network P needs at batch B and input height H, drawn up front in
     one launch per distinct p (keys: ('c', layer), 'rnn', 'dense'); entries covered by `inj` (explicit test masks) are left
-    out.  trunk_forward draws them itself unless they are handed in (grl_train_step draws both networks' masks on its
-    random-number chain, beside the feature stage)."""
+    out."""
     inj = inj or {}
     t_out = H
     for pool in P.pools:
@@ -227,28 +204,20 @@ def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None, gfeat=Non
         masks = step_masks(P, B, H, dev, inj, rng_site) if train else {}
     for li, (cv, bn, pool) in enumerate(zip(P.convs, P.bns, P.pools)):
         cout = cv.weight.shape[0]
-        if li == 0 and pool == 2 and not _SYNC_BN["on"] and ops.conv1_fused_supported(H, W) and \
-                (L1_FUSED == "always" or (L1_FUSED == "eval" and not bn.training and not need_grad)):
-            # layer 1 without its 32-channel pre-activation tensor (16x the input): conv1 -> BatchNorm -> ReLU -> pool
-            # -> dropout in registers.  With running statistics (inference) that is ONE pass (67 us where conv1 +
-            # BatchNorm take 57 + 44 at 224 windows).  In training it needs a statistics-only pass first and the
-            # backward pass recomputes conv1 twice more; measured (round 2, gpurun_out/r2f): each conv1 evaluation costs
-            # ~40 us of VALU work (im2col + hi/lo operand split), so four of them (43 + 67 + 196 + 192 us) lose to
-            # streaming the 229 MB tensor (70 + 44 + 41 + 85 us) -- SEPT_L1_FUSED=always keeps that form testable.
-            mom = bn.momentum if bn.momentum is not None else 0.1
+        if li == 0 and pool == 2 and not bn.training and not need_grad and ops.conv1_fused_supported(H, W):
+            # inference: block 1 in ONE pass with the running statistics -- conv1 -> BatchNorm -> ReLU -> pool (-> dropout
+            # scale) in registers, no 32-channel pre-activation tensor (67 us where conv1 + BatchNorm take 57 + 44 at 224
+            # windows).  (Round 2 also ran this form in training, by recomputation; it lost to streaming the tensor and then
+            # to the pool-first form below: DESIGN.md section 8.)
             c1p = _conv1_operand(cv)
-            if bn.training:
-                mean, invstd = ops.conv1_stats_only(x, cv.weight, cv.bias, bn.running_mean, bn.running_var,
-                                                    bn.num_batches_tracked, mom, bn.eps, prep=c1p)
-            else:
-                mean, invstd = ops.bn_eval_stats(bn.running_mean, bn.running_var, bn.eps)
+            mean, invstd = ops.bn_eval_stats(bn.running_mean, bn.running_var, bn.eps)
             drop = None
             if train and (P.drop_ps[li] > 0 or "drop2d" in inj):
                 d2 = inj.get("drop2d")
                 drop = d2[li] if d2 is not None else masks[("c", li)]
             out = ops.conv1_bn_relu_pool_forward(x, cv.weight, cv.bias, mean, invstd, bn.weight, bn.bias, drop, prep=c1p)
             S.blocks.append(SimpleNamespace(inp=None, pre=None, ext=None, out=out, mean=mean, invstd=invstd, drop=drop, pool=pool,
-                                            h=h, w=w, bn_train=bn.training, sync=False, l1_fused=True, idx=None))
+                                            h=h, w=w, bn_train=False, sync=False, idx=None))
             act = out
             h, w = h // pool, w // pool
             continue
@@ -270,7 +239,7 @@ def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None, gfeat=Non
             defer = BN_ACT_IN_CONV and li + 1 < len(P.convs) and not P.convs[li + 1].weight.requires_grad
             out = None if defer else ops.bn_relu_ext_forward(ext, None, mean, invstd, bn.weight, bn.bias, drop)   # idx stays pure positions
             S.blocks.append(SimpleNamespace(inp=None, pre=None, ext=ext, out=out, mean=mean, invstd=invstd, drop=drop, pool=pool,
-                                            h=h, w=w, bn_train=True, sync=False, l1_fused=False, idx=idx))
+                                            h=h, w=w, bn_train=True, sync=False, idx=idx))
             act = out
             h, w = h // pool, w // pool
             continue
@@ -330,7 +299,7 @@ def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None, gfeat=Non
         else:
             out = ops.bn_relu_pool_forward(pre, mean, invstd, bn.weight, bn.bias, drop, pool)
         S.blocks.append(SimpleNamespace(inp=act, pre=pre, ext=None, out=out, mean=mean, invstd=invstd, drop=drop, pool=pool, h=h,
-                                        w=w, bn_train=bn.training, sync=_SYNC_BN["on"] and bn.training, l1_fused=False, idx=idx))
+                                        w=w, bn_train=bn.training, sync=_SYNC_BN["on"] and bn.training, idx=idx))
         act = out
         h, w = h // pool, w // pool
     # ---- GRU: (B, T=h, D = w*C) with NHWC feature order (w, c) ----
@@ -559,18 +528,9 @@ def trunk_backward(S, P, dlogits, need_wgrad=True, need_dx=True, sum_dx=False):
 WGRAD_STREAM = os.environ.get("SEPT_WGRAD_STREAM", "1") != "0"
 # BatchNorm backward: channel sums from the pooled tensors (SEPT_BN_POOLED=0: from every window of the pre-activations)
 BN_POOLED_SUMS = os.environ.get("SEPT_BN_POOLED", "1") != "0"
-# layer 1 (conv1 + BatchNorm + ReLU + pool) without its pre-activation tensor: "eval" (default) = only with running
-# statistics and no backward pass, "always" / "never" (SEPT_L1_FUSED=1 / 0) force it
-L1_FUSED = {"0": "never", "1": "always", "always": "always", "never": "never"}.get(os.environ.get("SEPT_L1_FUSED", "eval"), "eval")
 # BatchNorm backward sums of blocks 1 / 2 from the epilogue of the data-gradient conv that produces their dy
 # (SEPT_BN_DGRAD_SUMS=0: the separate reduce pass over the pooled tensors)
 BN_SUMS_IN_DGRAD = os.environ.get("SEPT_BN_DGRAD_SUMS", "1") != "0"
-# block 1's BatchNorm backward apply pass inside conv1's data gradient (sept_conv1_backward_data_bn: no gradient-of-
-# conv1-output tensor for the frozen network).  OFF by default: measured (round 2, gpurun_out/r2t) 211 us against
-# 174 us for the separate apply + data-gradient launches at 224 windows -- the apply arithmetic sits in the row
-# loader's serial chain (load -> apply -> LDS -> MFMA -> LDS -> gather) and lengthens every step more than the
-# 229 MB it saves; SEPT_BN_APPLY_DGRAD=1 selects it (tests keep it correct).
-BN_APPLY_IN_DGRAD = os.environ.get("SEPT_BN_APPLY_DGRAD", "0") == "1"
 # block 1's backward pass of a network WITHOUT conv1 weight gradient (the frozen emotion model) from the pooled gradient +
 # recorded arg-max positions + the input, no pre-activation-sized tensor (ops.conv1_backward_data_sparse; -1.7 % step
 # time).  SEPT_L1_SPARSE=0: BatchNorm backward apply pass + dense data gradient as for the trainable one
@@ -625,23 +585,11 @@ CONV_FUSED_STATS = os.environ.get("SEPT_CONV_STATS", "1") != "0"
 NO_WGRAD_FORK = set()
 _WG_STREAMS = {}
 _DEFERRED = {"on": False, "pending": []}
-_BWD_ORDER = int(os.environ.get("SEPT_BWD_ORDER", "0"))
-# functional.grl_train_step: 1 = each branch runs forward -> loss -> backward as one chain (the emotion branch does not
-# wait for the gender forward); 0 = the branches meet after their forward passes (measured faster: DESIGN.md section 8)
-DECOUPLED_BRANCHES = os.environ.get("SEPT_DECOUPLED", "0") == "1"
-# MFMA-heavy weight gradients of a branch network on the (deferred) side stream too
-BIG_WGRAD_SIDE = os.environ.get("SEPT_WGRAD_BIG_SIDE", "0") == "1"
 # functional.grl_train_step: this many of the trainable branch's 5 x 5 weight gradients (layer 3 first) run inside the
 # FROZEN branch's chain (in front of its block 1) instead of inside their own: the trainable branch is the longer one by
 # exactly its weight gradients (measured: it finished 240 us after the frozen one), so the two backward chains then end
 # within 90 us of each other (-1.2 % step time; 2 or 3 moved: no better).  SEPT_WGRAD_TAIL=0 keeps them at home.
 TAIL_WGRADS = int(os.environ.get("SEPT_WGRAD_TAIL", "1"))
-# functional.grl_train_step experiments: the trainable network's weight-only operand builds / both
-# networks' dropout masks on the random-number chain beside the feature stage instead of in front of their consumers.
-# Each takes launches off a critical chain, and each measured SLOWER (2.32 / 2.28 against 2.265 ms per step in one call):
-# they lengthen the chain the cloak waits for and change the captured graph's shape.  Off.
-HOIST_OPERANDS = os.environ.get("SEPT_HOIST_OPERANDS", "0") == "1"
-HOIST_MASKS = os.environ.get("SEPT_HOIST_MASKS", "0") == "1"
 _TAIL_WGRADS = {"list": None, "max": 0, "ran": 0, "taken": 0}
 
 # HIP-graph capture and side streams.  On ROCm 7.2 hipStreamEndCapture aborts the PROCESS (core dump, no error
@@ -722,7 +670,7 @@ class _SideQueue:
 
     def big(self, fn, *operands):
         """MFMA-heavy weight gradients: on the side stream of a top-level network only"""
-        return fn() if (self.wg is None or (self.nested and not BIG_WGRAD_SIDE)) else self._run(fn, operands)
+        return fn() if (self.wg is None or self.nested) else self._run(fn, operands)
 
     def finish(self):
         if self.wg is None:
@@ -856,34 +804,14 @@ def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq, go
                 put(bn.weight, dgamma)
                 put(bn.bias, dbeta)
             continue
-        if (li == 0 and BN_APPLY_IN_DGRAD and need_dx and not blk.l1_fused and not blk.sync and blk.pool == 2
-                and blk.pre.shape[1] % 2 == 0 and blk.pre.shape[2] % 2 == 0 and blk.pre.shape[2] <= 128):
-            # block 1: the BatchNorm backward apply pass lives in conv1's data-gradient row loader -- the 64-byte-per-
-            # pixel gradient of conv1's output is only materialised when conv1's weight gradient needs it
-            want_w = need_wgrad and cv.weight.requires_grad
-            dx, dpre, dgamma, dbeta = ops.conv1_backward_data_bn(
-                blk.pre, dact, blk.mean, blk.invstd, bn.weight, bn.bias, blk.drop, cv.weight, presums=presums,
-                want_dpre=want_w, need_param_grads=want_bn, out_gamma=gout(bn.weight) if want_bn else None,
-                out_beta=gout(bn.bias) if want_bn else None, prep=_conv1_operand(cv),
-                y=blk.out if BN_POOLED_SUMS else None)
-            if want_bn:
-                put(bn.weight, dgamma)
-                put(bn.bias, dbeta)
-            if want_w:
-                dw, _ = sq.big(lambda dpre=dpre: ops.conv1_backward_weight(S.x, dpre, need_bias=False, out_w=gout(cv.weight)),
-                               dpre, S.x)
-                put(cv.weight, dw)
-                if cv.bias is not None:     # in front of a training-mode BatchNorm: exactly zero (see zero_bias_grad)
-                    put(cv.bias, zero_bias_grad(cv.bias))
-            continue
         if (li >= 1 and BN_APPLY_IN_CONV and not (need_wgrad and cv.weight.requires_grad) and blk.pool == 2 and not blk.sync
-                and not blk.l1_fused and blk.pre.shape[1] % 2 == 0 and blk.pre.shape[2] % 2 == 0):
+                and blk.pre.shape[1] % 2 == 0 and blk.pre.shape[2] % 2 == 0):
             prev, pbn, cin_ = S.blocks[li - 1], P.bns[li - 1], cv.weight.shape[1]
             ep = None   # what the conv's epilogue leaves for the block in front (as the unfused calls below)
             if prev.ext is not None:
                 if cin_ <= 32 and tuple(prev.ext.shape) == tuple(blk.pre.shape[:3]) + (cin_,):
                     ep = ("ext", prev.ext, prev.mean, prev.invstd, pbn.weight, pbn.bias, prev.drop)
-            elif (BN_SUMS_IN_DGRAD and BN_POOLED_SUMS and prev.bn_train and not prev.sync and not prev.l1_fused
+            elif (BN_SUMS_IN_DGRAD and BN_POOLED_SUMS and prev.bn_train and not prev.sync
                     and prev.pool == 2 and tuple(prev.out.shape) == tuple(blk.pre.shape[:3]) + (cin_,)):
                 ep = ("pool", prev.out, pbn.weight, pbn.bias, prev.drop)
             if ep is not None and not ops.conv5x5_bnapply_supported(blk.pre, cin_, True):
@@ -904,13 +832,7 @@ def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq, go
                 dact, presums = ops.conv5x5_dgrad_bnapply(blk.pre, dact, sums, blk.mean, blk.invstd, bn.weight, bn.bias,
                                                           blk.drop, wtd, ep)
                 continue
-        if blk.l1_fused:
-            dpre, dgamma, dbeta = ops.conv1_bn_relu_pool_backward(S.x, cv.weight, cv.bias, dact, blk.mean, blk.invstd,
-                                                                  bn.weight, bn.bias, blk.drop, need_param_grads=want_bn,
-                                                                  out_gamma=gout(bn.weight) if want_bn else None,
-                                                                  out_beta=gout(bn.bias) if want_bn else None,
-                                                                  prep=_conv1_operand(cv))
-        elif presums is not None:
+        if presums is not None:
             dpre, dgamma, dbeta = ops.bn_relu_pool_backward_presummed(dact, blk.pre, blk.mean, blk.invstd, bn.weight,
                                                                       bn.bias, blk.drop, presums, blk.pool,
                                                                       need_param_grads=want_bn,
@@ -965,8 +887,7 @@ def _trunk_backward_rnn_conv(S, P, dout, grads, put, need_wgrad, need_dx, sq, go
                                                              prev.drop)
                 if dact is None:
                     dact, presums = ops.conv5x5(dpre, wtd), None
-            elif (BN_SUMS_IN_DGRAD and BN_POOLED_SUMS and prev.bn_train and not prev.sync and not prev.l1_fused
-                    and prev.pool == 2):
+            elif BN_SUMS_IN_DGRAD and BN_POOLED_SUMS and prev.bn_train and not prev.sync and prev.pool == 2:
                 # the data-gradient conv's epilogue also forms the backward sums of the BatchNorm in front (from its
                 # output tile and that block's pooled activation): that block's reduce pass over y / dy disappears
                 pbn = P.bns[li - 1]
@@ -1140,16 +1061,10 @@ class GrlPairFn(torch.autograd.Function):
             s2.wait_stream(cur)
             _DEFERRED["on"] = WGRAD_STREAM     # the branches' small weight gradients fork; joined HERE, on `cur`
             try:
-                if _BWD_ORDER == 1:
-                    with torch.cuda.stream(s1):
-                        dx1, g1 = trunk_backward(S1, P1, d1, need_wgrad=ctx.need_w[0], need_dx=need_dx, sum_dx=True)
-                    with torch.cuda.stream(s2):
-                        dx2, g2 = trunk_backward(S2, P2, d2, need_wgrad=ctx.need_w[1], need_dx=need_dx, sum_dx=True)
-                else:
-                    with torch.cuda.stream(s2):    # the gender branch first: its recurrent chain is the critical path
-                        dx2, g2 = trunk_backward(S2, P2, d2, need_wgrad=ctx.need_w[1], need_dx=need_dx, sum_dx=True)
-                    with torch.cuda.stream(s1):
-                        dx1, g1 = trunk_backward(S1, P1, d1, need_wgrad=ctx.need_w[0], need_dx=need_dx, sum_dx=True)
+                with torch.cuda.stream(s2):    # the gender branch first: its recurrent chain is the critical path
+                    dx2, g2 = trunk_backward(S2, P2, d2, need_wgrad=ctx.need_w[1], need_dx=need_dx, sum_dx=True)
+                with torch.cuda.stream(s1):
+                    dx1, g1 = trunk_backward(S1, P1, d1, need_wgrad=ctx.need_w[0], need_dx=need_dx, sum_dx=True)
             finally:
                 _DEFERRED["on"] = prev
             cur.wait_stream(s1)
@@ -1217,26 +1132,14 @@ def grl_train_step(model, x, labels_emo, labels_gen, weights, gender_lambda, sca
         def draws():
             ops.begin_step(dev)
             return noise._epsilon(1)
-        masks1 = masks2 = None
         if two and before_cloak is not None:
             s2.wait_stream(cur)             # recorded BEFORE the feature stage is enqueued: s2 runs beside it
             x = before_cloak()
             with torch.cuda.stream(s2):
                 eps = draws()
-                Pe, Pg = trunk_params(emo, 'emotion', att), trunk_params(gen, 'gender', att)
-                if HOIST_MASKS:      # both networks' dropout masks (in the module's order: emotion, gender)
-                    if Pe.training:
-                        masks1 = step_masks(Pe, x.shape[0], x.shape[-2], dev, site=SITE_EMOTION)
-                    if Pg.training:
-                        masks2 = step_masks(Pg, x.shape[0], x.shape[-2], dev, site=SITE_GENDER)
-                if HOIST_OPERANDS:   # the trainable network's weight-only operand builds
-                    prepare_operands(Pg, rhos.shape[-1])
             cur.wait_stream(s2)
             if not capturing:
                 eps.record_stream(cur)
-                for mk, st_ in ((masks1, s1), (masks2, s2)):
-                    for t in (mk or {}).values():
-                        t.record_stream(st_)
         else:
             eps = draws()
             if before_cloak is not None:
@@ -1264,7 +1167,7 @@ def grl_train_step(model, x, labels_emo, labels_gen, weights, gender_lambda, sca
         def fwd(P):
             tag = "emotion" if P is P1 else "gender"
             ops.stamp(tag + " forward starts")
-            r = trunk_forward(xw, P, pool, need_grad=True, gfeat=global_feature, masks=masks1 if P is P1 else masks2,
+            r = trunk_forward(xw, P, pool, need_grad=True, gfeat=global_feature,
                               rng_site=SITE_EMOTION if P is P1 else SITE_GENDER, injected=inj1 if P is P1 else inj2)
             ops.stamp(tag + " forward done")
             return r
@@ -1279,12 +1182,13 @@ def grl_train_step(model, x, labels_emo, labels_gen, weights, gender_lambda, sca
             ops.stamp(tag + " backward done")
             return r
 
-        # (network, labels, loss coefficient, loss slot, weight gradients?, carries the scale term?); _BWD_ORDER 0 enqueues the
-        # gender chain first -- the dropout draws of a network use its own Philox call site (SITE_EMOTION / SITE_GENDER), so
-        # the masks do not depend on the enqueue order, nor on hand-scheduled vs autograd, capture vs eager
+        # (network, labels, loss coefficient, loss slot, weight gradients?, carries the scale term?); the gender chain is
+        # enqueued first (enqueueing the emotion branch first measured +2 %) -- the dropout draws of a network use its own
+        # Philox call site (SITE_EMOTION / SITE_GENDER), so the masks do not depend on the enqueue order, nor on
+        # hand-scheduled vs autograd, capture vs eager
         emo_args = (P1, labels_emo, 1.0, loss_a, need_w1, True)
         gen_args = (P2, labels_gen, float(gender_lambda), loss_b, need_w2, False)
-        order = ((s1, emo_args), (s2, gen_args)) if _BWD_ORDER == 1 else ((s2, gen_args), (s1, emo_args))
+        order = ((s2, gen_args), (s1, emo_args))
         res = {}
         prev = _DEFERRED["on"]
         if two:
@@ -1302,32 +1206,28 @@ def grl_train_step(model, x, labels_emo, labels_gen, weights, gender_lambda, sca
                 xn.record_stream(s2)
             _DEFERRED["on"] = WGRAD_STREAM     # the gender branch's small weight gradients fork; joined below, on `cur`
             try:
-                if DECOUPLED_BRANCHES:         # forward -> loss -> backward as one chain per branch
+                # the branches meet after their forward passes, as on the autograd tape (each branch as ONE chain forward ->
+                # loss -> backward measured 4 % slower: the graph executor then puts the two long chains on one queue)
+                saved = {}
+                for st, (P, *_r) in order:
+                    with torch.cuda.stream(st):
+                        saved[st] = fwd(P)
+                join()
+                ops.stamp("forward joined")
+                fork()
+                # the trainable branch first (it hands over weight gradients), the frozen branch picks them up in
+                # front of its block 1; whatever is left runs behind the frozen branch
+                _TAIL_WGRADS.update(list=[] if TAIL_WGRADS > 0 else None, max=TAIL_WGRADS, ran=0, taken=0)
+                try:
                     for st, (P, lab, coef, slot, nw, sc) in order:
                         with torch.cuda.stream(st):
-                            logits, S = fwd(P)
+                            logits, S = saved[st]
                             res[st] = (logits,) + bwd(P, logits, S, lab, coef, slot, nw, sc)
-                else:                          # the branches meet after their forward passes, as on the autograd tape
-                    saved = {}
-                    for st, (P, *_r) in order:
-                        with torch.cuda.stream(st):
-                            saved[st] = fwd(P)
-                    join()
-                    ops.stamp("forward joined")
-                    fork()
-                    # the trainable branch first (it hands over weight gradients), the frozen branch picks them up in
-                    # front of its block 1; whatever is left runs behind the frozen branch
-                    _TAIL_WGRADS.update(list=[] if TAIL_WGRADS > 0 else None, max=TAIL_WGRADS, ran=0, taken=0)
-                    try:
-                        for st, (P, lab, coef, slot, nw, sc) in order:
-                            with torch.cuda.stream(st):
-                                logits, S = saved[st]
-                                res[st] = (logits,) + bwd(P, logits, S, lab, coef, slot, nw, sc)
-                        with torch.cuda.stream(s1):
-                            _run_tail_wgrads(dev)
-                    finally:
-                        _TAIL_WGRADS["list"] = None
-                    saved.clear()
+                    with torch.cuda.stream(s1):
+                        _run_tail_wgrads(dev)
+                finally:
+                    _TAIL_WGRADS["list"] = None
+                saved.clear()
             finally:
                 _DEFERRED["on"] = prev
             join()
@@ -1428,173 +1328,6 @@ def syn_train_step(model, x, labels, weights, scale_lamda, use_scale_term=True, 
             if p_.requires_grad:
                 p_.grad = g.view(p_.shape)
     return loss, logits
-
-
-class SegmentSched:
-    """Capture of a multi-stream step as ONE HIP GRAPH PER CHAIN, replayed on real streams.
-
-    A single captured graph leaves the placement of its parallel chains to the HIP-graph executor, which deals nodes to
-    four hardware queues by the graph's shape ((queue + 1) mod 4 per extra edge of a depth-first walk): any change of
-    the graph reshuffles which chains share an in-order queue, and two long chains on one queue serialise (measured:
-    2.3 -> 2.6-2.7 ms per step after moving nine small launches).  Here every `run(stream, fn)`
-    records fn's launches into a graph of its own (its own memory pool: concurrently replayed graphs must not recycle
-    each other's temporaries) and `wait(a, b)` becomes a real stream dependency at replay time, so the chains run on the
-    streams -- hence the hardware queues -- the code names."""
-
-    def __init__(self, device):
-        self.device = device
-        self.main = torch.cuda.Stream(device=device)
-        self.plan, self.keep = [], []
-
-    def run(self, stream, fn):
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"), capture_origin():
-            r = fn()
-        self.plan.append(("launch", g, stream))
-        self.keep.append(r)       # results cross segment boundaries: they stay allocated in their segment's pool
-        return r
-
-    def wait(self, a, b):
-        self.plan.append(("wait", a, b))
-
-    def replay(self):
-        cur = torch.cuda.current_stream(self.device)
-        self.main.wait_stream(cur)
-        for op, x, y in self.plan:
-            if op == "wait":
-                x.wait_stream(y)
-            else:
-                with torch.cuda.stream(y):
-                    x.replay()
-        cur.wait_stream(self.main)
-
-
-def grl_train_step_segmented(sched, model, x, labels_emo, labels_gen, weights, gender_lambda, scale_lamda,
-                             use_scale_term=True, mask=None, pooling="mean", global_feature=None, before_cloak=None,
-                             tail=None):
-    """grl_train_step recorded through a SegmentSched: the same kernels in the same per-stream order, as six graphs
-    (draws + weight-only operand builds | features + cloak | two forward chains | two loss + backward chains | cloak
-    backward + `tail`, e.g. gradient placement and the optimiser).  Capture only -- nothing executes here."""
-    noise, emo, gen = model.intermed, model.original_model, model.gender_model
-    att = emo.att
-    pool = "flatten" if pooling is None else "mean"
-    locs, rhos = noise.locs, noise.rhos
-    dev = rhos.device
-    cur = sched.main
-    s1, s2 = branch_streams(dev)
-    P1, P2 = trunk_params(emo, 'emotion', att), trunk_params(gen, 'gender', att)
-    need_dx = locs.requires_grad or rhos.requires_grad
-    need_w1 = any(p.requires_grad for p in _param_list(P1))
-    need_w2 = any(p.requires_grad for p in _param_list(P2))
-    smin, smax, lam = float(noise.min_scale), float(noise.max_scale), float(gen.conv[0].lambda_)
-    m = None if mask is None else mask.to(dev, torch.float32).contiguous()
-    st = SimpleNamespace()
-    with torch.no_grad():
-        def draws():        # s2: the step's random numbers and its weight-only work, beside the feature stage
-            ops.begin_step(dev)
-            st.eps = noise._epsilon(1)
-            w_in = rhos.shape[-1]
-            prepare_operands(P2, w_in)
-            prepare_operands(P1, w_in)
-
-        def features():     # main
-            ops.stamp("step start", dev)
-            st.x = before_cloak() if before_cloak is not None else x
-
-        def cloak():        # main
-            shape = st.x.shape
-            st.B = B = shape[0]
-            if isinstance(st.x, ops.LazyWindows):
-                st.xn = ops.window_norm_cloak(st.x, locs.detach(), rhos.detach(), st.eps, m, smin, smax)
-            else:
-                st.xn = ops.cloak_forward(st.x.detach().float().contiguous().view(B, -1), locs.detach(), rhos.detach(), st.eps,
-                                          m, smin, smax)
-            st.xw = st.xn.view(B, shape[-2], shape[-1])
-            st.scale_mean = None
-            if use_scale_term and float(scale_lamda) != 0.0:
-                _, st.scale_mean = ops.cloak_scales(rhos.detach(), smin, smax, want_scales=False, want_mean=True)
-            st.loss_a = torch.empty((), dtype=torch.float32, device=dev)
-            st.loss_b = torch.empty((), dtype=torch.float32, device=dev)
-            ops.stamp("cloak forward done")
-
-        def fwd(P, tag):
-            def body():
-                ops.stamp(tag + " forward starts")
-                r = trunk_forward(st.xw, P, pool, need_grad=True, gfeat=global_feature,
-                                  rng_site=SITE_EMOTION if P is P1 else SITE_GENDER)
-                ops.stamp(tag + " forward done")
-                return r
-            return body
-
-        def bwd(P, tag, saved, labels, coef, slot_name, need_w, with_scale):
-            def body():
-                logits, S = saved()
-                slot = getattr(st, slot_name)
-                ops.stamp(tag + " backward starts")
-                d = ops.cross_entropy(logits, labels, weights, coef / st.B, slot)
-                if with_scale and st.scale_mean is not None:
-                    ops.loss_sub_log(slot, st.scale_mean, float(scale_lamda))
-                prev = _DEFERRED["on"]
-                _DEFERRED["on"] = WGRAD_STREAM      # small weight gradients fork inside this segment ...
-                try:
-                    r = trunk_backward(S, P, d, need_wgrad=need_w, need_dx=need_dx, sum_dx=True) if (need_w or need_dx) \
-                        else (None, {})
-                finally:
-                    _DEFERRED["on"] = prev
-                here = torch.cuda.current_stream(dev)
-                for wg, _keep in _DEFERRED["pending"]:
-                    here.wait_stream(wg)            # ... and rejoin its capture stream before it ends
-                _DEFERRED["pending"].clear()
-                ops.stamp(tag + " backward done")
-                return (logits,) + r
-            return body
-
-        def last():         # main
-            (l1, dx1, g1), (l2, dx2, g2) = st.r1, st.r2
-            if need_dx:
-                da, db_ = batch_sum_pair(dx1, dx2)
-                dlocs, drhos = ops.cloak_backward(da, db_, -lam, rhos.detach(), st.eps, m, smin,
-                                                  smax, scale_lambda=float(scale_lamda) if st.scale_mean is not None else 0.0,
-                                                  scale_mean=st.scale_mean, need_locs=locs.requires_grad,
-                                                  need_rhos=rhos.requires_grad,
-                                                  out_locs=grad_out(locs) if locs.requires_grad else None,
-                                                  out_rhos=grad_out(rhos) if rhos.requires_grad else None)
-                if locs.requires_grad:
-                    locs.grad = dlocs
-                if rhos.requires_grad:
-                    rhos.grad = drhos
-            st.loss = ops.add(st.loss_a, st.loss_b)
-            ops.stamp("gradients done")
-            for grads in (g1, g2):
-                for p, g in grads.items():
-                    if p.requires_grad:
-                        p.grad = g.view(p.shape)
-            if tail is not None:
-                tail()
-
-        sched.wait(s2, cur)
-        sched.run(s2, draws)
-        if before_cloak is not None:
-            sched.run(cur, features)
-        else:
-            st.x = x
-        sched.wait(cur, s2)
-        sched.run(cur, cloak)
-        sched.wait(s1, cur)
-        sched.wait(s2, cur)
-        st.f2 = sched.run(s2, fwd(P2, "gender"))
-        st.f1 = sched.run(s1, fwd(P1, "emotion"))
-        if not DECOUPLED_BRANCHES:      # the branches meet after their forward passes (the schedule measured faster)
-            sched.wait(cur, s1)
-            sched.wait(cur, s2)
-            sched.wait(s1, cur)
-            sched.wait(s2, cur)
-        st.r2 = sched.run(s2, bwd(P2, "gender", lambda: st.f2, labels_gen, float(gender_lambda), "loss_b", need_w2, False))
-        st.r1 = sched.run(s1, bwd(P1, "emotion", lambda: st.f1, labels_emo, 1.0, "loss_a", need_w1, True))
-        sched.wait(cur, s1)
-        sched.wait(cur, s2)
-        sched.run(cur, last)
-    return st.loss, st.r1[0], st.r2[0]
 
 
 class ScalesFn(torch.autograd.Function):

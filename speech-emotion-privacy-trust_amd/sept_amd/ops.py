@@ -266,27 +266,10 @@ def conv1_fused_supported(H, W):
     return bool(lib.sept_conv1_fused_supported(int(H), int(W)))
 
 
-def conv1_stats_only(x, w, bias, bn_running_mean=None, bn_running_var=None, bn_num_batches_tracked=None, momentum=0.1,
-                     eps=1e-5, prep=None):
-    """Batch statistics of conv1's output without storing it: (mean, invstd); the running buffers are updated."""
-    require_cuda(x, w)
-    B, H, W = x.shape
-    wptr, wp = _c1w(x, w, prep)
-    nparts = lib.sept_conv1_stats_parts(B, H)
-    parts = workspace("conv1_stats", nparts * 64, x.device)
-    check(lib.sept_conv1_stats_only(x.data_ptr(), wptr, _p(bias), wp.data_ptr(), parts.data_ptr(), B, H, W, _s(x)),
-          "sept_conv1_stats_only")
-    mean = torch.empty(32, dtype=torch.float32, device=x.device)
-    invstd = torch.empty_like(mean)
-    check(lib.sept_bn_stats_from_partials(parts.data_ptr(), nparts, B * H * W, 32, mean.data_ptr(), invstd.data_ptr(),
-                                          _p(bn_running_mean), _p(bn_running_var), _p(bn_num_batches_tracked),
-                                          float(momentum), float(eps), _s(x)), "sept_bn_stats_from_partials")
-    return mean, invstd
-
-
 def conv1_bn_relu_pool_forward(x, w, bias, mean, invstd, gamma, beta, dropscale=None, prep=None):
     """conv1 -> BatchNorm (given statistics) -> ReLU -> MaxPool 2x2 -> Dropout2d scale: x (B,H,W) fp32 ->
-    (B,H/2,W/2,32) bf16, the 32-channel pre-activation tensor never touching HBM."""
+    (B,H/2,W/2,32) bf16, the 32-channel pre-activation tensor never touching HBM.  The inference form of block 1
+    (running statistics, no backward); training uses the pool-first form (conv1_forward_pool)."""
     require_cuda(x, w, mean, invstd, gamma, beta)
     B, H, W = x.shape
     y = torch.empty((B, H // 2, W // 2, 32), dtype=torch.bfloat16, device=x.device)
@@ -295,37 +278,6 @@ def conv1_bn_relu_pool_forward(x, w, bias, mean, invstd, gamma, beta, dropscale=
                                               invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _p(dropscale),
                                               y.data_ptr(), B, H, W, _s(x)), "sept_conv1_bn_relu_pool_forward")
     return y
-
-
-def conv1_bn_relu_pool_backward(x, w, bias, dy, mean, invstd, gamma, beta, dropscale=None, need_param_grads=True,
-                                sync_group=None, sync=False, out_gamma=None, out_beta=None, prep=None):
-    """Backward of the fused layer-1 block by recomputation: dy (B,H/2,W/2,32) bf16 -> (dpre (B,H,W,32) bf16, dgamma,
-    dbeta).  Two passes over x (14 MB at the bench shape) + dy instead of passes over the 229 MB pre-activations."""
-    require_cuda(x, w, dy)
-    B, H, W = x.shape
-    wptr, wp = _c1w(x, w, prep)
-    nparts = lib.sept_conv1_stats_parts(B, H)
-    parts = workspace("conv1_bwd_parts", nparts * 64, x.device)
-    check(lib.sept_conv1_bn_relu_pool_backward_reduce(x.data_ptr(), wptr, _p(bias), wp.data_ptr(), dy.data_ptr(),
-                                                      mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                                      _p(dropscale), parts.data_ptr(), B, H, W, _s(x)),
-          "sept_conv1_bn_relu_pool_backward_reduce")
-    sums = torch.empty(64, dtype=torch.float32, device=x.device)
-    dgamma = dbeta = None
-    if need_param_grads:
-        dgamma = torch.empty(32, dtype=torch.float32, device=x.device) if out_gamma is None else out_gamma
-        dbeta = torch.empty(32, dtype=torch.float32, device=x.device) if out_beta is None else out_beta
-    check(lib.sept_bn_bwd_sums_from_partials(parts.data_ptr(), nparts, 32, sums.data_ptr(), _p(dgamma), _p(dbeta), _s(x)),
-          "sept_bn_bwd_sums_from_partials")
-    world = _allreduce_sum(sums, sync_group) if sync else 1
-    dpre = torch.empty((B, H, W, 32), dtype=torch.bfloat16, device=x.device)
-    check(lib.sept_conv1_bn_relu_pool_backward_apply(x.data_ptr(), 0 if prep is not None else w.data_ptr(), _p(bias),
-                                                     wp.data_ptr(), dy.data_ptr(),
-                                                     mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                                     _p(dropscale), sums.data_ptr(), float(B) * H * W * world,
-                                                     dpre.data_ptr(), B, H, W, _s(x)),
-          "sept_conv1_bn_relu_pool_backward_apply")
-    return dpre, dgamma, dbeta
 
 
 def conv1_backward_data(dy, w, prep=None):
@@ -478,42 +430,6 @@ def bn_relu_pool_backward_presummed(dy, x, mean, invstd, gamma, beta, dropscale,
                                                    ws.data_ptr(), dx.data_ptr(), _p(dgamma), _p(dbeta), B, H, W, C, pool,
                                                    _s(x)), "sept_bn_relu_pool_backward_presummed")
     return dx, dgamma, dbeta
-
-
-def conv1_backward_data_bn(pre, dy, mean, invstd, gamma, beta, dropscale, w, presums=None, want_dpre=False,
-                           need_param_grads=True, out_gamma=None, out_beta=None, prep=None, y=None):
-    """Backward of block 1 (BatchNorm + ReLU + MaxPool 2x2 + Dropout2d behind conv1) fused into conv1's data gradient:
-    pre (B,H,W,32) bf16 = conv1's stored output, dy (B,H/2,W/2,32) bf16 = gradient of the pooled activation.
-    Returns (dx (B,H,W) fp32, dpre or None, dgamma, dbeta); dpre (B,H,W,32) bf16 only when `want_dpre` (conv1's
-    weight gradient needs it).  `presums` = the (partials, count) a data-gradient conv left; else the sums are taken
-    here, from the pooled tensors when the pooled output `y` is given, from every window of `pre` otherwise."""
-    require_cuda(pre, dy, w)
-    B, H, W, C = pre.shape
-    dev = pre.device
-    ws = workspace("bn", lib.sept_bn_workspace_floats(C), dev)
-    sums = torch.empty(2 * C, dtype=torch.float32, device=dev)
-    dgamma = dbeta = None
-    if need_param_grads:
-        dgamma = torch.empty(C, dtype=torch.float32, device=dev) if out_gamma is None else out_gamma
-        dbeta = torch.empty(C, dtype=torch.float32, device=dev) if out_beta is None else out_beta
-    if presums is not None:
-        parts, nparts = presums
-        check(lib.sept_bn_backward_sums_presummed(dy.data_ptr(), pre.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
-                                                  gamma.data_ptr(), beta.data_ptr(), _p(dropscale), parts.data_ptr(), nparts,
-                                                  ws.data_ptr(), sums.data_ptr(), _p(dgamma), _p(dbeta), B, H, W, C, 2,
-                                                  _s(pre)), "sept_bn_backward_sums_presummed")
-    else:
-        check(lib.sept_bn_relu_pool_backward_reduce(dy.data_ptr(), pre.data_ptr(), _p(y), mean.data_ptr(), invstd.data_ptr(),
-                                                    gamma.data_ptr(), beta.data_ptr(), _p(dropscale), ws.data_ptr(),
-                                                    sums.data_ptr(), _p(dgamma), _p(dbeta), B, H, W, C, 2, _s(pre)),
-              "sept_bn_relu_pool_backward_reduce")
-    dx = torch.empty((B, H, W), dtype=torch.float32, device=dev)
-    dpre = torch.empty_like(pre) if want_dpre else None
-    wptr, wp = _c1w(pre, w, prep, "conv1_prep_bwd")
-    check(lib.sept_conv1_backward_data_bn(pre.data_ptr(), dy.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
-                                          beta.data_ptr(), _p(dropscale), sums.data_ptr(), float(B) * H * W, wptr, wp.data_ptr(),
-                                          dx.data_ptr(), _p(dpre), B, H, W, _s(pre)), "sept_conv1_backward_data_bn")
-    return dx, dpre, dgamma, dbeta
 
 
 def conv1_backward_data_sparse(x, pre, dy, idx, mean, invstd, gamma, beta, dropscale, w, bias, presums=None,

@@ -19,10 +19,6 @@ from .mel import LAYOUT_BTF, get_mel_plan
 # SEPT_HAND_SCHEDULED=0: the GRL step through the autograd tape (module forward, GrlStepLossFn, loss.backward()) instead
 # of functional.grl_train_step -- same kernels and gradient slots, the branches then meet at the loss
 HAND_SCHEDULED = os.environ.get("SEPT_HAND_SCHEDULED", "1") != "0"
-# SEPT_SEGMENTED=1: capture() records the GRL step as one HIP graph per chain and replays them on real streams
-# (functional.SegmentSched) instead of one graph whose chains the graph executor places
-SEGMENTED = os.environ.get("SEPT_SEGMENTED", "0") == "1"
-
 
 def _advance_rng(device):
     """New Philox sub-streams for this step (device-side counters: also valid inside a graph)."""
@@ -384,51 +380,8 @@ class GrlTrainer(_TrainerBase):
         process group the graph ends at the gradients, and replay() then runs the all-reduce and the update.
         Refill the inputs with copy_() between replays; call after at least one eager step.  `features` may be a
         callable producing the batch on the current stream (FusedPipeline)."""
-        if SEGMENTED and HAND_SCHEDULED and self._hand_schedulable(features) and SF.CONCURRENT_BRANCHES:
-            return self._capture_segmented(features, labels_emo, labels_gen, weights, mask, pooling, global_feature)
         return self._capture(lambda: self._forward_backward(features, labels_emo, labels_gen, weights, mask, pooling,
                                                             global_feature))
-
-    def _capture_segmented(self, features, labels_emo, labels_gen, weights, mask, pooling, global_feature=None):
-        """capture() as one graph per chain on real streams (functional.SegmentSched / grl_train_step_segmented)."""
-        if self.steps < 1:
-            raise RuntimeError("capture() needs at least one eager warm-up step (first-use setup, active-set discovery)")
-        self.model.train()
-        self.flat.zero_grad()
-        self._sync_lr()
-        self._ensure_state()
-        SF.set_sync_bn(self.sync_bn and self.world > 1, self.pg)
-        in_graph_update = self.world == 1
-        SF.invalidate_weight_cache()     # see _capture
-        sched = SF.SegmentSched(self.flat.flat.device)
-
-        def tail():
-            self.flat.gather_grads()
-            if in_graph_update:
-                self.optimizer_step()
-
-        fn = features if callable(features) else None
-        out = SF.grl_train_step_segmented(sched, self.model, None if fn else features, labels_emo, labels_gen, weights,
-                                          self.gender_lambda, self.scale_lamda, use_scale_term=not self.suppression,
-                                          mask=mask, pooling=pooling, global_feature=global_feature, before_cloak=fn,
-                                          tail=tail)
-        if in_graph_update:
-            self.steps -= 1            # the capture enqueued nothing
-        SF.invalidate_weight_cache()
-
-        def replay():
-            self._sync_lr()
-            sched.replay()
-            if in_graph_update:
-                self.steps += 1
-                SF.invalidate_weight_cache()
-            else:
-                self._allreduce_grads()
-                self.optimizer_step()
-            return out
-
-        replay.graph = sched
-        return replay
 
     @torch.no_grad()
     def eval_step(self, features, labels_emo, labels_gen, mask=None, pooling="mean", global_feature=None):

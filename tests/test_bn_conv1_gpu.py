@@ -201,11 +201,12 @@ def test_conv5x5_forward_with_fused_bn_statistics(B, H, W, cin, cout):
 
 @pytest.mark.parametrize("B,H,W", [(3, 200, 80), (2, 200, 128), (2, 34, 16), (5, 16, 48)])
 @pytest.mark.parametrize("drop", [False, True])
-def test_layer1_without_preactivation_tensor_equals_the_separate_kernels(B, H, W, drop):
-    """conv1 -> BatchNorm -> ReLU -> MaxPool 2x2 -> Dropout2d by recomputation (sept_conv1_stats_only,
-    sept_conv1_bn_relu_pool_forward / _backward_reduce / _backward_apply) against the separate conv1 + BatchNorm
-    kernels, which the tests above hold to torch: same statistics, same pooled output, same gradient of the
-    pre-activations, same dgamma / dbeta -- including a channel with a tiny and one with a negative gamma."""
+def test_block1_in_one_pass_with_given_statistics_equals_the_separate_kernels(B, H, W, drop):
+    """sept_conv1_bn_relu_pool_forward (the inference form of block 1: conv1 -> BatchNorm with given statistics -> ReLU ->
+    MaxPool 2x2 -> Dropout2d scale in registers, baseline_models.py:172-176 in eval mode) against the separate conv1 +
+    BatchNorm kernels, which the tests above hold to torch -- including a channel with a tiny and one with a negative
+    gamma -- and against plain torch."""
+    import torch.nn.functional as Fn
     from sept_amd import ops
     assert ops.conv1_fused_supported(H, W)
     assert not ops.conv1_fused_supported(H + 1, W) and not ops.conv1_fused_supported(H, W + 8)
@@ -217,65 +218,21 @@ def test_layer1_without_preactivation_tensor_equals_the_separate_kernels(B, H, W
     gamma[3], gamma[20] = 1e-5, -0.7
     gamma, beta = gamma.cuda(), (0.2 * torch.randn(32, generator=g)).cuda()
     dmask = ((torch.rand(B, 32, generator=g) > 0.2).float() * 1.25).cuda() if drop else None
-    dy = torch.randn(B, H // 2, W // 2, 32, generator=g).bfloat16().cuda()
-    # the separate kernels
-    rm, rv, nbt = torch.zeros(32).cuda(), torch.ones(32).cuda(), torch.zeros((), dtype=torch.int64).cuda()
-    pre, mean, invstd = ops.conv1_forward_stats(x, w, bias, rm, rv, nbt)
+    rmean, rvar = (0.1 * torch.randn(32, generator=g)).cuda(), (0.5 + torch.rand(32, generator=g)).cuda()
+    mean, invstd = ops.bn_eval_stats(rmean, rvar, 1e-5)
+    pre = ops.conv1_forward(x, w, bias)
     y = ops.bn_relu_pool_forward(pre, mean, invstd, gamma, beta, dmask, 2)
-    dpre, dgamma, dbeta = ops.bn_relu_pool_backward(dy, pre, mean, invstd, gamma, beta, dmask, 2)
-    # by recomputation
-    rm2, rv2, nbt2 = torch.zeros(32).cuda(), torch.ones(32).cuda(), torch.zeros((), dtype=torch.int64).cuda()
-    mean2, invstd2 = ops.conv1_stats_only(x, w, bias, rm2, rv2, nbt2)
-    assert torch.equal(mean, mean2) and torch.equal(invstd, invstd2) and torch.equal(rm, rm2) and torch.equal(rv, rv2)
-    assert int(nbt2) == 1
     y2 = ops.conv1_bn_relu_pool_forward(x, w, bias, mean, invstd, gamma, beta, dmask)
     assert y2.shape == y.shape
     differ = (y2.float() - y.float()).abs() > 0
     # the two paths fold the BatchNorm affine slightly differently (fma placement): a result may round the other way
     assert differ.float().mean() < 1e-3, float(differ.float().mean())
     assert ((y2.float() - y.float()).abs() <= y.float().abs() * 2 ** -7 + 1e-6).all()
-    dpre2, dgamma2, dbeta2 = ops.conv1_bn_relu_pool_backward(x, w, bias, dy, mean, invstd, gamma, beta, dmask)
-    assert dpre2.shape == dpre.shape
-    sg, sb = float(dgamma.abs().max()), float(dbeta.abs().max())
-    assert torch.allclose(dgamma2, dgamma, rtol=1e-3, atol=1e-4 * sg), (dgamma2 - dgamma).abs().max()
-    assert torch.allclose(dbeta2, dbeta, rtol=1e-3, atol=1e-4 * sb), (dbeta2 - dbeta).abs().max()
-    d, d2 = dpre.float(), dpre2.float()
-    # a window whose maximum is decided differently (the affine's last bit) moves one gradient to a neighbour
-    moved = ((d - d2).abs() > d.abs() * 2 ** -6 + 1e-3 * float(d.abs().max())).float().mean()
-    assert moved < 1e-3, float(moved)
-    assert float((d - d2).norm() / d.norm()) < 2e-2
-
-
-@pytest.mark.parametrize("B,H,W", [(3, 200, 80), (2, 200, 128), (2, 34, 16), (1, 6, 6), (3, 50, 22)])
-@pytest.mark.parametrize("drop", [False, True])
-@pytest.mark.parametrize("want_dpre", [False, True])
-def test_conv1_data_gradient_with_batchnorm_apply_folded_in(B, H, W, drop, want_dpre):
-    """sept_conv1_backward_data_bn (BatchNorm backward apply inside conv1's data-gradient row loader) against the
-    separate passes sept_bn_relu_pool_backward -> sept_conv1_backward_data, which the tests above hold to torch:
-    the same dgamma / dbeta, the same gradient of conv1's output (when asked for) up to a bf16 rounding of the
-    re-associated affine, the same dx."""
-    from sept_amd import ops
-    g = torch.Generator().manual_seed(H * W + B)
-    pre = (torch.randn(B, H, W, 32, generator=g) * 1.4 + 0.2).bfloat16().cuda()
-    w = (torch.randn(32, 1, 5, 5, generator=g) * 0.2).cuda()
-    gamma = 1 + 0.3 * torch.randn(32, generator=g)
-    gamma[7], gamma[20] = 3e-5, -0.6
-    gamma, beta = gamma.cuda(), (0.2 * torch.randn(32, generator=g)).cuda()
-    dmask = ((torch.rand(B, 32, generator=g) > 0.2).float() * 1.25).cuda() if drop else None
-    mean, invstd = ops.bn_stats(pre)
-    y = ops.bn_relu_pool_forward(pre, mean, invstd, gamma, beta, dmask, 2)
-    dy = torch.randn(B, H // 2, W // 2, 32, generator=g).bfloat16().cuda()
-    want_dpre_t, want_dg, want_db = ops.bn_relu_pool_backward(dy, pre, mean, invstd, gamma, beta, dmask, 2, y=y)
-    want_dx = ops.conv1_backward_data(want_dpre_t, w)
-    dx, dpre, dg, db = ops.conv1_backward_data_bn(pre, dy, mean, invstd, gamma, beta, dmask, w, want_dpre=want_dpre, y=y)
-    assert (dpre is not None) == want_dpre
-    assert torch.allclose(dg, want_dg, rtol=1e-5, atol=1e-6) and torch.allclose(db, want_db, rtol=1e-5, atol=1e-6)
-    if want_dpre:
-        d, d2 = want_dpre_t.float(), dpre.float()
-        assert ((d - d2).abs() <= d.abs() * 2 ** -7 + 1e-6 * float(d.abs().max())).all(), (d - d2).abs().max()
-    scale = float(want_dx.abs().max())
-    assert torch.allclose(dx, want_dx, rtol=2e-2, atol=2e-3 * scale), float((dx - want_dx).abs().max()) / scale
-    assert float((dx - want_dx).norm() / want_dx.norm()) < 3e-3
+    ref = Fn.max_pool2d(Fn.relu(Fn.batch_norm(Fn.conv2d(x[:, None], w, bias, padding=2), rmean, rvar, gamma, beta, False, 0.0, 1e-5)), 2)
+    if dmask is not None:
+        ref = ref * dmask[:, :, None, None]
+    ref = ref.permute(0, 2, 3, 1)
+    assert float((y2.float() - ref).norm() / ref.norm()) < 6e-3      # bf16 pre-activation + bf16 output
 
 
 @pytest.mark.parametrize("B, H, W, drop", [(3, 16, 24, False), (2, 20, 80, True), (4, 8, 16, True), (2, 200, 80, False),

@@ -249,10 +249,16 @@ def test_grl_train_step_vs_reference(F, G):
     _sim_step_check(grl, x, le, lg, wts, None, F, (p1, p2))
     assert all(p.grad is None for p in grl.original_model.parameters())
     # BatchNorm running statistics were updated for BOTH networks (F8)
+    if os.environ.get("SEPT_TEST_PRINT_NORMS"):
+        a_, b_ = grl.original_model.conv[1].running_mean.cpu().numpy(), G[k + "emo_bn1_running_mean"]
+        c_, d_ = grl.gender_model.conv[1][6].running_var.cpu().numpy(), G[k + "gen_bn2_running_var"]
+        print("BNSTATS mean abs", float(np.abs(a_ - b_).max()), "rel(>0.01)", float((np.abs(a_ - b_) / np.maximum(np.abs(b_), 1e-2)).max()),
+              "var rel", float((np.abs(c_ - d_) / np.abs(d_)).max()))
+    # (measured on MI355X: |d mean| 1.1e-6, 1.1e-4 relative; running_var 4.7e-4 - 5.2e-4 relative: bounds at ~2 x that)
     np.testing.assert_allclose(grl.original_model.conv[1].running_mean.cpu().numpy(), G[k + "emo_bn1_running_mean"],
-                               rtol=2e-2, atol=2e-3)
+                               rtol=2e-4, atol=2e-6)
     np.testing.assert_allclose(grl.gender_model.conv[1][6].running_var.cpu().numpy(), G[k + "gen_bn2_running_var"],
-                               rtol=2e-2)
+                               rtol=1e-3)
     assert int(grl.gender_model.conv[1][1].num_batches_tracked) == 1
 
 
@@ -314,8 +320,17 @@ def test_grl_train_step_ragged_batches(Bn, F):
     mo.grl_step_loss(q1, q2, le, lg, wts, 0.1, 0.05, ref).backward()
     close_logits(p1, q1.detach().numpy(), rtol=2 * SIM_RTOL, min_decided=0.0)
     close_logits(p2, q2.detach().numpy(), rtol=2 * SIM_RTOL, min_decided=0.0)
-    for name, (c, rel) in _grad_report(grl, ref).items():
-        assert c > (0.99 if _is_conv_stack(name) else 0.995), (name, c, rel)
+    rep = _grad_report(grl, ref)
+    if os.environ.get("SEPT_TEST_PRINT_NORMS"):
+        print("RAGGED", Bn, F, "min cos conv", min(c for n, (c, r) in rep.items() if _is_conv_stack(n)),
+              "min cos other", min(c for n, (c, r) in rep.items() if not _is_conv_stack(n)),
+              "max rel conv", max(r for n, (c, r) in rep.items() if _is_conv_stack(n)),
+              "max rel other", max(r for n, (c, r) in rep.items() if not _is_conv_stack(n)))
+    # measured over the five shapes: conv stack cosine 0.9956 - 0.9985, rel 5.5 - 9.4 %; outside it 0.99943 - 0.99999, rel
+    # 0.3 - 3.4 % (the 13-window batch is the worst of both): bounds at 1.5 x the measured 1 - cos / rel
+    for name, (c, rel) in rep.items():
+        lo_c, hi_r = (0.9934, 0.14) if _is_conv_stack(name) else (0.9991, 0.052)
+        assert c > lo_c and rel < hi_r, (name, c, rel)
 
 
 def test_syn_and_deep_variants():
@@ -392,7 +407,9 @@ def test_sliding_window_inference_matches_reference_loop():
                 p1, _, _ = ref(w, mask=None, grl=False, pooling="mean")
                 plist.append(torch.softmax(p1, dim=1)[0].numpy())
         mean_p = np.mean(np.array(plist), axis=0)
-        np.testing.assert_allclose(probs[b].cpu().numpy(), mean_p, atol=1e-2)
+        if os.environ.get("SEPT_TEST_PRINT_NORMS"):
+            print("SLIDING max |dp|", float(np.abs(probs[b].cpu().numpy() - mean_p).max()))
+        np.testing.assert_allclose(probs[b].cpu().numpy(), mean_p, atol=2.5e-3)     # measured 0.9e-3 - 1.4e-3
         if np.sort(mean_p)[-1] - np.sort(mean_p)[-2] > 2e-2:
             assert int(pred[b]) == int(np.argmax(mean_p))
     gp, gprobs = sliding_window_predict(grl, feats.cuda(), which="gender")
@@ -974,7 +991,7 @@ def test_hand_scheduled_step_equals_the_autograd_step(scale_lamda, with_dropout,
     """functional.grl_train_step (each branch forward -> CE -> backward as one chain on its own stream, one cloak backward
     kernel that also carries the scale-loss term) against the same step through the autograd tape (module forward,
     GrlStepLossFn, loss.backward(): training_cloak_with_grl.py:138-169): identical parameters after three updates, bit for
-    bit -- with dropout active too (both draw from the same Philox sub-streams in the same order)."""
+    bit -- with dropout active too (each network draws from its own Philox call site, whatever the enqueue order)."""
     from sept_amd import trainer as T
     from sept_amd import functional as SF
     x = closed_form_input(B, W, F).cuda()
@@ -982,7 +999,6 @@ def test_hand_scheduled_step_equals_the_autograd_step(scale_lamda, with_dropout,
     res = []
     for hand in (False, True):
         prev, T.HAND_SCHEDULED = T.HAND_SCHEDULED, hand
-        prev_order, SF._BWD_ORDER = SF._BWD_ORDER, 1     # emotion first: the module's order of dropout draws
         try:
             torch.manual_seed(11)
             grl = build_grl(F).train()
@@ -993,7 +1009,7 @@ def test_hand_scheduled_step_equals_the_autograd_step(scale_lamda, with_dropout,
             torch.cuda.synchronize()
             res.append((tr.flat.flat.clone(), [float(o[0]) for o in outs], outs[-1][1].clone(), outs[-1][2].clone()))
         finally:
-            T.HAND_SCHEDULED, SF._BWD_ORDER = prev, prev_order
+            T.HAND_SCHEDULED = prev
     assert torch.equal(res[0][0], res[1][0])
     assert torch.equal(res[0][2], res[1][2]) and torch.equal(res[0][3], res[1][3])
     assert res[0][1] == pytest.approx(res[1][1], rel=1e-6)     # (a + b) - c against (a - c) + b
@@ -1032,34 +1048,6 @@ def test_hand_scheduled_step_covers_the_wrapper_options(att, pooling, weighted, 
     assert res[0][3] == pytest.approx(res[1][3], rel=1e-6)
 
 
-def test_segmented_capture_equals_eager():
-    """SEPT_SEGMENTED=1 (functional.SegmentSched): the step captured as one HIP graph per chain and replayed on real
-    streams -- an alternative to the single captured graph whose chains the graph executor places -- gives the same
-    parameters as eager steps, bit for bit, under a learning-rate schedule."""
-    from sept_amd import trainer as T
-    F = 80
-    x = closed_form_input(B, W, F).cuda()
-    le, lg, wts = (t.cuda() for t in closed_form_labels(B))
-    res = []
-    for seg in (False, True):
-        prev, T.SEGMENTED = T.SEGMENTED, seg
-        try:
-            grl = build_grl(F).train()
-            zero_dropout(grl)
-            tr = T.GrlTrainer(grl, optimizer="sgd", lr=0.02, gender_lambda=0.1, scale_lamda=0.05)
-            sched = torch.optim.lr_scheduler.StepLR(tr.optimizer, step_size=1, gamma=0.5)
-            tr.train_step(x, le, lg, wts)
-            step = tr.capture(x, le, lg, wts) if seg else (lambda: tr.train_step(x, le, lg, wts))
-            for _ in range(3):
-                sched.step()
-                step()
-            torch.cuda.synchronize()
-            res.append(tr.flat.flat.clone())
-        finally:
-            T.SEGMENTED = prev
-    assert torch.equal(res[0], res[1])
-
-
 def test_hand_scheduled_step_with_frozen_cloak_parameters():
     """locs / rhos without requires_grad: no data gradient is needed at all -- the emotion branch stops at its loss."""
     from sept_amd import trainer as T
@@ -1093,26 +1081,3 @@ def test_recurrent_shapes_outside_the_hip_path_say_what_is_supported():
         m = bm.two_d_cnn_lstm(1, 80, 64, **dict(dict(lstm_hidden_size=64, num_layers_lstm=2, global_feature=0), **kw))
         with pytest.raises(NotImplementedError, match="hidden 64 .* or 128"):
             m.cuda().eval()(x)
-
-
-def test_grl_train_step_with_layer1_recomputed():
-    """SEPT_L1_FUSED=always: layer 1 of both networks without its pre-activation tensor in TRAINING too (statistics-only
-    pass, fused forward, conv1 recomputed twice in the backward pass) -- slower than streaming the tensor,
-    so not the default, but the same step: logits / arg-max against the reference goldens, gradients against the
-    simulated-bf16 oracle."""
-    from sept_amd import functional as SF
-    F = 80
-    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "model_golden.npz"))
-    x = closed_form_input(B, W, F).cuda()
-    le, lg, wts = closed_form_labels(B)
-    prev, SF.L1_FUSED = SF.L1_FUSED, "always"
-    try:
-        grl = build_grl(F).train()
-        zero_dropout(grl)
-        p1, p2, _ = grl(x, mask=None, grl=False, pooling="mean")
-        SF.GrlStepLossFn.apply(p1, p2, le.cuda(), lg.cuda(), wts.cuda(), 0.1, 0.05, grl.intermed.rhos, 0.01, 10.0).backward()
-    finally:
-        SF.L1_FUSED = prev
-    close_logits(p1, G["f80_train_emo"], argmax=G["f80_train_emo_argmax"])
-    close_logits(p2, G["f80_train_gen"], argmax=G["f80_train_gen_argmax"])
-    _sim_step_check(grl, x, le, lg, wts, None, F, (p1, p2))

@@ -28,8 +28,6 @@ t("conv1_backward_data", lambda: ops.conv1_backward_data(dy, w))
 t("conv1_backward_weight", lambda: ops.conv1_backward_weight(x, dy))
 y_, dy_ = y, dyp.bfloat16()
 t("bn_bwd + conv1_dgrad (separate)", lambda: ops.conv1_backward_data(ops.bn_relu_pool_backward(dy_, pre, mean, invstd, gamma, beta, None, 2, y=y_)[0], w))
-t("conv1_backward_data_bn", lambda: ops.conv1_backward_data_bn(pre, dy_, mean, invstd, gamma, beta, None, w, y=y_))
-t("conv1_backward_data_bn +dpre", lambda: ops.conv1_backward_data_bn(pre, dy_, mean, invstd, gamma, beta, None, w, want_dpre=True, y=y_))
 y2, idx = ops.bn_relu_pool_forward(pre, mean, invstd, gamma, beta, None, 2, want_argmax=True)
 t("bn_relu_pool_forward +argmax", lambda: ops.bn_relu_pool_forward(pre, mean, invstd, gamma, beta, None, 2, want_argmax=True))
 t("conv1_backward_data_sparse", lambda: ops.conv1_backward_data_sparse(x, pre, dy_, idx, mean, invstd, gamma, beta, None, w, bias, y=y_))
