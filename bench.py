@@ -234,6 +234,9 @@ def main():
     ap.add_argument("--clips-per-gpu", type=int, default=32)
     ap.add_argument("--mels", type=int, default=80)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dp-buckets", type=int, choices=[1, 2], default=1,
+                    help="N > 1: 1 = one all-reduce of the flat gradient buffer behind the backward pass (default); 2 = the "
+                         "adversary's gradients all-reduced from the join in front of the cloak backward kernel, locs / rhos after it")
     ap.add_argument("--graph", dest="graph", action="store_true", default=True,
                     help="replay the step from a captured HIP graph (default)")
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="enqueue every kernel from the host each step")
@@ -292,7 +295,7 @@ def main():
 
     F, clips = a.mels, a.clips_per_gpu
     model = build(F, dev)
-    trainer = GrlTrainer(model, optimizer="sgd", gender_lambda=0.1, scale_lamda=0.0)
+    trainer = GrlTrainer(model, optimizer="sgd", gender_lambda=0.1, scale_lamda=0.0, buckets=a.dp_buckets)
     mean = torch.full((F,), -20.0, device=dev)    # fixed per-mel statistics of the synthetic set
     std = torch.full((F,), 12.0, device=dev)
     pipe = FusedPipeline(trainer, n_mels=F, n_fft=800, mean=mean, std=std)
@@ -570,7 +573,7 @@ def main():
         comm.sort(), opt.sort()
         n_act = trainer.flat.n_active
         dp_info = {"world_size_reported_by_backend": torch.distributed.get_world_size(), "backend": torch.distributed.get_backend(),
-                   "allreduce_floats": int(n_act), "allreduce_bytes": int(n_act) * 4,
+                   "allreduce_floats": int(n_act), "allreduce_bytes": int(n_act) * 4, "buckets": a.dp_buckets,
                    "comm_ms": round(comm[len(comm) // 2], 4), "comm_ms_min": round(comm[0], 4),
                    "optimizer_ms": round(opt[len(opt) // 2], 4),
                    "note": "median of 5 instrumented steps after the timed region: ONE all-reduce of the flat gradient "

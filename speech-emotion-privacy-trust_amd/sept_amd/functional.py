@@ -1098,7 +1098,7 @@ class GrlPairFn(torch.autograd.Function):
 
 
 def grl_train_step(model, x, labels_emo, labels_gen, weights, gender_lambda, scale_lamda, use_scale_term=True, mask=None,
-                   pooling="mean", global_feature=None, before_cloak=None, injected=None):
+                   pooling="mean", global_feature=None, before_cloak=None, injected=None, at_join=None):
     """One forward + loss + backward of two_d_cnn_lstm_syn_with_grl under the loss of train()
     (training_cloak_with_grl.py:122-160), scheduled by hand instead of through the autograd tape:
 
@@ -1114,7 +1114,11 @@ def grl_train_step(model, x, labels_emo, labels_gen, weights, gender_lambda, sca
     or None with `before_cloak` a callable that produces it on the current stream (the feature stage: its launches then
     overlap the step's random-number kernels).  Returns (loss, logits_emotion, logits_gender); the gradients are in
     .grad of the trainable parameters (views of their flat slots where the trainer packed them).  `injected` (default: the
-    wrapper's `injected_masks` test hook): explicit dropout masks (emotion network's, gender network's), see trunk_forward."""
+    wrapper's `injected_masks` test hook): explicit dropout masks (emotion network's, gender network's), see trunk_forward.
+    `at_join`: called on the current stream where both backward chains (and every side stream) have been joined, in front of
+    the cloak backward kernel -- from here on every weight gradient of the two networks is final in its slot; only dL/dlocs
+    and dL/drhos are still to come.  The data-parallel trainer uses it to start the all-reduce of the first gradient bucket
+    (and, under capture, to end the first graph segment there)."""
     noise, emo, gen = model.intermed, model.original_model, model.gender_model
     injected = injected if injected is not None else getattr(model, "injected_masks", None)
     inj1, inj2 = injected if injected is not None else (None, None)
@@ -1248,6 +1252,8 @@ def grl_train_step(model, x, labels_emo, labels_gen, weights, gender_lambda, sca
             finally:
                 _DEFERRED["on"] = prev
             (l1, dx1, g1), (l2, dx2, g2) = res[s1], res[s2]
+        if at_join is not None:
+            at_join()
         if need_dx:
             da, db_ = batch_sum_pair(dx1, dx2)
             dlocs, drhos = ops.cloak_backward(da, db_, -lam, rhos.detach(), eps, m, smin, smax,

@@ -251,18 +251,21 @@ class _TrainerBase:
         # torch's schedulers warn "lr_scheduler.step() before optimizer.step()" unless the handle saw a step
         self.optimizer._opt_called = True
 
-    def _allreduce_grads(self):
-        """The one exchange of a data-parallel step: sum of the active prefix of the flat gradient buffer over the
-        ranks (the optimiser divides by the world size).  ONE message: 943 238 floats (3.8 MB) at 80 mels, 1 257 350
-        (5.0 MB) at 128 -- tens of microseconds over xGMI against a step of milliseconds.  It is not split into
-        buckets overlapped with the backward pass: the backward pass is one HIP-graph launch here, so an overlap would
-        need the collective INSIDE the captured graph, which this build does not rely on."""
+    def _allreduce_grads(self, lo=0, hi=None, async_op=False):
+        """The exchange of a data-parallel step: sum of (a slice of) the active prefix of the flat gradient buffer over the
+        ranks (the optimiser divides by the world size).  By default ONE message: 943 238 floats (3.8 MB) at 80 mels,
+        1 257 350 (5.0 MB) at 128 -- tens of microseconds over xGMI against a step of milliseconds.  A synchronous call
+        (`async_op=False`) is issued by ProcessGroupNCCL on the CALLER'S current stream in this torch (the `asyncOp`
+        argument of ProcessGroupNCCL::collective): behind a graph launch on the same stream it is one more in-order node,
+        with no event hop between streams.  GrlTrainer(buckets=2) splits it in two (see there)."""
         f = self.flat
-        torch.distributed.all_reduce(f.grad[:f.n_active], group=self.pg)
+        hi = f.n_active if hi is None else hi
+        return torch.distributed.all_reduce(f.grad[lo:hi], group=self.pg, async_op=async_op)
 
     def _capture(self, body):
         """Record `body()` (features / forward / loss / backward) plus gradient placement -- and, on a single rank,
-        the optimiser update -- into a HIP graph; returns replay()."""
+        the optimiser update -- into a HIP graph; returns replay().  (GrlTrainer._capture_bucketed is the two-segment
+        form of the data-parallel case.)"""
         if self.steps < 1:
             raise RuntimeError("capture() needs at least one eager warm-up step (first-use setup, active-set discovery)")
         self.model.train()
@@ -309,8 +312,14 @@ class _TrainerBase:
 class GrlTrainer(_TrainerBase):
     def __init__(self, cloak_model, optimizer="sgd", lr=None, momentum=0.9, weight_decay=1e-4, betas=(0.9, 0.98),
                  eps=1e-9, gender_lambda=0.1, scale_lamda=0.0, suppression=False, process_group=None, sync_bn=False,
-                 seed=None):
+                 seed=None, buckets=1):
+        """`buckets` (data-parallel only): 1 = ONE all-reduce of the flat gradient buffer behind the backward pass (default);
+        2 = the split at the join in front of the cloak backward kernel (<= 2 buckets overlapped with
+        the tail of backward): bucket 1 = every slot behind the cloak's (the adversary's conv / GRU / dense gradients: final
+        at that join) is all-reduced ASYNCHRONOUSLY while the cloak backward kernel runs, bucket 2 = dL/dlocs, dL/drhos
+        follows.  Same sums, so the parameters equal the single-bucket form bit for bit (tests/test_dp_gpu.py)."""
         self.model = cloak_model
+        self.buckets = int(buckets)
         self.sync_bn = sync_bn   # BatchNorm statistics of the GLOBAL batch (extra tiny all-reduces); default: per rank
         self.flat = FlatParams(cloak_model.parameters(), list(cloak_model.named_parameters()))  # filter(requires_grad), :417/:420
         # :417  SGD(lr=0.001, momentum=0.9, weight_decay=1e-4);  :420  Adam(lr=0.0005, weight_decay=1e-4,
@@ -327,8 +336,9 @@ class GrlTrainer(_TrainerBase):
                                       self.scale_lamda, rhos, float(noise.min_scale), float(noise.max_scale))
 
     def _forward_backward(self, features, labels_emo, labels_gen, weights, mask=None, pooling="mean",
-                          global_feature=None):
-        """`features`: the (B, 1, H, W) batch, or a callable that produces it on the current stream (FusedPipeline)."""
+                          global_feature=None, at_join=None):
+        """`features`: the (B, 1, H, W) batch, or a callable that produces it on the current stream (FusedPipeline).
+        `at_join`: see functional.grl_train_step (hand-scheduled path only)."""
         SF.set_sync_bn(self.sync_bn and self.world > 1, self.pg)
         if HAND_SCHEDULED and self._hand_schedulable(features):
             # forward, loss and backward of both branches as two chains on two streams (functional.grl_train_step)
@@ -336,8 +346,10 @@ class GrlTrainer(_TrainerBase):
             loss, preds, preds_grl = SF.grl_train_step(
                 self.model, None if fn else features, labels_emo, labels_gen, weights, self.gender_lambda, self.scale_lamda,
                 use_scale_term=not self.suppression, mask=mask, pooling=pooling, global_feature=global_feature,
-                before_cloak=fn)
+                before_cloak=fn, at_join=at_join)
             return loss, preds, preds_grl
+        if at_join is not None:
+            raise RuntimeError("the bucketed data-parallel step needs the hand-scheduled path")
         if callable(features):
             features = features()
         if isinstance(features, ops.LazyWindows):
@@ -358,6 +370,21 @@ class GrlTrainer(_TrainerBase):
             return True
         return features.is_cuda and features.dim() == 4 and features.shape[1] == 1 and not features.requires_grad
 
+    def _cloak_slots(self, features):
+        """(lo, hi) of the cloak parameters' slots when the two-bucket exchange applies -- a data-parallel job, the
+        hand-scheduled step, the active set known, dL/dlocs / dL/drhos written in place at the START of the flat buffer
+        (cloak_model.parameters() yields `intermed` first) -- else None (single bucket)."""
+        if self.buckets != 2 or self.world == 1 or not self.flat._settled:
+            return None
+        if not (HAND_SCHEDULED and self._hand_schedulable(features)):
+            return None
+        noise = self.model.intermed
+        slots = sorted(p._sept_flat[1:] for p in (noise.locs, noise.rhos) if p.requires_grad and getattr(p, "_sept_flat", None))
+        if not slots or slots[0][0] != 0 or any(a[0] + a[1] != b[0] for a, b in zip(slots, slots[1:])):
+            return None
+        hi = slots[-1][0] + slots[-1][1]
+        return (0, hi) if hi < self.flat.n_active else None
+
     def train_step(self, features, labels_emo, labels_gen, weights=None, mask=None, pooling="mean",
                    global_feature=None):
         """One iteration of the batch loop (:122-169) on this rank's shard.  Returns
@@ -365,6 +392,19 @@ class GrlTrainer(_TrainerBase):
         self.model.train()
         self.flat.zero_grad()
         self._sync_lr()
+        cloak = self._cloak_slots(features)
+        if cloak is not None:
+            # two buckets: the adversary's gradients are final at the join in front of the cloak backward kernel -- their
+            # all-reduce starts there, asynchronously, and the cloak's own two tensors follow behind the backward pass
+            pending = []
+            out = self._forward_backward(features, labels_emo, labels_gen, weights, mask, pooling, global_feature,
+                                         at_join=lambda: pending.append(self._allreduce_grads(cloak[1], None, async_op=True)))
+            self.flat.gather_grads()
+            for work in pending:
+                work.wait()
+            self._allreduce_grads(cloak[0], cloak[1])
+            self.optimizer_step()
+            return out
         out = self._forward_backward(features, labels_emo, labels_gen, weights, mask, pooling, global_feature)
         self.flat.gather_grads()
         if self.world > 1:
@@ -380,8 +420,60 @@ class GrlTrainer(_TrainerBase):
         process group the graph ends at the gradients, and replay() then runs the all-reduce and the update.
         Refill the inputs with copy_() between replays; call after at least one eager step.  `features` may be a
         callable producing the batch on the current stream (FusedPipeline)."""
+        cloak = self._cloak_slots(features)
+        if cloak is not None:
+            return self._capture_bucketed(cloak, lambda at_join: self._forward_backward(
+                features, labels_emo, labels_gen, weights, mask, pooling, global_feature, at_join=at_join))
         return self._capture(lambda: self._forward_backward(features, labels_emo, labels_gen, weights, mask, pooling,
                                                             global_feature))
+
+    def _capture_bucketed(self, cloak, body):
+        """capture() for GrlTrainer(buckets=2): the step as TWO graph segments cut at the join in front of the cloak
+        backward kernel -- segment A ends with every adversary gradient final, segment B is the cloak backward + gradient
+        placement -- so that a replay is: graph A, all-reduce of bucket 1 (asynchronous), graph B under it, wait, all-reduce
+        of bucket 2 (locs / rhos), the optimiser's graph.  Both segments share one memory pool (B reads A's tensors)."""
+        if self.steps < 1:
+            raise RuntimeError("capture() needs at least one eager warm-up step (first-use setup, active-set discovery)")
+        self.model.train()
+        self.flat.zero_grad()
+        self._sync_lr()
+        self._ensure_state()
+        SF.invalidate_weight_cache()     # see _capture
+        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        dev = self.flat.flat.device
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        torch.cuda.synchronize(dev)
+        with torch.cuda.stream(side), SF.capture_origin():
+            ga.capture_begin(capture_error_mode="thread_local")
+
+            def at_join():
+                ga.capture_end()
+                gb.capture_begin(pool=ga.pool(), capture_error_mode="thread_local")
+            out = body(at_join)
+            self.flat.gather_grads()
+            gb.capture_end()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        opt_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(opt_graph, capture_error_mode="thread_local"):
+            self.optimizer_step()
+        self.steps -= 1                # the captures enqueued nothing
+        SF.invalidate_weight_cache()
+
+        def replay():
+            self._sync_lr()
+            ga.replay()
+            work = self._allreduce_grads(cloak[1], None, async_op=True)
+            gb.replay()
+            work.wait()
+            self._allreduce_grads(cloak[0], cloak[1])
+            opt_graph.replay()
+            self.steps += 1
+            SF.invalidate_weight_cache()
+            return out
+
+        replay.graph, replay.graph_b, replay.opt_graph = ga, gb, opt_graph
+        return replay
 
     @torch.no_grad()
     def eval_step(self, features, labels_emo, labels_gen, mask=None, pooling="mean", global_feature=None):

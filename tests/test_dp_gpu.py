@@ -128,3 +128,51 @@ def test_two_ranks_captured_step_equals_eager_and_ranks_stay_in_step():
         assert p.exitcode == 0
     assert ret[0][0] and ret[1][0]
     assert torch.equal(ret[0][1], ret[1][1])
+
+
+def _worker_bucketed(rank, world, port, ret):
+    """each rank: one warm-up step + two more, (a) eager with ONE all-reduce, (b) eager with the two-bucket exchange, (c) the
+    two-segment captured form of (b)"""
+    import torch.distributed as dist
+    from sept_amd.trainer import GrlTrainer
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    per = B // world
+    sl = slice(rank * per, (rank + 1) * per)
+    x = closed_form_input(B, W, F)[sl].cuda()
+    le, lg, w = (t[sl].cuda() for t in closed_form_labels(B))
+    out, used = [], []
+    for buckets, use_graph in ((1, False), (2, False), (2, True)):
+        tr = GrlTrainer(_build(), optimizer="sgd", lr=0.05, gender_lambda=0.1, scale_lamda=0.05, seed=77, buckets=buckets)
+        tr.train_step(x, le, lg, w)                       # (the first step is always single-bucket: active set unknown)
+        used.append(tr._cloak_slots(x))
+        step = tr.capture(x, le, lg, w) if use_graph else (lambda: tr.train_step(x, le, lg, w))
+        if use_graph:
+            assert getattr(step, "graph_b", None) is not None      # really the two-segment form
+        step(), step()
+        torch.cuda.synchronize()
+        out.append(tr.flat.flat.clone().cpu())
+    ret[rank] = (bool(torch.equal(out[0], out[1])), bool(torch.equal(out[0], out[2])), used, out[0])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_bucket_exchange_equals_the_single_all_reduce():
+    """GrlTrainer(buckets=2): the adversary's gradients all-reduced from the join in
+    front of the cloak backward kernel, dL/dlocs / dL/drhos behind it -- eager and as two captured graph segments -- leave
+    the same parameters as the single all-reduce, bit for bit, on both ranks."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_bucketed, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    for r in range(2):
+        eq_eager, eq_graph, used, _ = ret[r]
+        assert used[0] is None and used[1] == (0, 2 * W * F) and used[2] == (0, 2 * W * F)    # locs + rhos lead the buffer
+        assert eq_eager and eq_graph
+    assert torch.equal(ret[0][3], ret[1][3])
