@@ -403,25 +403,25 @@ def main():
             feed.swap_in()
             step_fn()
             feed.prefetch(host[k % 2])          # AFTER the graph launch: see trainer.HostFeed
-        # two timed blocks of K steps; the line carries the faster one and lists both.  Why: in about one process out of
-        # six ONE graph launch of the first host-fed iterations stalls on the host for ~85 ms (tools/feed_diag.py shows the
-        # single 85 ms hipGraphLaunch; steady state is 2.03 vs 2.04 ms) -- a one-off of the runtime, not a rate
-        blocks = []
-        for blk in range(2):
-            barrier()
-            t0f = time.perf_counter()
-            for k in range(a.steps):
-                feed.swap_in()
-                step_fn()
-                feed.prefetch(host[k % 2])
-            barrier()
-            dtb = time.perf_counter() - t0f
-            if world > 1:
-                t = torch.tensor([dtb], device=dev)
-                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-                dtb = float(t.item())
-            blocks.append(dtb)
-        dtf = min(blocks)
+        # ONE timed block of K steps (round 3 took the faster of two because, in about one process out of six, one
+        # hipGraphLaunch among the FIRST host-fed iterations stalled on the host for ~85 ms: a first-use cost of the copy
+        # stream beside a running graph -- the eight untimed iterations above are where it lands now).  Every iteration's host
+        # time is kept, so an outlier would be visible on the line (iter_ms_max) instead of being averaged in or dropped.
+        barrier()
+        t0f = time.perf_counter()
+        marks = [t0f]
+        for k in range(a.steps):
+            feed.swap_in()
+            step_fn()
+            feed.prefetch(host[k % 2])
+            marks.append(time.perf_counter())
+        barrier()
+        dtf = time.perf_counter() - t0f
+        if world > 1:
+            t = torch.tensor([dtf], device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dtf = float(t.item())
+        iters = [(y - x) * 1e3 for x, y in zip(marks, marks[1:])]
         feed.swap_in()                          # leave nothing pending
         # the transfer by itself (nothing else on the GPU): tells a slow PCIe link / host of this box from a scheduling problem
         h2d = []
@@ -437,7 +437,9 @@ def main():
         host_fed = {"value": round(clips * world * a.steps / dtf, 2), "unit": "utterances/s",
                     "h2d_alone_ms": round(h2d_ms, 3), "h2d_alone_GBps": round(feed.nbytes / h2d_ms / 1e6, 1),
                     "ms_per_step": round(dtf / a.steps * 1e3, 3), "vs_resident": round(dt / dtf, 4),
-                    "blocks_ms_per_step": [round(b / a.steps * 1e3, 3) for b in blocks],
+                    "host_iter_ms_median": round(sorted(iters)[len(iters) // 2], 3), "host_iter_ms_max": round(max(iters), 3),
+                    "packing": "excluded: the two pinned batches are packed once before the loop (HostFeed.pack(out=) reuses "
+                               "pinned buffers in a real loader loop)",
                     "host_bytes_per_step_per_gpu": feed.nbytes,
                     "how": "two pinned host batches alternate: ONE H2D transfer per batch on a copy stream, enqueued right "
                            "behind the graph launch so that it runs under the replay, then a shader copy into the captured "

@@ -16,12 +16,18 @@
 //     transpose through a wave-private LDS scratch between the passes; 64/TPF frames ride
 //     in each wavefront (n_fft 800: 400 = 20 x 20, 20 lanes per frame, 3 frames per wave).
 //     Window and inter-pass twiddles live in VGPRs for the whole tile.
-//   * |X|^2 goes back to the scratch (each frame's row on its own banks); the filterbank -- a
-//     matrix product in the reference, matmul(spec, fb) -- runs on the matrix pipe in exact
-//     fp32 (v_mfma_f32_16x16x4_f32: bit-for-bit a k-ordered fmaf chain): the frames of one
-//     workgroup iteration are the 16 rows of the A operand, 16 filters the columns of B, and
-//     only the k range where those 16 filters are non-zero is walked (the band of the
-//     triangular filterbank; any filterbank is accepted, a dense one just walks more steps).
+//   * |X|^2 goes back to the scratch (each frame's row on its own banks) SPLIT into a bf16 pair hi + lo
+//     (hi = bf16(P), lo = bf16(P - hi): 16 significant bits, packed in the dword the fp32 value would
+//     take); the filterbank -- a matrix product in the reference, matmul(spec, fb) -- runs on the bf16
+//     matrix pipe (v_mfma_f32_16x16x32_bf16, fp32 accumulation): the frames of one workgroup iteration
+//     are the 16 rows of the A operand, 16 filters the columns of B, and only the k range where those 16
+//     filters are non-zero is walked (the band of the triangular filterbank; any filterbank is accepted,
+//     a dense one just walks more steps).  A lane's 8 A elements are 4 bins x (hi, lo); B holds each
+//     weight twice, so ONE product sums (hi + lo) * w over 16 bins, and a second one with the weights'
+//     own low parts completes (hi + lo) * (w_hi + w_lo): every term of the sum is non-negative, so the
+//     result is within ~2^-17 relative of the fp32 product (the tolerance is 1e-4) at a quarter of the
+//     matrix-pipe time of the exact-fp32 form (v_mfma_f32_16x16x4_f32, round 2-3: 2 x 32 cycles per 8
+//     bins against 2 x 16 per 16 bins).
 //     The (filter tile, k range) segments are dealt to the four waves on the host; a filter
 //     tile split between two waves lands in two LDS tiles that the final pass adds in a fixed
 //     order, so results do not depend on scheduling.  The whole workgroup finally converts
@@ -38,9 +44,11 @@
 namespace {
 
 constexpr int kWaves = 4;      // waves per workgroup
-constexpr int kBatch = 8;      // filterbank steps whose operands are fetched together
+constexpr int kBatch = 2;      // filterbank steps (16 bins each) whose operands are fetched together
+constexpr int kStepBins = 16;  // bins per filterbank step = the K = 32 of one MFMA / 2 (hi, lo)
 constexpr int kMaxSteps = 64;  // filterbank steps per wave (one header word per lane)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct MelArgs {
   const float* wav;      // [B][L]
@@ -48,8 +56,8 @@ struct MelArgs {
   const float2* window;  // [N] (pairs of window samples)
   const float2* tw;      // [N1][N2]  W_N^(k1*n2)
   const float2* ptw;     // [N/2+1]   e^{-i pi p / N}
-  const float2* btab;    // [n_steps][64]: B operands of one 8-bin step (two MFMAs) per lane
-  const int* steps;      // [kWaves][kMaxSteps + 2]: per step of the wave (first bin / 8) | flush << 10 | slot << 11 | filter tile << 12;
+  const uint4* btab;     // [n_steps][2][64]: B operands of one 16-bin step per lane: 4 bins x (w_hi, w_hi), then 4 bins x (w_lo, w_lo)
+  const int* steps;      // [kWaves][kMaxSteps + 2]: per step of the wave (first bin / 16) | flush << 10 | slot << 11 | filter tile << 12;
                          // then the wave's first step in btab and its number of steps
   int B, L, T, F, layout, tiles_per_clip;
 };
@@ -77,16 +85,21 @@ struct MelCfg {
   static constexpr int SPANP = SPAN + PAD * ((SPAN + HOP - 1) / HOP);     // padded floats
   static constexpr int MT = (FPI + 15) / 16;     // 16-frame row tiles of the filterbank product
   static_assert(N2 % TPF == 0 && N1 % TPF == 0, "TPF must divide both factors");
-  // P of frame g starts 0..63 floats into the frame's scratch (bank 20 g: see p_offset) and is read 8 bins at a time
-  static_assert(SCR >= N && 2 * SCR >= N + 1 + 63 + 8, "scratch must hold Z and the staggered P");
+  // P of frame g starts 0..63 dwords into the frame's scratch (bank 8 g: see p_offset), is padded with zeros to a whole
+  // number of 16-bin steps and is read 16 bins at a time
+  static constexpr int NPP = (N + 1 + kStepBins - 1) / kStepBins * kStepBins;   // bins incl. the zero tail
+  static_assert(SCR >= N && 2 * SCR >= NPP + 63, "scratch must hold Z and the staggered, padded P");
   static_assert(HOP % 4 == 0 && PAD % 2 == 0, "float4 staging / float2 reads");
 };
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~size_t(15); }
 
-// Float offset of frame g's power spectrum inside the scratch: the frame's own slot plus a stagger that puts
-// P[g][0] on bank 20 g mod 64 = 4 (5 g mod 16): the 16 rows x 4 consecutive floats that one half-wave reads for the
-// A operand fall on 64 distinct banks, and the three (TPF 20) frames a wave writes side by side do not collide.
+// Dword offset of frame g's (packed hi | lo) power spectrum inside the scratch: the frame's own slot plus a stagger that
+// puts P[g][0] on bank 8 g mod 64, i.e. on the 16-byte slot 2 g mod 16.  The A operand is one ds_read_b128 per lane (row
+// l & 15, bins 4 (l >> 4) .. + 3 of the step), served in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...:
+// a group holds rows {0-3, 12-15} of one 16-byte column and rows {4-11} of the next, so slot = 2 row (+ 1) mod 16 puts
+// its 16 lanes on 16 distinct slots = all 64 banks.  (The three frames a wave writes side by side then overlap pairwise
+// in 12 banks: a 2-way conflict on ds_write_b32 costs no cycles, MI355X_MICROARCH.md section LDS.)
 // -DSEPT_MEL_PROF (tools/mel_prof.hip): cycles per phase, summed over the waves of the launch
 #ifdef SEPT_MEL_PROF
 __device__ unsigned long long g_mel_prof[8];
@@ -109,7 +122,7 @@ __device__ unsigned long long g_mel_prof[8];
 template <class C>
 __device__ __forceinline__ int p_offset(int g) {
   const int base = g * 2 * C::SCR;
-  return base + (((20 * g - base) % 64) + 64) % 64;
+  return base + (((8 * g - base) % 64) + 64) % 64;
 }
 
 // AmplitudeToDB: 10 log10(clamp(x, 1e-10)).  The clamp floor is emitted as exactly -100 dB,
@@ -168,17 +181,17 @@ __global__ __launch_bounds__(kWaves * 64, REG_TABLES ? 2 : 1) void sept_mel_stft
   if (!lane_ok) fiw = C::FPW - 1;  // spare lanes shadow the last frame, never write
   float2* scr = scratch_all + size_t(wave * C::FPW + fiw) * C::SCR;
   float* P = reinterpret_cast<float*>(scratch_all) + p_offset<C>(wave * C::FPW + fiw);
-  // A operand of the filterbank product: lane l reads row (l & 15) of row tile mt, bins k + 2 (l >> 4) + {0, 1}
+  // A operand of the filterbank product: lane l reads row (l & 15) of row tile mt, bins k + 4 (l >> 4) .. + 3 (hi | lo pairs)
   const float* prow[C::MT];
 #pragma unroll
   for (int mt = 0; mt < C::MT; ++mt)
     prow[mt] = reinterpret_cast<const float*>(scratch_all) + p_offset<C>(min(mt * 16 + (lane & 15), C::FPI - 1)) +
-               2 * (lane >> 4);
+               4 * (lane >> 4);
   // this wave's share of the filterbank: a contiguous run of steps (one header word per lane)
   const int* stp = a.steps + __builtin_amdgcn_readfirstlane(wave) * (kMaxSteps + 2);
   const int hdr = stp[lane];
   const int wn = __builtin_amdgcn_readfirstlane(stp[kMaxSteps + 1]);
-  const float2* bt = a.btab + size_t(__builtin_amdgcn_readfirstlane(stp[kMaxSteps])) * 64 + lane;
+  const uint4* bt = a.btab + size_t(__builtin_amdgcn_readfirstlane(stp[kMaxSteps])) * 128 + lane;
   const int wlast = max(wn, 1) - 1;
 
   float2 win[REG_TABLES ? C::CPT : 1][REG_TABLES ? N1 : 1];
@@ -305,9 +318,12 @@ __global__ __launch_bounds__(kWaves * 64, REG_TABLES ? 2 : 1) void sept_mel_stft
       MEL_T(2)
 
       // B operands of this wave's first filterbank batch: in flight under the post-pass
-      float2 bq0[kBatch], bq1[kBatch];
+      uint4 bq0[kBatch][2], bq1[kBatch][2];
 #pragma unroll
-      for (int u = 0; u < kBatch; ++u) bq0[u] = (SEPT_MEL_ABLATE & 64) ? make_float2(1.f, 1.f) : bt[size_t(min(u, wlast)) * 64];
+      for (int u = 0; u < kBatch; ++u) {
+        bq0[u][0] = bt[size_t(min(u, wlast)) * 128];
+        bq0[u][1] = bt[size_t(min(u, wlast)) * 128 + 64];
+      }
 
       // ---- split post-pass: pairs (p, N-p) -> |X[p]|^2, |X[N-p]|^2 of the real 2N-FFT ----
       if constexpr (!(SEPT_MEL_ABLATE & 8)) {
@@ -330,14 +346,22 @@ __global__ __launch_bounds__(kWaves * 64, REG_TABLES ? 2 : 1) void sept_mel_stft
           p0[q] = 0.25f * (ar * ar + ai * ai);
           p1[q] = 0.25f * (br * br + bi * bi);
         }
+        auto split = [](float p) {   // hi | lo << 16, hi = bf16(p), lo = bf16(p - hi)
+          const __bf16 h = (__bf16)p;
+          const __bf16 l = (__bf16)(p - float(h));
+          return float(__builtin_bit_cast(float, unsigned(__builtin_bit_cast(unsigned short, h)) |
+                                                     (unsigned(__builtin_bit_cast(unsigned short, l)) << 16)));
+        };
         if (lane_ok) {
 #pragma unroll
           for (int q = 0; q < C::PPT; ++q) {
             if (j + TPF * q <= C::N / 2) {  // only the last q can fail (uniform per q for most lanes)
-              P[pa[q]] = p0[q];
-              P[pwb[q]] = p1[q];
+              P[pa[q]] = split(p0[q]);
+              P[pwb[q]] = split(p1[q]);
             }
           }
+          // the zero tail up to a whole 16-bin step (the Z values that lay there are not finite as bf16 pairs)
+          if (j < C::NPP - (C::N + 1)) P[C::N + 1 + j] = 0.f;
         }
       }
       MEL_T(3)
@@ -347,30 +371,32 @@ __global__ __launch_bounds__(kWaves * 64, REG_TABLES ? 2 : 1) void sept_mel_stft
       // ---- filterbank on the fp32 matrix pipe: this wave's steps (8 bins x 16 filters each) in batches; the A
       // operands of a batch are read before its MFMAs, the next batch's B operands are fetched while they run.
       if constexpr (!(SEPT_MEL_ABLATE & 16)) {
-        f32x4 acc[C::MT][2];
+        f32x4 acc[C::MT];
 #pragma unroll
-        for (int mt = 0; mt < C::MT; ++mt) acc[mt][0] = acc[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        auto batch = [&](const float2 (&bc)[kBatch], float2 (&bn)[kBatch], int i0) {
+        for (int mt = 0; mt < C::MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto batch = [&](const uint4 (&bc)[kBatch][2], uint4 (&bn)[kBatch][2], int i0) {
           int h[kBatch];
-          float2 av[C::MT][kBatch];
+          uint4 av[C::MT][kBatch];
 #pragma unroll
           for (int u = 0; u < kBatch; ++u) {
             h[u] = __builtin_amdgcn_readlane(hdr, min(i0 + u, wlast));
 #pragma unroll
             for (int mt = 0; mt < C::MT; ++mt)
-              av[mt][u] = (SEPT_MEL_ABLATE & 512) ? make_float2(float(h[u]), 1.f)
-                                                  : *reinterpret_cast<const float2*>(prow[mt] + 8 * (h[u] & 0x3ff));
+              av[mt][u] = *reinterpret_cast<const uint4*>(prow[mt] + kStepBins * (h[u] & 0x3ff));
           }
 #pragma unroll
-          for (int u = 0; u < kBatch; ++u)
-            bn[u] = (SEPT_MEL_ABLATE & 64) ? make_float2(1.f, 1.f) : bt[size_t(min(i0 + kBatch + u, wlast)) * 64];
+          for (int u = 0; u < kBatch; ++u) {
+            bn[u][0] = bt[size_t(min(i0 + kBatch + u, wlast)) * 128];
+            bn[u][1] = bt[size_t(min(i0 + kBatch + u, wlast)) * 128 + 64];
+          }
 #pragma unroll
           for (int u = 0; u < kBatch; ++u) {
             if (i0 + u < wn) {
 #pragma unroll
               for (int mt = 0; mt < C::MT; ++mt) {
-                acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][u].x, bc[u].x, acc[mt][0], 0, 0, 0);
-                acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][u].y, bc[u].y, acc[mt][1], 0, 0, 0);
+                const bf16x8 av8 = __builtin_bit_cast(bf16x8, av[mt][u]);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av8, __builtin_bit_cast(bf16x8, bc[u][1]), acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av8, __builtin_bit_cast(bf16x8, bc[u][0]), acc[mt], 0, 0, 0);
               }
               if ((h[u] & 0x400) && !(SEPT_MEL_ABLATE & 128)) {   // last step of this wave's part of the filter tile
                 // D[row 4 (l >> 4) + i][col l & 15]: frame row of the group, filter 16 tile + (l & 15)
@@ -381,9 +407,9 @@ __global__ __launch_bounds__(kWaves * 64, REG_TABLES ? 2 : 1) void sept_mel_stft
 #pragma unroll
                   for (int i = 0; i < 4; ++i) {
                     const int r = mt * 16 + 4 * (lane >> 4) + i;
-                    if (r < C::FPI && n < F) tl[size_t(it * C::FPI + r) * (F + 1) + n] = acc[mt][0][i] + acc[mt][1][i];
+                    if (r < C::FPI && n < F) tl[size_t(it * C::FPI + r) * (F + 1) + n] = acc[mt][i];
                   }
-                  acc[mt][0] = acc[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                  acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
               }
             }
@@ -436,7 +462,7 @@ struct sept_mel_plan {
   float2* d_window = nullptr;
   float2* d_tw = nullptr;
   float2* d_ptw = nullptr;
-  float2* d_btab = nullptr;
+  uint4* d_btab = nullptr;
   int* d_steps = nullptr;
   const void* kernel = nullptr;
   const char* kernel_name = nullptr;
@@ -523,28 +549,48 @@ extern "C" int sept_mel_plan_create(int n_fft, int hop, int n_mels, const float*
           if (lo < 0) lo = k;
           hi = k;
         }
-    tiles[t].k0 = lo < 0 ? 0 : lo & ~7;
-    tiles[t].steps = lo < 0 ? 0 : (hi - tiles[t].k0) / 8 + 1;   // all-zero filters: no work, the LDS tile stays 0
+    tiles[t].k0 = lo < 0 ? 0 : lo & ~(kStepBins - 1);
+    tiles[t].steps = lo < 0 ? 0 : (hi - tiles[t].k0) / kStepBins + 1;   // all-zero filters: no work, the LDS tile stays 0
     total += tiles[t].steps;
   }
   p.n_steps = std::max(total, 1);
-  // B operands: step s of tile t covers bins k0 + 8 s .. + 7; lane l feeds filter 16 t + (l & 15) with the bins
-  // k + 2 (l >> 4) (first MFMA) and k + 2 (l >> 4) + 1 (second) -- the pair one ds_read_b64 of P delivers
-  std::vector<float2> btab(size_t(p.n_steps) * 64, make_float2(0.f, 0.f));
+  // B operands: step s of tile t covers bins k0 + 16 s .. + 15; lane l feeds filter 16 t + (l & 15) with the bins
+  // k .. k + 3, k = k0 + 16 s + 4 (l >> 4) -- the four (hi, lo) pairs one ds_read_b128 of P delivers -- each weight twice:
+  // vector 0 = (w_hi, w_hi) x 4, vector 1 = (w_lo, w_lo) x 4 with w_hi = bf16(w), w_lo = bf16(w - w_hi)
+  auto bf16_bits = [](float f) -> unsigned short {   // round to nearest even (finite, non-negative weights)
+    unsigned u;
+    std::memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return static_cast<unsigned short>(u >> 16);
+  };
+  auto bf16_val = [](unsigned short b) {
+    const unsigned u = unsigned(b) << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+  };
+  std::vector<uint4> btab(size_t(p.n_steps) * 128, make_uint4(0, 0, 0, 0));
   std::vector<int> first_step(n_tiles);
   for (int t = 0, s0 = 0; t < n_tiles; s0 += tiles[t].steps, ++t) {
     first_step[t] = s0;
     for (int s = 0; s < tiles[t].steps; ++s)
       for (int l = 0; l < 64; ++l) {
-        const int m = t * 16 + (l & 15), k = tiles[t].k0 + 8 * s + 2 * (l >> 4);
-        auto w = [&](int kk) { return (m < n_mels && kk < p.n_freq) ? fb_host[size_t(kk) * n_mels + m] : 0.0f; };
-        btab[size_t(s0 + s) * 64 + l] = make_float2(w(k), w(k + 1));
+        const int m = t * 16 + (l & 15), k = tiles[t].k0 + kStepBins * s + 4 * (l >> 4);
+        unsigned hi[4], lo[4];
+        for (int e = 0; e < 4; ++e) {
+          const float w = (m < n_mels && k + e < p.n_freq) ? fb_host[size_t(k + e) * n_mels + m] : 0.0f;
+          const unsigned short h = bf16_bits(w), lw = bf16_bits(w - bf16_val(h));
+          hi[e] = unsigned(h) | (unsigned(h) << 16);
+          lo[e] = unsigned(lw) | (unsigned(lw) << 16);
+        }
+        btab[(size_t(s0 + s) * 2 + 0) * 64 + l] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        btab[(size_t(s0 + s) * 2 + 1) * 64 + l] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
       }
   }
   // deal the steps to the waves in order (each wave gets one contiguous run): a tile is cut between waves at most
   // once, and its second part then goes to LDS tile 1
   std::vector<int> steps(size_t(kWaves) * (kMaxSteps + 2), 0);
-  SEPT_REQUIRE(n_tiles <= 256 && p.n_freq / 8 < 1024, SEPT_ERR_UNSUPPORTED, "sept_mel_plan_create: n_mels=%d / n_fft=%d too large",
+  SEPT_REQUIRE(n_tiles <= 256 && p.n_freq / kStepBins < 1024, SEPT_ERR_UNSUPPORTED, "sept_mel_plan_create: n_mels=%d / n_fft=%d too large",
                n_mels, n_fft);
   {
     const int target = (total + kWaves - 1) / kWaves;
@@ -566,7 +612,7 @@ extern "C" int sept_mel_plan_create(int n_fft, int hop, int n_mels, const float*
                      "sept_mel_plan_create: n_mels=%d, n_fft=%d need more than %d filterbank steps per wave", n_mels, n_fft, kMaxSteps);
         for (int c = 0; c < take; ++c)
           steps[size_t(wave) * (kMaxSteps + 2) + load + c] =
-              ((tiles[t].k0 / 8) + done + c) | (c + 1 == take ? 0x400 : 0) | (parts << 11) | (t << 12);
+              ((tiles[t].k0 / kStepBins) + done + c) | (c + 1 == take ? 0x400 : 0) | (parts << 11) | (t << 12);
         done += take;
         load += take;
         flat += take;
@@ -625,7 +671,7 @@ extern "C" int sept_mel_plan_create(int n_fft, int hop, int n_mels, const float*
   hipError_t e = up(reinterpret_cast<void**>(&h->d_window), win.data(), sizeof(float2) * win.size());
   if (e == hipSuccess) e = up(reinterpret_cast<void**>(&h->d_tw), tw.data(), sizeof(float2) * tw.size());
   if (e == hipSuccess) e = up(reinterpret_cast<void**>(&h->d_ptw), ptw.data(), sizeof(float2) * ptw.size());
-  if (e == hipSuccess) e = up(reinterpret_cast<void**>(&h->d_btab), btab.data(), sizeof(float2) * btab.size());
+  if (e == hipSuccess) e = up(reinterpret_cast<void**>(&h->d_btab), btab.data(), sizeof(uint4) * btab.size());
   if (e == hipSuccess) e = up(reinterpret_cast<void**>(&h->d_steps), steps.data(), sizeof(int) * steps.size());
   if (e == hipSuccess) e = sept::allow_max_lds(h->kernel);
   if (e == hipSuccess && h->kernel_s) e = sept::allow_max_lds(h->kernel_s);
