@@ -350,6 +350,23 @@ int sept_conv1_backward_data_sparse(const void* dy_pooled, const void* idx_u8, c
                                     const float* dropscale, const float* sums, double n_total, const float* w, float* wprep,
                                     float* coef, float* dx, int B, int H, int W, void* stream);
 
+/* Every weight-only operand build of a network in ONE launch: conv1's operand block (sept_conv1_prep), the bf16 operands of
+ * the 5x5 convs (sept_conv5x5_prep_weights) and the packed recurrent input matrices (sept_gru_pack), each item with the exact
+ * element mapping of its stand-alone entry (bit-identical results).  At most 12 items per call.
+ *   SEPT_PREP_CONV1   : src0 = w (32,1,5,5), src1 = bias (32) or NULL, dst0 = wprep (sept_conv1_prep_floats() floats)
+ *   SEPT_PREP_CONV5X5 : src0 = w OIHW fp32, dst0 = wt bf16, p0 = cout, p1 = cin, p2 = mode (0 forward, 1 data gradient)
+ *   SEPT_PREP_GRU     : src0 / src1 = W_ih forward / reverse (G, K), src2 / src3 = b_ih forward / reverse (G),
+ *                       dst0 = wcat (2G, K), dst1 = wcatT (K, 2G), dst2 = bcat (2G), p0 = G, p1 = K, p2 = C, p3 = Wd
+ *                       (C > 0: layer-0 columns permuted from (c, w) to (w, c) feature order, C * Wd == K; C == 0: copied) */
+enum { SEPT_PREP_CONV1 = 1, SEPT_PREP_CONV5X5 = 2, SEPT_PREP_GRU = 3 };
+typedef struct sept_prep_item {
+  int kind;
+  const void *src0, *src1, *src2, *src3;
+  void *dst0, *dst1, *dst2;
+  int p0, p1, p2, p3;
+} sept_prep_item;
+int sept_prepare_operands(const sept_prep_item* items, int n_items, void* stream);
+
 /* conv1's weights in operand form: every sept_conv1_* entry point builds it into `wprep` from (w, bias) unless called
  * with w == NULL ("wprep is current"); sept_conv1_prep builds it explicitly so a caller can keep it across calls. */
 int sept_conv1_prep(const float* w, const float* bias, float* wprep, void* stream);

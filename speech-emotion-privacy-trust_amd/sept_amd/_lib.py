@@ -23,6 +23,16 @@ def _load():
 
 lib = _load()
 
+
+class PrepItem(ctypes.Structure):
+    """sept_prep_item of include/sept.h (one weight-only operand build of sept_prepare_operands)"""
+    _fields_ = [("kind", c_int), ("src0", c_void_p), ("src1", c_void_p), ("src2", c_void_p), ("src3", c_void_p),
+                ("dst0", c_void_p), ("dst1", c_void_p), ("dst2", c_void_p), ("p0", c_int), ("p1", c_int), ("p2", c_int),
+                ("p3", c_int)]
+
+
+PREP_CONV1, PREP_CONV5X5, PREP_GRU = 1, 2, 3
+
 # name -> (restype, argtypes); kept in one table so tests can check it against sept.h
 SIGNATURES = {
     "sept_last_error": (c_char_p, []),
@@ -34,6 +44,7 @@ SIGNATURES = {
     "sept_mel_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     "sept_mel_kernel_name": (c_char_p, [c_void_p]),
     "sept_conv5x5_prep_weights": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "sept_prepare_operands": (c_int, [POINTER(PrepItem), c_int, c_void_p]),
     "sept_conv5x5_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                      c_void_p]),
     "sept_conv5x5_stats_parts": (c_int, [c_int] * 5),

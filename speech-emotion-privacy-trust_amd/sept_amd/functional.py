@@ -30,13 +30,19 @@ def invalidate_weight_cache():
     _EPOCH[0] += 1
 
 
+def _stamp(t, t2=None):
+    # frozen parameters (requires_grad False) are never touched by the raw-pointer optimiser
+    if t2 is None:
+        return (t.data_ptr(), t._version, _EPOCH[0] if t.requires_grad else -1)
+    return (t.data_ptr(), t._version, t2.data_ptr(), t2._version, _EPOCH[0] if (t.requires_grad or t2.requires_grad) else -1)
+
+
 def _cached(tag, t, fn):
     """Derived operand of parameter `t`, stored ON the parameter object (so it can never be
     served to another tensor that happens to reuse the address) and refreshed whenever torch
     bumps the tensor version or the HIP optimiser bumps the epoch."""
     store = t.__dict__.setdefault("_sept_derived", {})
-    # frozen parameters (requires_grad False) are never touched by the raw-pointer optimiser
-    stamp = (t.data_ptr(), t._version, _EPOCH[0] if t.requires_grad else -1)
+    stamp = _stamp(t)
     hit = store.get(tag)
     if hit is None or hit[0] != stamp:
         hit = store[tag] = (stamp, fn())
@@ -46,12 +52,62 @@ def _cached(tag, t, fn):
 def _cached_pair(tag, t1, t2, fn):
     """As _cached, for an operand derived from two parameters (forward + reverse GRU weights)."""
     store = t1.__dict__.setdefault("_sept_derived", {})
-    stamp = (t1.data_ptr(), t1._version, t2.data_ptr(), t2._version,
-             _EPOCH[0] if (t1.requires_grad or t2.requires_grad) else -1)
+    stamp = _stamp(t1, t2)
     hit = store.get(tag)
     if hit is None or hit[0] != stamp:
         hit = store[tag] = (stamp, fn())
     return hit[1]
+
+
+def _is_stale(tag, t, t2=None):
+    hit = t.__dict__.get("_sept_derived", {}).get(tag)
+    return hit is None or hit[0] != _stamp(t, t2)
+
+
+def _store(tag, t, value, t2=None):
+    t.__dict__.setdefault("_sept_derived", {})[tag] = (_stamp(t, t2), value)
+
+
+def prepare_operands(P, W_in, need_dgrad=True):
+    """Every weight-only operand of network P that is out of date -- conv1's operand block, the bf16 operands of the 5x5 convs
+    (forward and, when a backward pass will follow, data-gradient orientation), the packed recurrent input matrices -- built
+    by ONE launch (ops.prepare_operands) and placed in the cache entries trunk_forward / trunk_backward look up.  A trainable
+    network's weights change every optimiser step, so without this its forward chain opens seven consumers with a 5 us
+    operand-build launch each (the frozen network builds them once for good).  One stale operand is left to its consumer."""
+    items, sinks = [], []
+    fp32 = lambda t: t.dtype == torch.float32 and t.is_contiguous()   # noqa: E731  (parameters: views of the flat buffer)
+    for li, cv in enumerate(P.convs):
+        w = cv.weight
+        if not fp32(w):
+            continue
+        if li == 0:
+            if w.shape != (32, 1, 5, 5) or (cv.bias is not None and not fp32(cv.bias)):
+                continue
+            if _is_stale("conv1prep", w, cv.bias):
+                items.append(("conv1", w.detach(), None if cv.bias is None else cv.bias.detach()))
+                sinks.append(lambda v, w=w, b=cv.bias: _store("conv1prep", w, v, b))
+        else:
+            for tag, mode in (("convfwd", 0), ("convdgrad", 1)):
+                if (mode == 0 or need_dgrad) and _is_stale(tag, w):
+                    items.append(("conv5x5", w.detach(), mode))
+                    sinks.append(lambda v, w=w, tag=tag: _store(tag, w, v))
+    wd = W_in
+    for pool in P.pools:
+        wd //= pool
+    C = P.convs[-1].weight.shape[0]
+    r = P.rnn
+    for layer in range(2):
+        wif, wir = getattr(r, f"weight_ih_l{layer}"), getattr(r, f"weight_ih_l{layer}_reverse")
+        bif, bir = getattr(r, f"bias_ih_l{layer}"), getattr(r, f"bias_ih_l{layer}_reverse")
+        if all(fp32(t) for t in (wif, wir, bif, bir)) and _is_stale(f"wih_cat{layer}", wif, wir):
+            items.append(("gru", wif.detach(), wir.detach(), bif.detach(), bir.detach(), C if layer == 0 else 0, wd if layer == 0 else 0))
+            sinks.append(lambda v, wif=wif, wir=wir, layer=layer: _store(f"wih_cat{layer}", wif, v, wir))
+    if len(items) < 2:
+        return 0
+    for k in range(0, len(items), 12):
+        for sink, v in zip(sinks[k:k + 12], ops.prepare_operands(items[k:k + 12], P.convs[0].weight.device)):
+            sink(v)
+    return len(items)
 
 
 def _gru_cat_weights(wif, wir, bif, bir, layer, C, Wd):
@@ -193,6 +249,7 @@ def trunk_forward(x, P, pooling="mean", need_grad=True, injected=None, gfeat=Non
     B, H, W = x.shape
     dev = x.device
     train = P.training
+    prepare_operands(P, W, need_dgrad=need_grad)
     inj = injected or getattr(P, "injected", None) or {}
     if inj:
         inj = {k: ([m.to(dev, torch.float32).contiguous() for m in v] if k == "drop2d" else v.to(dev, torch.float32).contiguous())

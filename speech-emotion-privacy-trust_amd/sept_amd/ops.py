@@ -198,6 +198,45 @@ def conv5x5_forward_act(ext, mean_in, invstd_in, gamma_in, beta_in, dropscale, w
     return out, mean, invstd
 
 
+def prepare_operands(items, device):
+    """All weight-only operand builds of a network in ONE launch (sept_prepare_operands).  `items`: a list of
+       ("conv1", w, bias_or_None)                      -> wprep
+       ("conv5x5", w_oihw, mode)                       -> wt bf16 ([25][cout][cin], or [25][cin][cout] flipped for mode 1)
+       ("gru", wif, wir, bif, bir, C, Wd)              -> (wcat (2G, K), bcat (2G), wcatT (K, 2G))
+    Returns the built operands in the same order, bit-identical to conv1_prep / conv5x5_prep_weights / sept_gru_pack."""
+    from ._lib import PREP_CONV1, PREP_CONV5X5, PREP_GRU, PrepItem
+    arr, outs = (PrepItem * len(items))(), []
+    for k, it in enumerate(items):
+        a = arr[k]
+        if it[0] == "conv1":
+            _, w, bias = it
+            require_cuda(w)
+            wp = torch.empty(lib.sept_conv1_prep_floats(), dtype=torch.float32, device=device)
+            a.kind, a.src0, a.src1, a.dst0 = PREP_CONV1, w.data_ptr(), _p(bias), wp.data_ptr()
+            outs.append(wp)
+        elif it[0] == "conv5x5":
+            _, w, mode = it
+            require_cuda(w)
+            cout, cin = w.shape[0], w.shape[1]
+            wt = torch.empty((25, cout, cin) if mode == 0 else (25, cin, cout), dtype=torch.bfloat16, device=device)
+            a.kind, a.src0, a.dst0, a.p0, a.p1, a.p2 = PREP_CONV5X5, w.data_ptr(), wt.data_ptr(), cout, cin, int(mode)
+            outs.append(wt)
+        elif it[0] == "gru":
+            _, wif, wir, bif, bir, C, Wd = it
+            require_cuda(wif, wir, bif, bir)
+            G, K = wif.shape
+            wcat = torch.empty((2 * G, K), dtype=torch.float32, device=device)
+            wcatT = torch.empty((K, 2 * G), dtype=torch.float32, device=device)
+            bcat = torch.empty(2 * G, dtype=torch.float32, device=device)
+            a.kind, a.src0, a.src1, a.src2, a.src3 = PREP_GRU, wif.data_ptr(), wir.data_ptr(), bif.data_ptr(), bir.data_ptr()
+            a.dst0, a.dst1, a.dst2, a.p0, a.p1, a.p2, a.p3 = wcat.data_ptr(), wcatT.data_ptr(), bcat.data_ptr(), G, K, int(C), int(Wd)
+            outs.append((wcat, bcat, wcatT))
+        else:
+            raise ValueError(f"prepare_operands: unknown item {it[0]!r}")
+    check(lib.sept_prepare_operands(arr, len(items), current_stream_ptr(device)), "sept_prepare_operands")
+    return outs
+
+
 def _p(t):
     return 0 if t is None else t.data_ptr()
 

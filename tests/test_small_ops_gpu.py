@@ -481,3 +481,39 @@ def test_windows_formed_inside_the_cloak_kernel(T, masked, normed):
     want = ops.cloak_forward(x.view(x.shape[0], -1), locs, rhos, eps, mask, 0.01, 10.0)
     assert lw.shape == (x.shape[0], 1, win, F) and torch.equal(lw.materialise().view_as(x), x)
     assert torch.equal(got, want)
+
+
+def test_fused_operand_prep_equals_the_separate_entries():
+    """sept_prepare_operands: conv1's operand block, 5x5 conv operands in both orientations and the packed recurrent
+    matrices (layer 0 with its column permutation) from ONE launch, bit-identical to sept_conv1_prep /
+    sept_conv5x5_prep_weights / sept_gru_pack; and functional.prepare_operands fills exactly the cache entries the
+    forward / backward passes look up (a second call finds nothing stale)."""
+    from sept_amd import functional as SF, ops
+    g = torch.Generator().manual_seed(13)
+    w1, b1 = torch.randn(32, 1, 5, 5, generator=g).cuda(), torch.randn(32, generator=g).cuda()
+    w2, w3 = torch.randn(64, 32, 5, 5, generator=g).cuda(), torch.randn(128, 64, 5, 5, generator=g).cuda()
+    C, Wd, H = 128, 10, 64
+    wf, wr = torch.randn(3 * H, C * Wd, generator=g).cuda(), torch.randn(3 * H, C * Wd, generator=g).cuda()
+    bf, br = torch.randn(3 * H, generator=g).cuda(), torch.randn(3 * H, generator=g).cuda()
+    wf1, wr1 = torch.randn(3 * H, 2 * H, generator=g).cuda(), torch.randn(3 * H, 2 * H, generator=g).cuda()
+    items = [("conv1", w1, b1), ("conv5x5", w2, 0), ("conv5x5", w2, 1), ("conv5x5", w3, 0), ("conv5x5", w3, 1),
+             ("gru", wf, wr, bf, br, C, Wd), ("gru", wf1, wr1, bf, br, 0, 0), ("conv1", w1, None)]
+    got = ops.prepare_operands(items, w1.device)
+    assert torch.equal(got[0], ops.conv1_prep(w1, b1)) and torch.equal(got[7], ops.conv1_prep(w1, None))
+    for k, (w, mode) in zip((1, 2, 3, 4), ((w2, 0), (w2, 1), (w3, 0), (w3, 1))):
+        assert torch.equal(got[k], ops.conv5x5_prep_weights(w, mode))
+    for k, (a, b, layer) in zip((5, 6), ((wf, wr, 0), (wf1, wr1, 1))):
+        wcat, bcat, wcatT = SF._gru_cat_weights(a, b, bf, br, layer, C, Wd)
+        assert torch.equal(got[k][0], wcat) and torch.equal(got[k][1], bcat) and torch.equal(got[k][2], wcatT)
+    # through the cache of a real network
+    from model import baseline_models as bm
+    m = bm.two_d_cnn_lstm(1, 80, 64, lstm_hidden_size=64, num_layers_lstm=2, pred="gender", attention_size=128, att=None,
+                          global_feature=0).cuda()
+    P = SF.trunk_params(m, "gender")
+    assert SF.prepare_operands(P, 80) == 7            # conv1 + 2 x 2 conv operands + 2 recurrent packs
+    assert SF.prepare_operands(P, 80) == 0            # nothing stale any more
+    assert torch.equal(SF._conv1_operand(P.convs[0]), ops.conv1_prep(m.conv[0].weight, m.conv[0].bias))
+    hit = SF._cached("convdgrad", m.conv[10].weight, lambda: None)
+    assert hit is not None and torch.equal(hit, ops.conv5x5_prep_weights(m.conv[10].weight, 1))
+    SF.invalidate_weight_cache()
+    assert SF.prepare_operands(P, 80, need_dgrad=False) == 5
