@@ -5,7 +5,7 @@
 # the mel kernel, HBM traffic (separate FETCH_SIZE / WRITE_SIZE passes) and the bench line itself.
 set -e
 export TMPDIR=/tmp
-O=$1; R=${2:-r03}
+O=$1; R=${2:-r04}
 mkdir -p $O
 python3 bench.py --steps 20 --warmup 3 > $O/${R}_bench.json 2> $O/bench.err
 rocprofv3 --kernel-trace --output-format csv -d $O/replay -- python3 bench.py --replay-only --steps 30 --warmup 3 > $O/replay.log 2>&1
@@ -31,5 +31,8 @@ head -3 $O/${R}_step_traffic.txt
 # kernel-only timings of every (n_fft, n_mels) the reference extracts (mel1 = 800, mel2 = 1600, default 1024, MFCC 400)
 for nf in 800 1600 1024 400; do for m in 80 128; do python3 tools/bench_mel.py --n_fft $nf --mels $m --iters 30 >> $O/${R}_mel_timings.txt; done; done
 SEPT_STAMPS=1 python3 tools/step_stamps.py > $O/${R}_step_stamps.txt 2>/dev/null
+# the in-kernel launch clock behind the bench line's roofline figure: against HIP events alone / on two streams, and the
+# instrumented capture against the plain one
+python3 tools/kclock_check.py > $O/${R}_kclock_check.txt 2>/dev/null
 rm -rf $O/replay $O/full $O/sq_conv $O/sq_mel $O/inst_mel $O/sq_step $O/pmc_fetch $O/pmc_write
 ls -la $O/${R}_*
