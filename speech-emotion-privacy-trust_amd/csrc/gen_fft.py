@@ -16,7 +16,7 @@ on the m-point sub-transforms.  Sizes needed: n_fft 800 -> 20x20, 1600 -> 40x20,
 import math
 import sys
 
-SIZES = [8, 10, 16, 20, 32, 40]
+SIZES = [8, 10, 16, 20, 25, 32, 40, 50]
 
 
 class Emitter:

@@ -49,6 +49,7 @@ constexpr int kStepBins = 16;  // bins per filterbank step = the K = 32 of one M
 constexpr int kMaxSteps = 64;  // filterbank steps per wave (one header word per lane)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // a 16-byte vector that is only 4-byte aligned
 
 struct MelArgs {
   const float* wav;      // [B][L]
@@ -59,6 +60,8 @@ struct MelArgs {
   const uint4* btab;     // [n_steps][2][64]: B operands of one 16-bin step per lane: 4 bins x (w_hi, w_hi), then 4 bins x (w_lo, w_lo)
   const int* steps;      // [kWaves][kMaxSteps + 2]: per step of the wave (first bin / 16) | flush << 10 | slot << 11 | filter tile << 12;
                          // then the wave's first step in btab and its number of steps
+  const float2* tw16;    // shuffle kernel: [M][16]   W_N^(j * k1) (lane j's twiddle of column-FFT output k1)
+  const float2* ptw2;    // shuffle kernel: [16][MP]  e^{-i pi p / N} at p = k1 + M * k2, laid out [k2][k1] (pitch MP odd)
   int B, L, T, F, layout, tiles_per_clip;
 };
 
@@ -450,6 +453,339 @@ __global__ __launch_bounds__(kWaves * 64, REG_TABLES ? 2 : 1) void sept_mel_stft
 #endif
 }
 
+
+// =======================================================================================================================
+// Shuffle form (round 4): N = 16 * M, SIXTEEN lanes per frame = one DPP row, four frames per wave.
+//
+//   pass A   lane j transforms its decimated column x[j + 16 m], m < M, in registers (FftReg<M>), then multiplies by
+//            W_N^(j k1);
+//   pass B   the 16-point transforms ACROSS the lanes of the row, M of them side by side, as four radix-2 decimation-in-
+//            frequency stages whose partners come through DPP (lane ^ 8: row_ror:8; ^ 4: row_shl:4 / row_shr:4 under bank
+//            masks; ^ 2, ^ 1: quad_perm) -- the butterflies of the north star's "wavefront-shuffle" formulation.  Lane l
+//            ends up with Z[k1 + M * bitrev4(l)], k1 < M;
+//   split    the partner of bin p = k1 + M k2 of the real transform is N - p = (M - k1) + M (15 - k2): the MIRRORED lane
+//            (row_mirror), register M - k1 -- so the post-pass needs no memory either (k1 = 0 pairs k2 with 16 - k2: one
+//            ds_bpermute of one register);
+//   then     |X|^2 as a packed bf16 (hi, lo) pair into the frame's row of P, and the filterbank exactly as above (the 16
+//            frames of a workgroup iteration are the 16 rows of the MFMA A operand), dB and the store straight from the
+//            accumulators.
+// Against the transpose form (sept_mel_stft_kernel) nothing of the frame ever goes through the LDS between the span image
+// and P: 81 LDS-array cycles per frame instead of ~170 and no 40 KB transpose scratch, for ~17 % more VALU instructions
+// (the cross-lane stages are radix 2).  52 KB of LDS and <= 168 VGPRs: three workgroups = three waves per SIMD.
+// Measured (B 256, 5 s clips, F 80): 158 us against 160 us for the transpose form, 162 against 176-182 at F 128; LDS busy
+// 17.6 % against 28.9 %, VALU-active 36.6 % against 29.6 %.  Leaving phases out (tools/mel_prof.hip, -DSEPT_SHFL_ABLATE)
+// prices the transform at ~70 us (its VALU issue floor at three waves per SIMD is ~53) and everything else -- staging,
+// two barriers a tile, filterbank operands (54 KB of table per 16 frames from L2), dB, stores -- at ~88 us; an LDS-DMA
+// prefetch of the next span, a third "free" barrier and staggered workgroups were built and measured neutral or worse
+// (DESIGN.md section 8, round 4).
+template <int M, int HOP>
+struct ShflCfg {
+  static constexpr int L = 16, N = L * M, NFFT = 2 * N;
+  static constexpr int FPW = 4, FPI = FPW * kWaves, TILE = FPI;   // one frame group per tile
+  static constexpr int MP = (M & 1) ? M : M + 1;
+  static constexpr int SPAN = HOP * (TILE - 1) + NFFT;
+  static constexpr int NPP = (N + 1 + kStepBins - 1) / kStepBins * kStepBins;
+  static constexpr int PROW = NPP + 64;     // dwords per row of P: the padded spectrum + room for the bank stagger
+  // lane j of frame g reads the float2 (j + 16 m) of its frame: 16 lanes = 32 consecutive banks; the two frames of a
+  // 32-lane ds_read_b64 group must sit 32 banks apart
+  static_assert(HOP % 64 == 32, "frame pitch must be 32 mod 64 banks (hop 160)");
+  static_assert(HOP % 4 == 0 && SPAN % 4 == 0, "float4 staging");
+};
+
+template <int M, int HOP>
+struct ShflSmem {
+  using C = ShflCfg<M, HOP>;
+  size_t span, p, win, ptw, tw, total;
+  __host__ __device__ ShflSmem() {
+    size_t off = 0;
+    span = off;
+    off = align16(off + sizeof(float) * C::SPAN);
+    p = off;
+    off = align16(off + sizeof(float) * size_t(C::FPI) * C::PROW);
+    win = off;
+    off = align16(off + sizeof(float2) * C::N);
+    ptw = off;
+    off = align16(off + sizeof(float2) * 16 * C::MP);
+    tw = off;
+    off = align16(off + sizeof(float2) * 16 * M);
+    total = off;
+  }
+};
+
+template <int CTRL, int BANK = 0xF>
+__device__ __forceinline__ float dpp(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL,
+                                                               0xF, BANK, false));
+}
+// value of lane ^ H inside the 16-lane row
+template <int H>
+__device__ __forceinline__ float lane_xor(float v) {
+  if constexpr (H == 8) return dpp<0x128>(0.f, v);                          // row_ror:8
+  else if constexpr (H == 4) return dpp<0x114, 0xA>(dpp<0x104, 0x5>(0.f, v), v);   // row_shl:4 into banks 0,2; row_shr:4 into 1,3
+  else if constexpr (H == 2) return dpp<0x4E>(0.f, v);                      // quad_perm [2,3,0,1]
+  else return dpp<0xB1>(0.f, v);                                            // quad_perm [1,0,3,2]
+}
+
+// -DSEPT_SHFL_ABLATE=mask (tools/mel_prof.hip): leave a phase of the shuffle kernel out to time the rest (results are then
+// garbage): 1 span staging, 2 column FFTs, 4 cross-lane stages, 8 split post-pass, 16 filterbank, 32 dB + stores
+#ifndef SEPT_SHFL_ABLATE
+#define SEPT_SHFL_ABLATE 0
+#endif
+template <int M, int HOP>
+__global__ __launch_bounds__(kWaves * 64, 3) void sept_mel_shfl_kernel(MelArgs a) {
+  using C = ShflCfg<M, HOP>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const ShflSmem<M, HOP> lay;
+  float* sp = reinterpret_cast<float*>(smem + lay.span);
+  float* Pall = reinterpret_cast<float*>(smem + lay.p);
+  float2* win = reinterpret_cast<float2*>(smem + lay.win);
+  float2* ptw = reinterpret_cast<float2*>(smem + lay.ptw);
+  float2* tws = reinterpret_cast<float2*>(smem + lay.tw);
+  const int tid = threadIdx.x;
+  constexpr int nthr = kWaves * 64;
+  const int L = a.L, F = a.F, T = a.T;
+  for (int i = tid; i < C::N; i += nthr) win[i] = a.window[i];
+  for (int i = tid; i < 16 * C::MP; i += nthr) ptw[i] = a.ptw2[i];
+  for (int i = tid; i < 16 * M; i += nthr) tws[i] = a.tw16[i];
+
+  const int lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, g = wave * C::FPW + (lane >> 4);      // lane in its row; frame of the group
+  const int k2 = ((j & 1) << 3) | ((j & 2) << 1) | ((j & 4) >> 1) | ((j & 8) >> 3);   // bitrev4(j): pass B leaves it here
+  // row offsets of P: row r starts at bank 8 r (see p_offset of the transpose form: conflict-free b128 reads)
+  auto prow_of = [](int r) { const int base = r * C::PROW; return base + (((8 * r - base) % 64) + 64) % 64; };
+  float* P = Pall + prow_of(g);
+  const float* prow = Pall + prow_of(lane & 15) + 4 * (lane >> 4);
+  // Stage constants of the cross-lane transform.  A radix-2 decimation-in-frequency butterfly is t = x + y in the lower lane
+  // of a pair and t = y - x in the upper one (x own, y partner), then t * w (w = 1 below, W_{2h}^(j mod h) above).  Values are
+  // kept PRE-SIGNED for the stage about to run -- the upper lane holds -x -- so that both lanes evaluate the same
+  // expression t = own + sigma * partner (sigma = -1 below, +1 above): one v_fmac_f32 with the partner as its DPP operand,
+  // in place.  The pre-sign of the next stage is folded into this stage's twiddle, the first stage's into the column
+  // twiddle table (host side).
+  float sg[4];
+  float2 st[3];
+  {
+    const int hs[4] = {8, 4, 2, 1};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bool up = (j & hs[s]) != 0;
+      sg[s] = up ? 1.f : -1.f;
+      if (s < 3) {
+        float sn, cs;
+        const float ang = -3.14159265358979323846f * float(j & (hs[s] - 1)) / float(hs[s]);   // W_{2h}^(j mod h)
+        sincosf(ang, &sn, &cs);
+        const float nxt = (j & hs[s + 1]) ? -1.f : 1.f;                                        // pre-sign of stage s + 1
+        st[s] = up ? make_float2(cs * nxt, sn * nxt) : make_float2(nxt, 0.f);
+      }
+    }
+  }
+  // k1 = 0: bin M k2 pairs with M ((16 - k2) mod 16): the lane of this row that holds it
+  const int k2n = (16 - k2) & 15;
+  const int src0 = (lane & 48) | (((k2n & 1) << 3) | ((k2n & 2) << 1) | ((k2n & 4) >> 1) | ((k2n & 8) >> 3));
+  // this wave's share of the filterbank (whole filter tiles)
+  const int* stp = a.steps + __builtin_amdgcn_readfirstlane(wave) * (kMaxSteps + 2);
+  const int hdr = stp[lane];
+  const int wn = __builtin_amdgcn_readfirstlane(stp[kMaxSteps + 1]);
+  const uint4* bt = a.btab + size_t(__builtin_amdgcn_readfirstlane(stp[kMaxSteps])) * 128 + lane;
+  const int wlast = max(wn, 1) - 1;
+
+  const long n_tiles = long(a.B) * a.tiles_per_clip;
+#ifdef SEPT_MEL_PROF
+  long long tp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_ = __builtin_amdgcn_s_memtime();
+#endif
+  for (long tile_id = blockIdx.x; tile_id < n_tiles; tile_id += gridDim.x) {
+    const int b = tile_id / a.tiles_per_clip;
+    const int t0 = int(tile_id % a.tiles_per_clip) * C::TILE;
+    // Two barriers per tile.  They order LDS traffic only (sept::lds_barrier): __syncthreads() would also drain vmcnt, i.e.
+    // wait for the acknowledgement of the previous tile's dB stores and for operand loads that are meant to stay in flight.
+    // No barrier is needed HERE: the span image was last read before [D] of the previous tile, which this wave has passed,
+    // and the P rows are rewritten only after [B], which no wave passes before all have finished their filterbank reads.
+    if constexpr (!(SEPT_SHFL_ABLATE & 1)) {
+      const float* w = a.wav + size_t(b) * L;
+      const int s0 = t0 * HOP - C::N;
+      const bool interior = (s0 >= 0) && (s0 + C::SPAN <= L) && ((s0 & 3) == 0) && ((reinterpret_cast<uintptr_t>(w) & 15) == 0);
+      if (interior) {
+        const float4* src = reinterpret_cast<const float4*>(w + s0);
+        for (int i = tid; i < C::SPAN / 4; i += nthr) reinterpret_cast<float4*>(sp)[i] = src[i];
+      } else {
+        for (int i = tid; i < C::SPAN; i += nthr) {
+          int s_ = s0 + i;
+          s_ = s_ < 0 ? -s_ : s_;
+          s_ = s_ >= L ? 2 * (L - 1) - s_ : s_;
+          s_ = min(max(s_, 0), L - 1);   // frames past the clip end: value unused
+          sp[i] = w[s_];
+        }
+      }
+    }
+    MEL_T(0)
+    sept::lds_barrier();   // [B] the span image is complete
+    MEL_T(1)
+
+    // ---- pass A: the lane's decimated column, windowed, transformed in registers ----
+    float re[M], im[M];
+    {
+      const float2* fr = reinterpret_cast<const float2*>(sp + g * HOP);
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        const float2 v = fr[j + 16 * m], w = win[j + 16 * m];
+        re[m] = v.x * w.x;
+        im[m] = v.y * w.y;
+      }
+    }
+    if constexpr (!(SEPT_SHFL_ABLATE & 2)) FftReg<M>::run(re, im);
+#pragma unroll
+    for (int k1 = 0; k1 < M; ++k1) {
+      const float2 w = tws[k1 * 16 + j];
+      const float r = re[k1] * w.x - im[k1] * w.y;
+      im[k1] = re[k1] * w.y + im[k1] * w.x;
+      re[k1] = r;
+    }
+    // ---- pass B: 16-point transforms across the lanes of the row (radix-2, decimation in frequency) ----
+#define SEPT_SHFL_STAGE(H, S)                                                  \
+  _Pragma("unroll") for (int k1 = 0; k1 < M; ++k1) {                           \
+    const float tr = __builtin_fmaf(lane_xor<H>(re[k1]), sg[S], re[k1]);       \
+    const float ti = __builtin_fmaf(lane_xor<H>(im[k1]), sg[S], im[k1]);       \
+    if constexpr (S < 3) {                                                     \
+      re[k1] = tr * st[S < 3 ? S : 0].x - ti * st[S < 3 ? S : 0].y;            \
+      im[k1] = tr * st[S < 3 ? S : 0].y + ti * st[S < 3 ? S : 0].x;            \
+    } else {                                                                   \
+      re[k1] = tr;                                                             \
+      im[k1] = ti;                                                             \
+    }                                                                          \
+  }
+    if constexpr (!(SEPT_SHFL_ABLATE & 4)) {
+    SEPT_SHFL_STAGE(8, 0)
+    SEPT_SHFL_STAGE(4, 1)
+    SEPT_SHFL_STAGE(2, 2)
+    SEPT_SHFL_STAGE(1, 3)
+    }
+#undef SEPT_SHFL_STAGE
+    MEL_T(4)
+    // ---- split post-pass in registers: X[p] of the real 2N-point transform from Z[p] and Z[N - p] ----
+    {
+      auto split = [](float p) {   // hi | lo << 16, hi = bf16(p), lo = bf16(p - hi)
+        const __bf16 h = (__bf16)p;
+        const __bf16 l = (__bf16)(p - float(h));
+        return __builtin_bit_cast(float, unsigned(__builtin_bit_cast(unsigned short, h)) |
+                                             (unsigned(__builtin_bit_cast(unsigned short, l)) << 16));
+      };
+      const float2* tqrow = ptw + k2 * C::MP;
+      const float zb0x = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src0 * 4, __builtin_bit_cast(int, re[0])));
+      const float zb0y = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src0 * 4, __builtin_bit_cast(int, im[0])));
+      // one evaluation yields BOTH bins of a pair (p, N - p) -- |E + T|^2 and |E - T|^2 -- and the pair (k1, lane l) /
+      // (M - k1, lane 15 - l) is visited from both sides, so each lane takes the half k1 <= (M - 1) / 2 of its pairs and
+      // writes the partner's bin too (row position (M - k1) + M (15 - k2)); k1 = 0 and, for even M, k1 = M / 2 pair
+      // inside their own register and are evaluated one-sided
+      auto one = [&](int k1, float zbx, float zby, bool both, int other) {
+        const float zax = re[k1], zay = im[k1];
+        const float2 tq = tqrow[k1];
+        // 2E = Za + conj(Zb), 2O = -i (Za - conj(Zb))
+        const float er = zax + zbx, ei = zay - zby;
+        const float orr = zay + zby, oi = zbx - zax;
+        const float tr = orr * tq.x - oi * tq.y, ti = orr * tq.y + oi * tq.x;
+        const float ar = er + tr, ai = ei + ti;
+        P[k1 + M * k2] = split(0.25f * (ar * ar + ai * ai));
+        if (both) {
+          const float br = er - tr, bi = ei - ti;
+          P[other] = split(0.25f * (br * br + bi * bi));
+        }
+      };
+      one(0, zb0x, zb0y, false, 0);
+      if (j == 0) {   // p = 0 also yields the Nyquist bin X[N] (|E - T|^2 of the same evaluation)
+        const float er = re[0] + zb0x, ei = im[0] - zb0y, orr = im[0] + zb0y, oi = zb0x - re[0];
+        const float2 tq = tqrow[0];
+        const float tr = orr * tq.x - oi * tq.y, ti = orr * tq.y + oi * tq.x;
+        const float br = er - tr, bi = ei - ti;
+        P[C::N] = split(0.25f * (br * br + bi * bi));
+      }
+      if constexpr (!(SEPT_SHFL_ABLATE & 8)) {
+#pragma unroll
+        for (int k1 = 1; k1 <= (M - 1) / 2; ++k1)
+          one(k1, dpp<0x140>(0.f, re[M - k1]), dpp<0x140>(0.f, im[M - k1]), true, (M - k1) + M * (15 - k2));   // row_mirror
+        if constexpr (M % 2 == 0) one(M / 2, dpp<0x140>(0.f, re[M / 2]), dpp<0x140>(0.f, im[M / 2]), false, 0);
+      }
+      if (j < C::NPP - (C::N + 1)) P[C::N + 1 + j] = 0.f;   // the zero tail up to a whole 16-bin step
+    }
+    // B operands of the wave's filterbank steps: requested HERE, where the transform's registers have just died, so that
+    // all of them are in flight across the barrier (the table is 2 KB per step from L2: fetched two steps at a time inside
+    // the phase, as the transpose form does, every batch waited ~500 cycles for the next)
+    constexpr int kAll = 8;
+    uint4 bq[kAll][2];
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!(SEPT_SHFL_ABLATE & 16)) {
+#pragma unroll
+      for (int u = 0; u < kAll; ++u) {
+        bq[u][0] = bt[size_t(min(u, wlast)) * 128];
+        bq[u][1] = bt[size_t(min(u, wlast)) * 128 + 64];
+      }
+    }
+    MEL_T(5)
+    sept::lds_barrier();   // [D] the power spectra of the 16 frames are in place
+    MEL_T(6)
+
+    // ---- filterbank on the bf16 matrix pipe (whole filter tiles per wave), dB, store ----
+    if constexpr (!(SEPT_SHFL_ABLATE & 16)) {
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int nfr = min(C::TILE, T - t0);
+      // every operand load is waited for HERE, the surplus ones of a wave with fewer than eight steps included: a load left
+      // outstanding makes hipcc guard its destination registers with vmcnt(0) at their next use -- the sample reads of the
+      // NEXT tile -- and vmcnt(0) there also waits for the acknowledgement of the dB stores issued in between
+      __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0) -- on EVERY path, a wave without steps included
+#pragma unroll 1
+      for (int i0 = 0; i0 < wn; i0 += kAll) {
+        if (i0 > 0) {   // more than eight steps for this wave (wide filterbanks): the rest in groups, waited for
+#pragma unroll
+          for (int u = 0; u < kAll; ++u) {
+            bq[u][0] = bt[size_t(min(i0 + u, wlast)) * 128];
+            bq[u][1] = bt[size_t(min(i0 + u, wlast)) * 128 + 64];
+          }
+          __builtin_amdgcn_s_waitcnt(0x0f70);
+        }
+        int h[kAll];
+        uint4 av[kAll];
+#pragma unroll
+        for (int u = 0; u < kAll; ++u) {
+          h[u] = __builtin_amdgcn_readlane(hdr, min(i0 + u, wlast));
+          av[u] = *reinterpret_cast<const uint4*>(prow + kStepBins * (h[u] & 0x3ff));
+        }
+#pragma unroll
+        for (int u = 0; u < kAll; ++u) {
+          if (i0 + u < wn) {
+            const bf16x8 av8 = __builtin_bit_cast(bf16x8, av[u]);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av8, __builtin_bit_cast(bf16x8, bq[u][1]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av8, __builtin_bit_cast(bf16x8, bq[u][0]), acc, 0, 0, 0);
+            if (h[u] & 0x400) {   // the filter tile is complete: D[row 4 (l >> 4) + i][col l & 15]
+              const int n = (h[u] >> 12) * 16 + (lane & 15), r0 = 4 * (lane >> 4);
+              if (n < F && !(SEPT_SHFL_ABLATE & 32)) {
+                f32x4 db;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) db[i] = power_to_db(acc[i]);
+                if (a.layout == SEPT_MEL_LAYOUT_BFT) {
+                  // the lane's four frames are consecutive floats of filter n's row: one 16-byte store (4-byte aligned: T is
+                  // odd), four lanes = 64 contiguous bytes
+                  float* o = a.out + (size_t(b) * F + n) * T + t0 + r0;
+                  if (r0 + 4 <= nfr) *reinterpret_cast<f32x4u*>(o) = db;
+                  else
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) if (r0 + i < nfr) o[i] = db[i];
+                } else {
+#pragma unroll
+                  for (int i = 0; i < 4; ++i) if (r0 + i < nfr) a.out[(size_t(b) * T + t0 + r0 + i) * F + n] = db[i];
+                }
+              }
+              acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+          }
+        }
+      }
+    }
+    MEL_T(7)
+  }
+#ifdef SEPT_MEL_PROF
+  if (lane == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_mel_prof[i], (unsigned long long)tp_[i]);
+#endif
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------
@@ -462,6 +798,9 @@ struct sept_mel_plan {
   float2* d_window = nullptr;
   float2* d_tw = nullptr;
   float2* d_ptw = nullptr;
+  float2* d_tw16 = nullptr;   // shuffle form
+  float2* d_ptw2 = nullptr;
+  bool shfl = false;
   uint4* d_btab = nullptr;
   int* d_steps = nullptr;
   const void* kernel = nullptr;
@@ -507,6 +846,21 @@ const Variant kVariants[] = {
     SEPT_MEL_VARIANT(400, 160, 10, 20, 10, 2, true),   SEPT_MEL_VARIANT(400, 160, 10, 20, 10, 1, true),
 };
 
+// the shuffle form (sept_mel_shfl_kernel): n_fft = 32 M at hop 160
+struct ShflVariant {
+  int n_fft, hop, M, MP;
+  const void* fn;
+  const char* name;
+  int tile;
+  size_t smem;
+};
+#define SEPT_MEL_SHFL(nfft, hop, m)                                                                                     \
+  {                                                                                                                     \
+    nfft, hop, m, ShflCfg<m, hop>::MP, reinterpret_cast<const void*>(&sept_mel_shfl_kernel<m, hop>),                  \
+        "sept_mel_shfl_kernel<" #m ", " #hop ">", ShflCfg<m, hop>::TILE, ShflSmem<m, hop>().total                       \
+  }
+const ShflVariant kShflVariants[] = {SEPT_MEL_SHFL(800, 160, 25)};
+
 }  // namespace
 
 extern "C" int sept_mel_plan_create(int n_fft, int hop, int n_mels, const float* window_host,
@@ -535,6 +889,10 @@ extern "C" int sept_mel_plan_create(int n_fft, int hop, int n_mels, const float*
   p.kernel = var->fn;
   p.kernel_name = var->name;
   p.tile = var->tile;
+  const ShflVariant* sv = nullptr;
+  for (const ShflVariant& v : kShflVariants)
+    if (v.n_fft == n_fft && v.hop == hop && !getenv("SEPT_MEL_TRANSPOSE_FORM")) sv = &v;   // (the env switch: A/B timing aid)
+  p.shfl = sv != nullptr;
 
   // ---- filterbank as MFMA work: per tile of 16 filters the 8-bin steps that cover its non-zero rows ----
   struct Tile { int k0, steps; };
@@ -551,6 +909,7 @@ extern "C" int sept_mel_plan_create(int n_fft, int hop, int n_mels, const float*
         }
     tiles[t].k0 = lo < 0 ? 0 : lo & ~(kStepBins - 1);
     tiles[t].steps = lo < 0 ? 0 : (hi - tiles[t].k0) / kStepBins + 1;   // all-zero filters: no work, the LDS tile stays 0
+    if (p.shfl && tiles[t].steps == 0) tiles[t].steps = 1;   // (the shuffle form stores from the accumulators: one zero step)
     total += tiles[t].steps;
   }
   p.n_steps = std::max(total, 1);
@@ -570,29 +929,53 @@ extern "C" int sept_mel_plan_create(int n_fft, int hop, int n_mels, const float*
     return f;
   };
   std::vector<uint4> btab(size_t(p.n_steps) * 128, make_uint4(0, 0, 0, 0));
-  std::vector<int> first_step(n_tiles);
-  for (int t = 0, s0 = 0; t < n_tiles; s0 += tiles[t].steps, ++t) {
-    first_step[t] = s0;
-    for (int s = 0; s < tiles[t].steps; ++s)
-      for (int l = 0; l < 64; ++l) {
-        const int m = t * 16 + (l & 15), k = tiles[t].k0 + kStepBins * s + 4 * (l >> 4);
-        unsigned hi[4], lo[4];
-        for (int e = 0; e < 4; ++e) {
-          const float w = (m < n_mels && k + e < p.n_freq) ? fb_host[size_t(k + e) * n_mels + m] : 0.0f;
-          const unsigned short h = bf16_bits(w), lw = bf16_bits(w - bf16_val(h));
-          hi[e] = unsigned(h) | (unsigned(h) << 16);
-          lo[e] = unsigned(lw) | (unsigned(lw) << 16);
-        }
-        btab[(size_t(s0 + s) * 2 + 0) * 64 + l] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-        btab[(size_t(s0 + s) * 2 + 1) * 64 + l] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+  auto fill_step = [&](int t, int s, int dst) {   // step s of filter tile t -> row `dst` of btab
+    for (int l = 0; l < 64; ++l) {
+      const int m = t * 16 + (l & 15), k = tiles[t].k0 + kStepBins * s + 4 * (l >> 4);
+      unsigned hi[4], lo[4];
+      for (int e = 0; e < 4; ++e) {
+        const float w = (m < n_mels && k + e < p.n_freq) ? fb_host[size_t(k + e) * n_mels + m] : 0.0f;
+        const unsigned short h = bf16_bits(w), lw = bf16_bits(w - bf16_val(h));
+        hi[e] = unsigned(h) | (unsigned(h) << 16);
+        lo[e] = unsigned(lw) | (unsigned(lw) << 16);
       }
-  }
-  // deal the steps to the waves in order (each wave gets one contiguous run): a tile is cut between waves at most
-  // once, and its second part then goes to LDS tile 1
+      btab[(size_t(dst) * 2 + 0) * 64 + l] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+      btab[(size_t(dst) * 2 + 1) * 64 + l] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    }
+  };
   std::vector<int> steps(size_t(kWaves) * (kMaxSteps + 2), 0);
   SEPT_REQUIRE(n_tiles <= 256 && p.n_freq / kStepBins < 1024, SEPT_ERR_UNSUPPORTED, "sept_mel_plan_create: n_mels=%d / n_fft=%d too large",
                n_mels, n_fft);
-  {
+  if (p.shfl) {
+    // whole filter tiles per wave (the shuffle form stores straight from its accumulators): longest tile first onto the
+    // least loaded wave; btab is laid out wave by wave so that each wave walks a contiguous run
+    std::vector<int> order(n_tiles), load(kWaves, 0);
+    for (int t = 0; t < n_tiles; ++t) order[t] = t;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return tiles[x].steps > tiles[y].steps; });
+    std::vector<std::vector<int>> mine(kWaves);
+    for (int t : order) {
+      const int w = int(std::min_element(load.begin(), load.end()) - load.begin());
+      mine[w].push_back(t);
+      load[w] += tiles[t].steps;
+    }
+    int flat = 0;
+    for (int w = 0; w < kWaves; ++w) {
+      SEPT_REQUIRE(load[w] <= kMaxSteps, SEPT_ERR_UNSUPPORTED,
+                   "sept_mel_plan_create: n_mels=%d, n_fft=%d need more than %d filterbank steps per wave", n_mels, n_fft, kMaxSteps);
+      steps[size_t(w) * (kMaxSteps + 2) + kMaxSteps] = flat;
+      int at = 0;
+      for (int t : mine[w])
+        for (int c = 0; c < tiles[t].steps; ++c, ++at, ++flat) {
+          fill_step(t, c, flat);
+          steps[size_t(w) * (kMaxSteps + 2) + at] = ((tiles[t].k0 / kStepBins) + c) | (c + 1 == tiles[t].steps ? 0x400 : 0) | (t << 12);
+        }
+      steps[size_t(w) * (kMaxSteps + 2) + kMaxSteps + 1] = at;
+    }
+  } else {
+    for (int t = 0, s0 = 0; t < n_tiles; s0 += tiles[t].steps, ++t)
+      for (int sidx = 0; sidx < tiles[t].steps; ++sidx) fill_step(t, sidx, s0 + sidx);
+    // deal the steps to the waves in order (each wave gets one contiguous run): a tile is cut between waves at most
+    // once, and its second part then goes to LDS tile 1
     const int target = (total + kWaves - 1) / kWaves;
     int wave = 0, load = 0, flat = 0;
     steps[kMaxSteps] = 0;
@@ -623,7 +1006,12 @@ extern "C" int sept_mel_plan_create(int n_fft, int hop, int n_mels, const float*
   }
 
   p.smem = var->smem(n_mels);
-  if (p.smem > 80 * 1024) {  // shallower tile: two workgroups per CU beat the smaller halo
+  if (p.shfl) {
+    p.smem = sv->smem;
+    p.kernel = sv->fn;
+    p.kernel_name = sv->name;
+    p.tile = sv->tile;
+  } else if (p.smem > 80 * 1024) {  // shallower tile: two workgroups per CU beat the smaller halo
     const Variant* alt = var + 1;
     const size_t s1 = alt->smem(n_mels);
     if (s1 <= 80 * 1024 || p.smem > 160 * 1024) {
@@ -641,7 +1029,7 @@ extern "C" int sept_mel_plan_create(int n_fft, int hop, int n_mels, const float*
     for (const Variant& v : kVariants)
       if (v.n_fft == n_fft && v.hop == hop && !deep) deep = &v;
     const Variant* shallow = deep + 1;
-    if (var == deep && shallow->smem(n_mels) <= 160 * 1024) {
+    if (!p.shfl && var == deep && shallow->smem(n_mels) <= 160 * 1024) {
       p.kernel_s = shallow->fn;
       p.kernel_name_s = shallow->name;
       p.tile_s = shallow->tile;
@@ -662,6 +1050,24 @@ extern "C" int sept_mel_plan_create(int n_fft, int hop, int n_mels, const float*
     const double ang = -M_PI * double(q) / N;
     ptw[q] = make_float2(float(std::cos(ang)), float(std::sin(ang)));
   }
+  // shuffle form: W_N^(j k1) per (k1, lane j) and the split twiddle at p = k1 + M k2 laid out [k2][k1]
+  std::vector<float2> tw16, ptw2;
+  if (p.shfl) {
+    const int M = sv->M, MP = sv->MP;
+    tw16.resize(size_t(M) * 16);
+    ptw2.assign(size_t(16) * MP, make_float2(0.f, 0.f));
+    for (int k1 = 0; k1 < M; ++k1)
+      for (int jj = 0; jj < 16; ++jj) {
+        const double ang = -2.0 * M_PI * double((long long)jj * k1 % N) / N;
+        const double pre = (jj & 8) ? -1.0 : 1.0;   // the upper lanes of the first cross-lane stage hold -x (see the kernel)
+        tw16[size_t(k1) * 16 + jj] = make_float2(float(pre * std::cos(ang)), float(pre * std::sin(ang)));
+      }
+    for (int kk2 = 0; kk2 < 16; ++kk2)
+      for (int k1 = 0; k1 < M; ++k1) {
+        const double ang = -M_PI * double(k1 + M * kk2) / N;
+        ptw2[size_t(kk2) * MP + k1] = make_float2(float(std::cos(ang)), float(std::sin(ang)));
+      }
+  }
   sept_mel_plan* h = new sept_mel_plan(p);
   auto up = [&](void** dptr, const void* src, size_t bytes) -> hipError_t {
     hipError_t e = hipMalloc(dptr, bytes);
@@ -671,6 +1077,8 @@ extern "C" int sept_mel_plan_create(int n_fft, int hop, int n_mels, const float*
   hipError_t e = up(reinterpret_cast<void**>(&h->d_window), win.data(), sizeof(float2) * win.size());
   if (e == hipSuccess) e = up(reinterpret_cast<void**>(&h->d_tw), tw.data(), sizeof(float2) * tw.size());
   if (e == hipSuccess) e = up(reinterpret_cast<void**>(&h->d_ptw), ptw.data(), sizeof(float2) * ptw.size());
+  if (e == hipSuccess && p.shfl) e = up(reinterpret_cast<void**>(&h->d_tw16), tw16.data(), sizeof(float2) * tw16.size());
+  if (e == hipSuccess && p.shfl) e = up(reinterpret_cast<void**>(&h->d_ptw2), ptw2.data(), sizeof(float2) * ptw2.size());
   if (e == hipSuccess) e = up(reinterpret_cast<void**>(&h->d_btab), btab.data(), sizeof(uint4) * btab.size());
   if (e == hipSuccess) e = up(reinterpret_cast<void**>(&h->d_steps), steps.data(), sizeof(int) * steps.size());
   if (e == hipSuccess) e = sept::allow_max_lds(h->kernel);
@@ -688,6 +1096,8 @@ extern "C" int sept_mel_plan_destroy(sept_mel_plan* plan) {
   (void)hipFree(plan->d_window);
   (void)hipFree(plan->d_tw);
   (void)hipFree(plan->d_ptw);
+  (void)hipFree(plan->d_tw16);
+  (void)hipFree(plan->d_ptw2);
   (void)hipFree(plan->d_btab);
   (void)hipFree(plan->d_steps);
   delete plan;
@@ -722,6 +1132,8 @@ extern "C" int sept_mel_forward(const sept_mel_plan* plan, const float* wav, int
   a.ptw = plan->d_ptw;
   a.btab = plan->d_btab;
   a.steps = plan->d_steps;
+  a.tw16 = plan->d_tw16;
+  a.ptw2 = plan->d_ptw2;
   a.B = B;
   a.L = L;
   a.T = 1 + L / plan->hop;
@@ -748,7 +1160,8 @@ extern "C" int sept_mel_forward(const sept_mel_plan* plan, const float* wav, int
   a.tiles_per_clip = (a.T + tile - 1) / tile;
   // persistent workgroups (per-lane window / twiddle tables are loaded once, then many tiles)
   const long n_tiles = long(B) * a.tiles_per_clip;
-  const int wg_per_cu = smem <= 80 * 1024 ? 2 : 1;
+  int wg_per_cu = plan->shfl ? int(std::min<size_t>(4, (160 * 1024) / smem)) : (smem <= 80 * 1024 ? 2 : 1);
+  if (const char* e = getenv("SEPT_MEL_WG_PER_CU")) wg_per_cu = std::max(1, atoi(e));   // tuning aid
   dim3 grid(unsigned(std::min<long>(n_tiles, 256L * wg_per_cu))), block(kWaves * 64);
   void* args[] = {&a};
   SEPT_HIP(hipLaunchKernel(kernel, grid, block, args, smem, static_cast<hipStream_t>(stream)));

@@ -7,6 +7,7 @@
 #include "../speech-emotion-privacy-trust_amd/csrc/sept_mel.hip"
 
 #include <cstdio>
+#include <cstring>
 
 int main(int argc, char** argv) {
   const int n_fft = argc > 1 ? atoi(argv[1]) : 800, F = argc > 2 ? atoi(argv[2]) : 80, B = 256, L = 80000, hop = 160;
@@ -61,7 +62,10 @@ int main(int argc, char** argv) {
   printf("%s ablate=%d: %.1f us per launch\n", sept_mel_kernel_name(plan), SEPT_MEL_ABLATE, ms * 1e3 / iters);
   return 0;
 #else
-  const char* names[8] = {"stage span", "pass 1", "pass 2", "post-pass", "barrier (P ready)", "filterbank", "barrier (P used)", "dB + store"};
+  const bool shfl = std::strstr(sept_mel_kernel_name(plan), "shfl") != nullptr;
+  const char* names_t[8] = {"stage span", "pass 1", "pass 2", "post-pass", "barrier (P ready)", "filterbank", "barrier (P used)", "dB + store"};
+  const char* names_s[8] = {"staging / wait", "barrier B", "sample reads", "barrier C", "DMA + FFT + stages", "post-pass + B loads", "barrier D", "filterbank + stores"};
+  const char** names = shfl ? names_s : names_t;
   double tot = 0;
   for (int i = 0; i < 8; ++i) tot += double(z[i]);
   printf("%s: %.1f us per launch (instrumented)\n", sept_mel_kernel_name(plan), ms * 1e3 / iters);
