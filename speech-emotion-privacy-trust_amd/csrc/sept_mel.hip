@@ -474,7 +474,7 @@ __global__ __launch_bounds__(kWaves * 64, REG_TABLES ? 2 : 1) void sept_mel_stft
 // (the cross-lane stages are radix 2).  52 KB of LDS and <= 168 VGPRs: three workgroups = three waves per SIMD.
 // Measured (B 256, 5 s clips, F 80): 158 us against 160 us for the transpose form, 162 against 176-182 at F 128; LDS busy
 // 17.6 % against 28.9 %, VALU-active 36.6 % against 29.6 %.  Leaving phases out (tools/mel_prof.hip, -DSEPT_SHFL_ABLATE)
-// prices the transform at ~70 us (its VALU issue floor at three waves per SIMD is ~53) and everything else -- staging,
+// prices the transform at ~70 us (the kernel's VALU issue floor is ~58: 68.9 M wave-instructions per launch) and everything else -- staging,
 // two barriers a tile, filterbank operands (54 KB of table per 16 frames from L2), dB, stores -- at ~88 us; an LDS-DMA
 // prefetch of the next span, a third "free" barrier and staggered workgroups were built and measured neutral or worse
 // (DESIGN.md section 8, round 4).

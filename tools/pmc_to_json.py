@@ -24,7 +24,7 @@ def tag_of(name):
     m = re.search(r"sept_conv5x5_wgrad_kernel<(\d+), (\d+)", name)
     if m:
         return f"conv5x5_wgrad<{m.group(1)},{m.group(2)}>"
-    if "sept_mel_stft_kernel" in name:
+    if "sept_mel_stft_kernel" in name or "sept_mel_shfl_kernel" in name:
         return "mel"
     return None
 

@@ -19,7 +19,7 @@ def main(run_dir, steps, out_csv):
     steps = int(steps)
     f = glob.glob(f"{run_dir}/**/*kernel_trace.csv", recursive=True)
     rows = sorted(csv.DictReader(open(f[0])), key=lambda r: int(r["Start_Timestamp"]))
-    starts = [i for i, r in enumerate(rows) if "sept_mel_stft_kernel" in r["Kernel_Name"]]
+    starts = [i for i, r in enumerate(rows) if "sept_mel_" in r["Kernel_Name"]]
     if len(starts) < steps:
         raise SystemExit(f"only {len(starts)} step starts in the trace, need {steps}")
     win = rows[starts[-steps]:]

@@ -18,7 +18,7 @@ def main():
     d, step = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 20
     f = glob.glob(d + "/*/*kernel_trace.csv")[0]
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-    idx = [i for i, r in enumerate(rows) if "sept_mel_stft" in r["Kernel_Name"]]
+    idx = [i for i, r in enumerate(rows) if "sept_mel_" in r["Kernel_Name"]]
     s, e = idx[step], idx[step + 1]
     t0 = int(rows[s]["Start_Timestamp"])
     for r in rows[s:e]:
