@@ -455,7 +455,9 @@ __global__ __launch_bounds__(kWaves * 64, REG_TABLES ? 2 : 1) void sept_mel_stft
 
 
 // =======================================================================================================================
-// Shuffle form (round 4): N = 16 * M, SIXTEEN lanes per frame = one DPP row, four frames per wave.
+// Shuffle form (round 4): N = 16 * M, SIXTEEN lanes per frame = one DPP row, four frames per wave.  Instantiated for
+// n_fft 800 (M = 25), 1024 (M = 32) and 1600 (M = 50) at hop 160; measured against the transpose form (B 256, 80 / 128
+// mels, one call): 800: 153-158 / 162 us vs 158-160 / 178; 1024: 231 / 237 vs 276 / 291; 1600: 360 / 368 vs 565 / 586.
 //
 //   pass A   lane j transforms its decimated column x[j + 16 m], m < M, in registers (FftReg<M>), then multiplies by
 //            W_N^(j k1);
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(kWaves * 64, REG_TABLES ? 2 : 1) void sept_mel_stft
 // Against the transpose form (sept_mel_stft_kernel) nothing of the frame ever goes through the LDS between the span image
 // and P: 81 LDS-array cycles per frame instead of ~170 and no 40 KB transpose scratch, for ~17 % more VALU instructions
 // (the cross-lane stages are radix 2).  52 KB of LDS and <= 168 VGPRs: three workgroups = three waves per SIMD.
-// Measured (B 256, 5 s clips, F 80): 158 us against 160 us for the transpose form, 162 against 176-182 at F 128; LDS busy
+// Measured (n_fft 800, B 256, 5 s clips, F 80): 158 us against 160 us for the transpose form, 162 against 176-182 at F 128; LDS busy
 // 17.6 % against 28.9 %, VALU-active 36.6 % against 29.6 %.  Leaving phases out (tools/mel_prof.hip, -DSEPT_SHFL_ABLATE)
 // prices the transform at ~70 us (the kernel's VALU issue floor is ~58: 68.9 M wave-instructions per launch) and everything else -- staging,
 // two barriers a tile, filterbank operands (54 KB of table per 16 frames from L2), dB, stores -- at ~88 us; an LDS-DMA
@@ -488,6 +490,11 @@ struct ShflCfg {
   static constexpr int PROW = NPP + 64;     // dwords per row of P: the padded spectrum + room for the bank stagger
   // lane j of frame g reads the float2 (j + 16 m) of its frame: 16 lanes = 32 consecutive banks; the two frames of a
   // 32-lane ds_read_b64 group must sit 32 banks apart
+  // occupancy target: M = 25 fits 168 VGPRs and 53 KB of LDS (three workgroups per CU); longer columns need ~200 VGPRs, and
+  // from M = 50 on the two twiddle tables (13 KB, read once per tile and lane) stay in global memory / L1 so that two
+  // workgroups fit
+  static constexpr int WPS = M <= 25 ? 3 : 2;
+  static constexpr bool TBL_LDS = M <= 32;
   static_assert(HOP % 64 == 32, "frame pitch must be 32 mod 64 banks (hop 160)");
   static_assert(HOP % 4 == 0 && SPAN % 4 == 0, "float4 staging");
 };
@@ -505,9 +512,9 @@ struct ShflSmem {
     win = off;
     off = align16(off + sizeof(float2) * C::N);
     ptw = off;
-    off = align16(off + sizeof(float2) * 16 * C::MP);
+    if (C::TBL_LDS) off = align16(off + sizeof(float2) * 16 * C::MP);
     tw = off;
-    off = align16(off + sizeof(float2) * 16 * M);
+    if (C::TBL_LDS) off = align16(off + sizeof(float2) * 16 * M);
     total = off;
   }
 };
@@ -532,21 +539,23 @@ __device__ __forceinline__ float lane_xor(float v) {
 #define SEPT_SHFL_ABLATE 0
 #endif
 template <int M, int HOP>
-__global__ __launch_bounds__(kWaves * 64, 3) void sept_mel_shfl_kernel(MelArgs a) {
+__global__ __launch_bounds__(kWaves * 64, (ShflCfg<M, HOP>::WPS)) void sept_mel_shfl_kernel(MelArgs a) {
   using C = ShflCfg<M, HOP>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const ShflSmem<M, HOP> lay;
   float* sp = reinterpret_cast<float*>(smem + lay.span);
   float* Pall = reinterpret_cast<float*>(smem + lay.p);
   float2* win = reinterpret_cast<float2*>(smem + lay.win);
-  float2* ptw = reinterpret_cast<float2*>(smem + lay.ptw);
-  float2* tws = reinterpret_cast<float2*>(smem + lay.tw);
+  const float2* ptw = C::TBL_LDS ? reinterpret_cast<const float2*>(smem + lay.ptw) : a.ptw2;
+  const float2* tws = C::TBL_LDS ? reinterpret_cast<const float2*>(smem + lay.tw) : a.tw16;
   const int tid = threadIdx.x;
   constexpr int nthr = kWaves * 64;
   const int L = a.L, F = a.F, T = a.T;
   for (int i = tid; i < C::N; i += nthr) win[i] = a.window[i];
-  for (int i = tid; i < 16 * C::MP; i += nthr) ptw[i] = a.ptw2[i];
-  for (int i = tid; i < 16 * M; i += nthr) tws[i] = a.tw16[i];
+  if constexpr (C::TBL_LDS) {
+    for (int i = tid; i < 16 * C::MP; i += nthr) reinterpret_cast<float2*>(smem + lay.ptw)[i] = a.ptw2[i];
+    for (int i = tid; i < 16 * M; i += nthr) reinterpret_cast<float2*>(smem + lay.tw)[i] = a.tw16[i];
+  }
 
   const int lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, g = wave * C::FPW + (lane >> 4);      // lane in its row; frame of the group
@@ -708,7 +717,7 @@ __global__ __launch_bounds__(kWaves * 64, 3) void sept_mel_shfl_kernel(MelArgs a
     // B operands of the wave's filterbank steps: requested HERE, where the transform's registers have just died, so that
     // all of them are in flight across the barrier (the table is 2 KB per step from L2: fetched two steps at a time inside
     // the phase, as the transpose form does, every batch waited ~500 cycles for the next)
-    constexpr int kAll = 8;
+    constexpr int kAll = M <= 32 ? 8 : 4;   // (M = 50: the transform's 100 registers leave room for four steps in flight)
     uint4 bq[kAll][2];
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (!(SEPT_SHFL_ABLATE & 16)) {
@@ -859,7 +868,7 @@ struct ShflVariant {
     nfft, hop, m, ShflCfg<m, hop>::MP, reinterpret_cast<const void*>(&sept_mel_shfl_kernel<m, hop>),                  \
         "sept_mel_shfl_kernel<" #m ", " #hop ">", ShflCfg<m, hop>::TILE, ShflSmem<m, hop>().total                       \
   }
-const ShflVariant kShflVariants[] = {SEPT_MEL_SHFL(800, 160, 25)};
+const ShflVariant kShflVariants[] = {SEPT_MEL_SHFL(800, 160, 25), SEPT_MEL_SHFL(1024, 160, 32), SEPT_MEL_SHFL(1600, 160, 50)};
 
 }  // namespace
 
