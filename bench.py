@@ -234,6 +234,10 @@ def main():
     ap.add_argument("--clips-per-gpu", type=int, default=32)
     ap.add_argument("--mels", type=int, default=80)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dp-rehearse", action="store_true",
+                    help="one-GPU rehearsal of the data-parallel schedule over RCCL: a process group of ONE rank, the step as "
+                         "graph -> gradient all-reduce (an identity) -> update graph; the line's `dp` object then reports what "
+                         "the hand-offs around the collective cost (N = 1 only)")
     ap.add_argument("--dp-buckets", type=int, choices=[1, 2], default=1,
                     help="N > 1: 1 = one all-reduce of the flat gradient buffer behind the backward pass (default); 2 = the "
                          "adversary's gradients all-reduced from the join in front of the cloak backward kernel, locs / rhos after it")
@@ -260,6 +264,15 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd))
+    # stdout carries the JSON line and nothing else: libraries write there too (RCCL prints a five-line version banner to
+    # stdout when its first communicator comes up), so file descriptor 1 is pointed at stderr for the run and the line goes
+    # out through a duplicate of the original
+    sys.stdout.flush()
+    line_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
+    def emit(obj):
+        print(json.dumps(obj), file=line_out, flush=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -272,7 +285,14 @@ def main():
     backend = os.environ.get("SEPT_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if a.dp_rehearse and world > 1:
+        raise SystemExit("--dp-rehearse is the one-GPU rehearsal of the schedule an N-GPU run takes anyway")
+    if a.dp_rehearse:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+    if world > 1 or a.dp_rehearse:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -290,12 +310,13 @@ def main():
         res = {"n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "data": "synthetic"}
         res.update(secondary(a, dev))
-        print(json.dumps(res))
+        emit(res)
         return
 
     F, clips = a.mels, a.clips_per_gpu
     model = build(F, dev)
-    trainer = GrlTrainer(model, optimizer="sgd", gender_lambda=0.1, scale_lamda=0.0, buckets=a.dp_buckets)
+    trainer = GrlTrainer(model, optimizer="sgd", gender_lambda=0.1, scale_lamda=0.0, buckets=a.dp_buckets,
+                         rehearse_dp=a.dp_rehearse)
     mean = torch.full((F,), -20.0, device=dev)    # fixed per-mel statistics of the synthetic set
     std = torch.full((F,), 12.0, device=dev)
     pipe = FusedPipeline(trainer, n_mels=F, n_fft=800, mean=mean, std=std)
@@ -324,10 +345,10 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         if rank == 0:
-            print(json.dumps({"mode": "replay-only", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            emit(({"mode": "replay-only", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                               "ms_per_step": round(dt / a.steps * 1e3, 3), "value": round(clips * world * a.steps / dt, 2),
                               "unit": "utterances/s", "config": {"clips_per_gpu": clips, "windows_per_gpu": Bw, "n_mels": F}}))
-        if world > 1:
+        if world > 1 or a.dp_rehearse:
             torch.distributed.destroy_process_group()
         return
     ops.TIMER = ops.KernelTimer()
@@ -554,7 +575,7 @@ def main():
 
     # ---- multi-GPU: what the one exchange of the step costs (event-timed on the stream the trainer enqueues it on) ----
     dp_info = None
-    if world > 1:
+    if trainer.dp:
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         comm, opt = [], []
         for _ in range(5):
@@ -581,7 +602,10 @@ def main():
                    "note": "median of 5 instrumented steps after the timed region: ONE all-reduce of the flat gradient "
                            "buffer behind the captured graph, then the optimiser (its own small captured graph in the timed "
                            "steps); not overlapped with the backward pass (DESIGN.md section 6)"}
-    if world > 1:
+        if a.dp_rehearse:
+            dp_info["rehearsal"] = ("ONE rank: the all-reduce is an identity; ms_per_step of this line is the data-parallel "
+                                    "schedule (graph, collective on the same stream, update graph) over the real backend")
+    if world > 1 or a.dp_rehearse:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     if rank != 0:
@@ -613,7 +637,7 @@ def main():
                                f"+GRL gender adversary fwd+bwd+SGD (BASELINE config 5); {clips} clips "
                                f"({Bw} windows) per GPU per step",
                    "clips_per_gpu": clips, "windows_per_gpu": Bw, "n_mels": F, "n_fft": 800,
-                   "parallelism": f"dp{world}", "optimizer": "sgd", "hip_graph": bool(a.graph), "loss": round(loss_val, 5),
+                   "parallelism": f"dp{world}" + (" (--dp-rehearse: data-parallel schedule over RCCL, one rank)" if a.dp_rehearse else ""), "optimizer": "sgd", "hip_graph": bool(a.graph), "loss": round(loss_val, 5),
                    "input": "resident: the K timed steps replay over one batch already in HBM (the metric's definition); "
                             "the host-fed rate of the same run is under host_fed",
                    "feature_stage_ms": round(feat_ms, 3),
@@ -657,7 +681,7 @@ def main():
     if world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(F)
         res["vs_cpu_baseline"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
-    print(json.dumps(res))
+    emit(res)
 
 
 if __name__ == "__main__":

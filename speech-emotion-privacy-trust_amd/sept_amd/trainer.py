@@ -178,6 +178,10 @@ class _TrainerBase:
         self.world = 1
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
+        # `dp`: the step takes the data-parallel schedule (graph, gradient all-reduce, update graph).  True for world > 1;
+        # GrlTrainer(rehearse_dp=True) forces it on a process group of ONE rank, so that the schedule runs over the real
+        # backend (RCCL) on a one-GPU box -- the exchange is then an identity, everything around it is the real thing
+        self.dp = self.world > 1
         self.optimizer = SeptOptimizer(self)
         self._seed_rng(seed)
 
@@ -273,7 +277,7 @@ class _TrainerBase:
         self._sync_lr()
         self._ensure_state()
         graph = torch.cuda.CUDAGraph()
-        in_graph_update = self.world == 1
+        in_graph_update = not self.dp
         # the derived operands of the TRAINABLE weights (bf16 conv operands, packed GRU matrices) must be rebuilt
         # INSIDE the graph on every replay: drop whatever an earlier eager forward left in the cache so the capture
         # misses, and drop the capture's (graph-private, never executed) entries afterwards so eager code rebuilds.
@@ -312,8 +316,10 @@ class _TrainerBase:
 class GrlTrainer(_TrainerBase):
     def __init__(self, cloak_model, optimizer="sgd", lr=None, momentum=0.9, weight_decay=1e-4, betas=(0.9, 0.98),
                  eps=1e-9, gender_lambda=0.1, scale_lamda=0.0, suppression=False, process_group=None, sync_bn=False,
-                 seed=None, buckets=1):
-        """`buckets` (data-parallel only): 1 = ONE all-reduce of the flat gradient buffer behind the backward pass (default);
+                 seed=None, buckets=1, rehearse_dp=False):
+        """`rehearse_dp`: take the data-parallel schedule although the process group has one rank (needs an initialised
+        process group; tests/test_dp_gpu.py and `bench.py --dp-rehearse` run RCCL this way on a one-GPU box).
+        `buckets` (data-parallel only): 1 = ONE all-reduce of the flat gradient buffer behind the backward pass (default);
         2 = the split at the join in front of the cloak backward kernel (<= 2 buckets overlapped with
         the tail of backward): bucket 1 = every slot behind the cloak's (the adversary's conv / GRU / dense gradients: final
         at that join) is all-reduced ASYNCHRONOUSLY while the cloak backward kernel runs, bucket 2 = dL/dlocs, dL/drhos
@@ -327,6 +333,10 @@ class GrlTrainer(_TrainerBase):
         self._init_optim(optimizer, lr, {"sgd": 1e-3, "adam": 5e-4}, momentum, weight_decay, betas, eps, process_group,
                          seed)
         self.gender_lambda, self.scale_lamda, self.suppression = gender_lambda, scale_lamda, suppression
+        if rehearse_dp:
+            if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+                raise RuntimeError("rehearse_dp=True needs an initialised process group (world size 1 is enough)")
+            self.dp = True
 
     def loss(self, preds, preds_grl, labels_emo, labels_gen, weights, training=True):
         noise = self.model.intermed
@@ -374,7 +384,7 @@ class GrlTrainer(_TrainerBase):
         """(lo, hi) of the cloak parameters' slots when the two-bucket exchange applies -- a data-parallel job, the
         hand-scheduled step, the active set known, dL/dlocs / dL/drhos written in place at the START of the flat buffer
         (cloak_model.parameters() yields `intermed` first) -- else None (single bucket)."""
-        if self.buckets != 2 or self.world == 1 or not self.flat._settled:
+        if self.buckets != 2 or not self.dp or not self.flat._settled:
             return None
         if not (HAND_SCHEDULED and self._hand_schedulable(features)):
             return None
@@ -407,7 +417,7 @@ class GrlTrainer(_TrainerBase):
             return out
         out = self._forward_backward(features, labels_emo, labels_gen, weights, mask, pooling, global_feature)
         self.flat.gather_grads()
-        if self.world > 1:
+        if self.dp:
             # the loss is a mean over the local shard (:150-151), so averaging equal shards gives
             # the global-batch gradient; the scale term is batch independent and survives averaging
             self._allreduce_grads()
@@ -511,7 +521,7 @@ class SynTrainer(_TrainerBase):
         self._sync_lr()
         out = self._forward_backward(features, labels, weights, mask, pooling, global_feature)
         self.flat.gather_grads()
-        if self.world > 1:
+        if self.dp:
             self._allreduce_grads()
         self.optimizer_step()
         return out
@@ -560,7 +570,7 @@ class BaselineTrainer(_TrainerBase):
         self._sync_lr()
         out = self._forward_backward(features, labels, weights)
         self.flat.gather_grads()
-        if self.world > 1:
+        if self.dp:
             self._allreduce_grads()
         self.optimizer_step()
         return out

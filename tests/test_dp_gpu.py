@@ -176,3 +176,48 @@ def test_two_bucket_exchange_equals_the_single_all_reduce():
         assert used[0] is None and used[1] == (0, 2 * W * F) and used[2] == (0, 2 * W * F)    # locs + rhos lead the buffer
         assert eq_eager and eq_graph
     assert torch.equal(ret[0][3], ret[1][3])
+
+
+def _worker_rccl_world1(port, ret):
+    """ONE rank over RCCL (backend "nccl"): the data-parallel schedule -- eager, captured with one bucket, captured with two
+    -- against the single-rank schedule of the same trainer class, three steps each"""
+    import torch.distributed as dist
+    from sept_amd.trainer import GrlTrainer
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    x = closed_form_input(B, W, F).cuda()
+    le, lg, w = (t.cuda() for t in closed_form_labels(B))
+    out, forms = [], []
+    for rehearse, buckets, use_graph in ((False, 1, True), (True, 1, False), (True, 1, True), (True, 2, True)):
+        tr = GrlTrainer(_build(), optimizer="sgd", lr=0.05, gender_lambda=0.1, scale_lamda=0.05, seed=77, buckets=buckets,
+                        rehearse_dp=rehearse)
+        tr.train_step(x, le, lg, w)
+        step = tr.capture(x, le, lg, w) if use_graph else (lambda: tr.train_step(x, le, lg, w))
+        forms.append((tr.dp, getattr(step, "opt_graph", None) is not None, getattr(step, "graph_b", None) is not None))
+        step(), step()
+        torch.cuda.synchronize()
+        out.append(tr.flat.flat.clone().cpu())
+    ret["eq"] = [bool(torch.equal(out[0], o)) for o in out[1:]]
+    ret["forms"] = forms
+    ret["backend"] = str(dist.get_backend())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_schedule_over_rccl_with_one_rank():
+    """The data-parallel step over the REAL backend (RCCL; torch's "nccl") on this one-GPU box: a process group of one
+    rank, GrlTrainer(rehearse_dp=True).  The all-reduce is an identity, but ProcessGroupNCCL's stream hand-offs around it,
+    the graph / collective / graph replay sequence and the two-bucket split at the cloak join are the ones an N-GPU job
+    runs; the parameters after three steps must equal the single-rank schedule's bit for bit."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = 35500 + os.getpid() % 2000
+    p = ctx.Process(target=_worker_rccl_world1, args=(port, ret))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0
+    assert ret["backend"] == "nccl"
+    # (dp schedule?, separate update graph?, two segments?)
+    assert ret["forms"] == [(False, False, False), (True, False, False), (True, True, False), (True, True, True)]
+    assert ret["eq"] == [True, True, True]
