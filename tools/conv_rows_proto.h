@@ -234,6 +234,11 @@ const Variant kVariants[] = {
     SEPT_ROWS_VARIANT(64, 128, 32, 2, 2, 10, 2),
     SEPT_ROWS_VARIANT(64, 32, 32, 4, 1, 5, 2),
     SEPT_ROWS_VARIANT(128, 64, 32, 2, 2, 10, 2),
+#elif defined(SEPT_ROWS_WN1)
+    SEPT_ROWS_VARIANT(32, 64, 16, 4, 1, 5, 3),
+    SEPT_ROWS_VARIANT(64, 128, 16, 4, 1, 5, 3),
+    SEPT_ROWS_VARIANT(64, 32, 16, 4, 1, 5, 3),
+    SEPT_ROWS_VARIANT(128, 64, 16, 4, 1, 5, 3),
 #else
     SEPT_ROWS_VARIANT(32, 64, 32, 2, 2, 5, 3),
     SEPT_ROWS_VARIANT(64, 128, 32, 2, 2, 5, 3),
