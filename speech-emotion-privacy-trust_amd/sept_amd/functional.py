@@ -1189,18 +1189,31 @@ def grl_train_step(model, x, labels_emo, labels_gen, weights, gender_lambda, sca
     s1, s2 = branch_streams(dev)
     with torch.no_grad():
         ops.stamp("step start", dev)
-        # ---- random numbers of the step on s2 while the caller's feature stage runs on cur
-        def draws():
+        # ---- random numbers of the step on s2 while the caller's feature stage runs on cur: the cloak's epsilon and -- so
+        # that neither branch's chain opens with a mask launch -- the dropout masks of both networks (their own Philox call
+        # sites: the same values trunk_forward would draw itself)
+        P1, P2 = trunk_params(emo, 'emotion', att), trunk_params(gen, 'gender', att)
+        pre_masks = {}
+
+        def draws(xs=None):
             ops.begin_step(dev)
-            return noise._epsilon(1)
+            e = noise._epsilon(1)
+            if xs is not None:
+                for P, site, inj in ((P1, SITE_EMOTION, inj1), (P2, SITE_GENDER, inj2)):
+                    if P.training:
+                        pre_masks[id(P)] = step_masks(P, xs[0], xs[-2], dev, inj or getattr(P, "injected", None), site)
+            return e
         if two and before_cloak is not None:
             s2.wait_stream(cur)             # recorded BEFORE the feature stage is enqueued: s2 runs beside it
             x = before_cloak()
             with torch.cuda.stream(s2):
-                eps = draws()
+                eps = draws(x.shape)
             cur.wait_stream(s2)
             if not capturing:
                 eps.record_stream(cur)
+                for md in pre_masks.values():
+                    for t in md.values():
+                        t.record_stream(s1), t.record_stream(s2)
         else:
             eps = draws()
             if before_cloak is not None:
@@ -1216,7 +1229,6 @@ def grl_train_step(model, x, labels_emo, labels_gen, weights, gender_lambda, sca
         xw = xn.view(B, shape[-2], shape[-1])
         ops.stamp("cloak forward done")
         need_dx = locs.requires_grad or rhos.requires_grad
-        P1, P2 = trunk_params(emo, 'emotion', att), trunk_params(gen, 'gender', att)
         need_w2 = any(p.requires_grad for p in _param_list(P2))
         need_w1 = any(p.requires_grad for p in _param_list(P1))
         scale_mean = None
@@ -1228,7 +1240,7 @@ def grl_train_step(model, x, labels_emo, labels_gen, weights, gender_lambda, sca
         def fwd(P):
             tag = "emotion" if P is P1 else "gender"
             ops.stamp(tag + " forward starts")
-            r = trunk_forward(xw, P, pool, need_grad=True, gfeat=global_feature,
+            r = trunk_forward(xw, P, pool, need_grad=True, gfeat=global_feature, masks=pre_masks.get(id(P)),
                               rng_site=SITE_EMOTION if P is P1 else SITE_GENDER, injected=inj1 if P is P1 else inj2)
             ops.stamp(tag + " forward done")
             return r
