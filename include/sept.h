@@ -516,6 +516,13 @@ int sept_head_forward(const float* x, const float* W1, const float* b1, const fl
 int sept_head_backward(const float* dlogits, const float* Wh, const float* d1, const float* dropscale,
                        const float* W1, float* dd1, float* dx, int B, int T, int D, int D1, int NC,
                        void* stream);
+/* sept_head_backward with the incoming gradient formed in the kernel: dlogits = scale * w_b * (softmax(logits_b) - onehot(label_b)),
+ * sept_cross_entropy's expression (training_cloak_with_grl.py:143-151: the weighted cross-entropy of one prediction layer,
+ * NC <= 8 classes); `dlogits` (B, NC) is written for the head's weight gradients.  The loss VALUE still comes from
+ * sept_cross_entropy (which may then run anywhere behind the head's forward pass, off the backward chain). */
+int sept_head_backward_ce(const float* logits, const long long* labels, const float* weights, float scale,
+                          const float* Wh, const float* d1, const float* dropscale, const float* W1, float* dlogits,
+                          float* dd1, float* dx, int B, int T, int D, int D1, int NC, void* stream);
 
 /* Multi-head self-attention pooling of two_d_cnn_lstm with att='self_att' (baseline_models.py:233-242,
  * cloak_models.py:178-186): scores (B, T, NH) = att_linear2(tanh(att_linear1(x))) come from sept_gemm +

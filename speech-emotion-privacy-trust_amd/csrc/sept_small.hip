@@ -732,14 +732,38 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* x, const flo
 }
 // data path of the backward pass: d_d1a = dlogits Wh; d_d1 = d_d1a * (d1 > 0) * dropscale; dz = d_d1 W1;
 // dx[b][t][:] = dz / T.  d_d1 is also returned (operand of the weight gradients, which stay separate GEMMs).
-__global__ __launch_bounds__(256) void head_bwd_kernel(const float* dlogits, const float* Wh, const float* d1,
+// CE: the incoming gradient is that of the weighted cross-entropy of THESE logits (ce_kernel's expression, same
+// operations in the same order: dlogits = scale w_b (softmax - onehot)), formed here instead of being read -- the loss
+// kernel then no longer stands between the head's forward and backward launches on the chain; `dlogits` is written
+// (the head's weight gradients read it).
+constexpr int kHeadMaxNC = 8;
+template <bool CE>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* dlogits_in, const float* Wh, const float* d1,
                                                        const float* drop, const float* W1, float* dd1, float* dx, int T,
-                                                       int D, int D1, int NC) {
+                                                       int D, int D1, int NC, const float* logits, const long long* labels,
+                                                       const float* wts, float scale, float* dlogits_out) {
   __shared__ float gs[kHeadMaxD];
+  __shared__ float dls[kHeadMaxNC];
   const int b = blockIdx.x, tid = threadIdx.x;
+  if constexpr (CE) {
+    if (tid < NC) {
+      const float* l = logits + size_t(b) * NC;
+      float mx = l[0];
+      for (int c = 1; c < NC; ++c) mx = fmaxf(mx, l[c]);
+      float se = 0.f;
+      for (int c = 0; c < NC; ++c) se += expf(l[c] - mx);
+      const float lse = mx + logf(se);
+      const int y = int(labels[b]);
+      const float wi = wts ? wts[b] : 1.0f;
+      const float v = scale * wi * (expf(l[tid] - lse) - (tid == y ? 1.0f : 0.0f));
+      dls[tid] = v;
+      dlogits_out[size_t(b) * NC + tid] = v;
+    }
+    __syncthreads();
+  }
   if (tid < D1) {
     float s = 0.f;
-    for (int c = 0; c < NC; ++c) s = fmaf(dlogits[size_t(b) * NC + c], Wh[size_t(c) * D1 + tid], s);
+    for (int c = 0; c < NC; ++c) s = fmaf(CE ? dls[c] : dlogits_in[size_t(b) * NC + c], Wh[size_t(c) * D1 + tid], s);
     const float g = d1[size_t(b) * D1 + tid] > 0.f ? s * (drop ? drop[size_t(b) * D1 + tid] : 1.0f) : 0.f;
     gs[tid] = g;
     dd1[size_t(b) * D1 + tid] = g;
@@ -1227,8 +1251,22 @@ extern "C" int sept_head_backward(const float* dlogits, const float* Wh, const f
   if (B == 0) return SEPT_OK;
   SEPT_REQUIRE(dlogits && Wh && d1 && W1 && dd1 && dx && B > 0 && T > 0 && D > 0 && D <= kHeadMaxD && D1 > 0 &&
                    D1 <= kHeadMaxD && NC > 0, SEPT_ERR_INVALID, "sept_head_backward: B=%d T=%d D=%d D1=%d NC=%d", B, T, D, D1, NC);
-  hipLaunchKernelGGL(head_bwd_kernel, dim3(B), dim3(256), 0, ST(stream), dlogits, Wh, d1, dropscale, W1, dd1, dx, T, D, D1,
-                     NC);
+  hipLaunchKernelGGL(head_bwd_kernel<false>, dim3(B), dim3(256), 0, ST(stream), dlogits, Wh, d1, dropscale, W1, dd1, dx, T, D,
+                     D1, NC, static_cast<const float*>(nullptr), static_cast<const long long*>(nullptr),
+                     static_cast<const float*>(nullptr), 0.f, static_cast<float*>(nullptr));
+  return sept::launch_check("head_bwd_kernel");
+}
+
+extern "C" int sept_head_backward_ce(const float* logits, const long long* labels, const float* weights, float scale,
+                                     const float* Wh, const float* d1, const float* dropscale, const float* W1,
+                                     float* dlogits, float* dd1, float* dx, int B, int T, int D, int D1, int NC,
+                                     void* stream) {
+  if (B == 0) return SEPT_OK;
+  SEPT_REQUIRE(logits && labels && dlogits && Wh && d1 && W1 && dd1 && dx && B > 0 && T > 0 && D > 0 && D <= kHeadMaxD &&
+                   D1 > 0 && D1 <= kHeadMaxD && NC > 0 && NC <= kHeadMaxNC,
+               SEPT_ERR_INVALID, "sept_head_backward_ce: B=%d T=%d D=%d D1=%d NC=%d", B, T, D, D1, NC);
+  hipLaunchKernelGGL(head_bwd_kernel<true>, dim3(B), dim3(256), 0, ST(stream), static_cast<const float*>(nullptr), Wh, d1,
+                     dropscale, W1, dd1, dx, T, D, D1, NC, logits, labels, weights, scale, dlogits);
   return sept::launch_check("head_bwd_kernel");
 }
 

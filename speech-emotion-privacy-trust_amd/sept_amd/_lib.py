@@ -131,6 +131,7 @@ SIGNATURES = {
     "sept_lstm_backward": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_void_p]),
     "sept_head_forward": (c_int, [c_void_p] * 10 + [c_int] * 5 + [c_void_p]),
     "sept_head_backward": (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p]),
+    "sept_head_backward_ce": (c_int, [c_void_p] * 3 + [c_float] + [c_void_p] * 7 + [c_int] * 5 + [c_void_p]),
     "sept_scale_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
     "sept_gru_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                               c_void_p, c_void_p]),

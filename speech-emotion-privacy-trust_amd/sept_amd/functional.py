@@ -492,10 +492,18 @@ def _into(out, src):
     return src if out is None else ops.copy_into(out, src.contiguous())
 
 
-def trunk_backward(S, P, dlogits, need_wgrad=True, need_dx=True, sum_dx=False):
+def head_ce_fusable(S, P):
+    """the head's backward kernel can form the cross-entropy gradient itself (ops.head_backward_ce): fused head, ONE
+    prediction layer of at most 8 classes"""
+    return bool(getattr(S, "fused_head", False)) and len(P.heads) == 1 and P.heads[0].weight.shape[0] <= 8
+
+
+def trunk_backward(S, P, dlogits, need_wgrad=True, need_dx=True, sum_dx=False, ce=None):
     """Returns (dx (B,H,W) fp32 or None, grads: dict parameter-tensor-id -> gradient) for one
     network.  With need_wgrad False (frozen model) only the data path is evaluated.  Weight gradients are
     written straight into the flat gradient buffer of the trainer that owns the parameters (grad_out).
+    `ce` = (logits, labels, weights, scale) instead of `dlogits` (head_ce_fusable(S, P) only): the gradient of the weighted
+    cross-entropy is formed inside the head's backward kernel, so no loss kernel stands on the chain in front of it.
     sum_dx: the caller only needs the input gradient SUMMED over the batch (the cloak's backward pass: its parameters are
     shared by every sample) -- dx may then come back as (1,H,W), formed without any per-sample pass (pool-first block 1)."""
     B, T = S.B, S.T
@@ -506,12 +514,19 @@ def trunk_backward(S, P, dlogits, need_wgrad=True, need_dx=True, sum_dx=False):
         if need_wgrad and param is not None and param.requires_grad:
             grads[param] = g
 
-    dlogits = dlogits.contiguous()
-    sq = _SideQueue(dlogits.device, need_wgrad)
+    if ce is not None:
+        if not head_ce_fusable(S, P):
+            raise SeptError("trunk_backward(ce=...): this head does not take the fused cross-entropy gradient")
+    else:
+        dlogits = dlogits.contiguous()
+    sq = _SideQueue(S.d1.device if ce is not None else dlogits.device, need_wgrad)
     Hh = S.Hh
     H2, G = 2 * Hh, (4 if S.lstm else 3) * Hh
     if S.fused_head:
-        d_d1, dout = ops.head_backward(dlogits, S.wh, S.d1, S.dmask, P.dense1.weight, T)
+        if ce is not None:
+            dlogits, d_d1, dout = ops.head_backward_ce(ce[0], ce[1], ce[2], ce[3], S.wh, S.d1, S.dmask, P.dense1.weight, T)
+        else:
+            d_d1, dout = ops.head_backward(dlogits, S.wh, S.d1, S.dmask, P.dense1.weight, T)
         if need_wgrad:
             def head_wgrads():
                 c0 = 0
@@ -1245,13 +1260,27 @@ def grl_train_step(model, x, labels_emo, labels_gen, weights, gender_lambda, sca
             ops.stamp(tag + " forward done")
             return r
 
+        # The loss VALUE is needed by nobody inside the step: where the head's backward kernel can form the cross-entropy
+        # gradient itself, the loss kernels of both networks leave the chains' heads and run at the END of the frozen
+        # branch's chain (the shorter one), behind the join that follows the forward passes.
+        loss_jobs = []
+
         def bwd(P, logits, S, labels, coef, loss_slot, need_w, with_scale):
             tag = "emotion" if P is P1 else "gender"
             ops.stamp(tag + " backward starts")
-            d = ops.cross_entropy(logits, labels, weights, coef / B, loss_slot)
-            if with_scale and scale_mean is not None:
-                ops.loss_sub_log(loss_slot, scale_mean, float(scale_lamda))
-            r = trunk_backward(S, P, d, need_wgrad=need_w, need_dx=need_dx, sum_dx=True) if (need_w or need_dx) else (None, {})
+
+            def loss_value(want_grad):
+                d_ = ops.cross_entropy(logits, labels, weights, coef / B, loss_slot, want_grad=want_grad)
+                if with_scale and scale_mean is not None:
+                    ops.loss_sub_log(loss_slot, scale_mean, float(scale_lamda))
+                return d_
+            if two and (need_w or need_dx) and head_ce_fusable(S, P):
+                loss_jobs.append((lambda: loss_value(False), logits))
+                r = trunk_backward(S, P, None, need_wgrad=need_w, need_dx=need_dx, sum_dx=True,
+                                   ce=(logits, labels, weights, coef / B))
+            else:
+                d = loss_value(True)
+                r = trunk_backward(S, P, d, need_wgrad=need_w, need_dx=need_dx, sum_dx=True) if (need_w or need_dx) else (None, {})
             ops.stamp(tag + " backward done")
             return r
 
@@ -1298,6 +1327,10 @@ def grl_train_step(model, x, labels_emo, labels_gen, weights, gender_lambda, sca
                             res[st] = (logits,) + bwd(P, logits, S, lab, coef, slot, nw, sc)
                     with torch.cuda.stream(s1):
                         _run_tail_wgrads(dev)
+                        for job, lg in loss_jobs:   # both forward passes are behind s1 since the join above
+                            if not capturing:
+                                lg.record_stream(s1)
+                            job()
                 finally:
                     _TAIL_WGRADS["list"] = None
                 saved.clear()

@@ -1049,6 +1049,22 @@ def head_backward(dlogits, Wh, d1, dropscale, W1, T):
     return dd1, dx
 
 
+def head_backward_ce(logits, labels, weights, scale_, Wh, d1, dropscale, W1, T):
+    """head_backward whose incoming gradient is that of the weighted cross-entropy of `logits` (cross_entropy's expression,
+    formed in the kernel) -> (dlogits (B,NC), dd1 (B,D1), dx (B,T,D))."""
+    B, NC = logits.shape
+    D1, D = W1.shape
+    labels = labels.reshape(-1)
+    assert labels.dtype == torch.int64 and labels.numel() == B
+    dl = torch.empty_like(logits)
+    dd1 = torch.empty((B, D1), dtype=torch.float32, device=logits.device)
+    dx = torch.empty((B, T, D), dtype=torch.float32, device=logits.device)
+    check(lib.sept_head_backward_ce(logits.data_ptr(), labels.data_ptr(), _p(weights), float(scale_), Wh.data_ptr(),
+                                    d1.data_ptr(), _p(dropscale), W1.data_ptr(), dl.data_ptr(), dd1.data_ptr(), dx.data_ptr(),
+                                    B, T, D, D1, NC, _s(logits)), "sept_head_backward_ce")
+    return dl, dd1, dx
+
+
 def mean_t_forward(x):
     B, T, D = x.shape
     z = torch.empty((B, D), dtype=torch.float32, device=x.device)
