@@ -517,3 +517,38 @@ def test_fused_operand_prep_equals_the_separate_entries():
     assert hit is not None and torch.equal(hit, ops.conv5x5_prep_weights(m.conv[10].weight, 1))
     SF.invalidate_weight_cache()
     assert SF.prepare_operands(P, 80, need_dgrad=False) == 5
+
+
+@pytest.mark.parametrize("NC,use_w,drop", [(4, True, True), (2, False, False), (6, True, False)])
+def test_head_backward_with_the_cross_entropy_gradient_formed_in_the_kernel(NC, use_w, drop):
+    """sept_head_backward_ce == sept_cross_entropy + sept_head_backward bit for bit, and both follow torch autograd through
+    mean_t -> dense1 -> ReLU (* dropout scale) -> prediction layer -> weighted cross-entropy (baseline_models.py:231-258,
+    training_cloak_with_grl.py:143-151)."""
+    from sept_amd import ops
+    torch.manual_seed(5)
+    B, T, D, D1 = 37, 25, 128, 128
+    x = torch.randn(B, T, D)
+    W1, b1 = torch.randn(D1, D) * 0.1, torch.randn(D1) * 0.1
+    Wh, bh = torch.randn(NC, D1) * 0.2, torch.randn(NC) * 0.1
+    labels = torch.randint(0, NC, (B,))
+    w = (torch.rand(B) + 0.5) if use_w else None
+    mask = ((torch.rand(B, D1) > 0.2).float() / 0.8) if drop else None
+    scale = 0.1 / B
+    c = lambda t: None if t is None else t.cuda()
+    logits, z, d1, d1a = ops.head_forward(c(x), c(W1), c(b1), c(mask), c(Wh), c(bh))
+    loss = torch.zeros((), device="cuda")
+    dl = ops.cross_entropy(logits, c(labels), c(w), scale, loss)
+    dd1, dx = ops.head_backward(dl, c(Wh), d1, c(mask), c(W1), T)
+    dl2, dd1_2, dx2 = ops.head_backward_ce(logits, c(labels), c(w), scale, c(Wh), d1, c(mask), c(W1), T)
+    assert torch.equal(dl, dl2) and torch.equal(dd1, dd1_2) and torch.equal(dx, dx2)
+    xr = x.clone().requires_grad_(True)
+    a = torch.relu(xr.mean(1) @ W1.T + b1)
+    if mask is not None:
+        a = a * mask
+    lg = a @ Wh.T + bh
+    ce = torch.nn.functional.cross_entropy(lg, labels, reduction="none")
+    ref = scale * ((ce * w).sum() if w is not None else ce.sum())
+    ref.backward()
+    torch.testing.assert_close(logits.cpu(), lg.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(loss.cpu(), ref.detach(), rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(dx2.cpu(), xr.grad, rtol=1e-3, atol=1e-8)
