@@ -653,8 +653,9 @@ def main():
                                  "instrumented capture of the same step.  Alone, this clock and HIP events agree within 5 % "
                                  "(profiles/r04_kclock_check.txt); a rocprofv3 kernel trace of the replay "
                                  "(profiles/r04_replay_kernel_stats.csv) slows the submission of the graph's nodes "
-                                 "(2.1-2.2 ms per step under the tracer), the two branches overlap less, and it reads "
-                                 "10-30 % SHORTER for kernels that co-run in the real replay (DESIGN.md section 4)",
+                                 "(2.1-2.2 ms per step under the tracer) and with it which kernels co-run: its averages for "
+                                 "co-running kernels differ from this clock by -15 ... +18 % from call to call (DESIGN.md "
+                                 "section 4)",
                          "launches_per_step": in_replay[dominant][0],
                          "by_kernel_ms": {t: [n, round(ms, 4)] for t, (n, ms) in sorted(in_replay.items())},
                          "by_kernel_frac": {t: round(conv_flops(t, Bw, F) / (ms * 1e-3) / MFMA_PEAK, 4)
