@@ -1264,6 +1264,7 @@ def grl_train_step(model, x, labels_emo, labels_gen, weights, gender_lambda, sca
         # gradient itself, the loss kernels of both networks leave the chains' heads and run at the END of the frozen
         # branch's chain (the shorter one), behind the join that follows the forward passes.
         loss_jobs = []
+        loss_sum = None
 
         def bwd(P, logits, S, labels, coef, loss_slot, need_w, with_scale):
             tag = "emotion" if P is P1 else "gender"
@@ -1331,6 +1332,8 @@ def grl_train_step(model, x, labels_emo, labels_gen, weights, gender_lambda, sca
                             if not capturing:
                                 lg.record_stream(s1)
                             job()
+                        if len(loss_jobs) == 2:     # both loss values were formed here: their sum too, off the step's tail
+                            loss_sum = ops.add(loss_a, loss_b)
                 finally:
                     _TAIL_WGRADS["list"] = None
                 saved.clear()
@@ -1342,7 +1345,7 @@ def grl_train_step(model, x, labels_emo, labels_gen, weights, gender_lambda, sca
             _DEFERRED["pending"].clear()
             (l1, dx1, g1), (l2, dx2, g2) = res[s1], res[s2]
             if not capturing:
-                for t in (l1, l2, dx1, dx2, loss_a, loss_b):
+                for t in (l1, l2, dx1, dx2, loss_a, loss_b, loss_sum):
                     if t is not None:
                         t.record_stream(cur)
         else:
@@ -1368,7 +1371,7 @@ def grl_train_step(model, x, labels_emo, labels_gen, weights, gender_lambda, sca
                 locs.grad = dlocs
             if rhos.requires_grad:
                 rhos.grad = drhos
-        loss = ops.add(loss_a, loss_b)
+        loss = loss_sum if loss_sum is not None else ops.add(loss_a, loss_b)
         ops.stamp("gradients done")
         for grads in (g1, g2):
             for p, g in grads.items():
