@@ -455,9 +455,11 @@ __global__ __launch_bounds__(kWaves * 64, REG_TABLES ? 2 : 1) void sept_mel_stft
 
 
 // =======================================================================================================================
-// Shuffle form (round 4): N = 16 * M, SIXTEEN lanes per frame = one DPP row, four frames per wave.  Instantiated for
-// n_fft 800 (M = 25), 1024 (M = 32) and 1600 (M = 50) at hop 160; measured against the transpose form (B 256, 80 / 128
-// mels, one call): 800: 153-158 / 162 us vs 158-160 / 178; 1024: 231 / 237 vs 276 / 291; 1600: 360 / 368 vs 565 / 586.
+// Shuffle form (round 4): N = L * M, L = SIXTEEN lanes per frame = one DPP row, four frames per wave (the description below)
+// or EIGHT (half a row, eight frames per wave, 32-frame tiles = two row groups per filterbank operand).  Instantiated for
+// n_fft 800 (M = 25), 1024 (M = 32) and 1600 (M = 50) at hop 160 with L = 16 and for n_fft 400 at hop 200 (the MFCC front
+// end) with L = 8; measured against the transpose form (B 256, 80 / 128 mels, one call): 800: 153-158 / 162 us vs
+// 158-160 / 178; 1024: 231 / 237 vs 276 / 291; 1600: 360 / 368 vs 565 / 586; 400 / hop 200 / 128 mels: 74-75 vs 158.5.
 //
 //   pass A   lane j transforms its decimated column x[j + 16 m], m < M, in registers (FftReg<M>), then multiplies by
 //            W_N^(j k1);
@@ -480,10 +482,13 @@ __global__ __launch_bounds__(kWaves * 64, REG_TABLES ? 2 : 1) void sept_mel_stft
 // two barriers a tile, filterbank operands (54 KB of table per 16 frames from L2), dB, stores -- at ~88 us; an LDS-DMA
 // prefetch of the next span, a third "free" barrier and staggered workgroups were built and measured neutral or worse
 // (DESIGN.md section 8, round 4).
-template <int M, int HOP>
+template <int M, int HOP, int LN = 16>
 struct ShflCfg {
-  static constexpr int L = 16, N = L * M, NFFT = 2 * N;
-  static constexpr int FPW = 4, FPI = FPW * kWaves, TILE = FPI;   // one frame group per tile
+  // L lanes per frame: 16 (one DPP row) or 8 (half a row: n_fft 400 = 2 * 8 * 25, the MFCC front end)
+  static constexpr int L = LN, LG = (LN == 16 ? 4 : 3), N = L * M, NFFT = 2 * N;
+  static constexpr int FPW = 64 / L, FPI = FPW * kWaves, TILE = FPI;   // one frame group per tile
+  static constexpr int MT = TILE / 16;                                  // 16-frame row groups of the filterbank product
+  static_assert(LN == 16 || LN == 8, "lanes per frame");
   static constexpr int MP = (M & 1) ? M : M + 1;
   static constexpr int SPAN = HOP * (TILE - 1) + NFFT;
   static constexpr int NPP = (N + 1 + kStepBins - 1) / kStepBins * kStepBins;
@@ -493,15 +498,17 @@ struct ShflCfg {
   // occupancy target: M = 25 fits 168 VGPRs and 53 KB of LDS (three workgroups per CU); longer columns need ~200 VGPRs, and
   // from M = 50 on the two twiddle tables (13 KB, read once per tile and lane) stay in global memory / L1 so that two
   // workgroups fit
-  static constexpr int WPS = M <= 25 ? 3 : 2;
+  static constexpr int WPS = (M <= 25 && L == 16) ? 3 : 2;
   static constexpr bool TBL_LDS = M <= 32;
-  static_assert(HOP % 64 == 32, "frame pitch must be 32 mod 64 banks (hop 160)");
+  // (hop 200 with eight lanes per frame: neighbouring frames of a ds_read_b64 group overlap in 8 of their 16 banks --
+  // two-way conflicts on the sample reads, accepted)
+  static_assert(L == 8 || HOP % 64 == 32, "frame pitch must be 32 mod 64 banks (hop 160)");
   static_assert(HOP % 4 == 0 && SPAN % 4 == 0, "float4 staging");
 };
 
-template <int M, int HOP>
+template <int M, int HOP, int LN = 16>
 struct ShflSmem {
-  using C = ShflCfg<M, HOP>;
+  using C = ShflCfg<M, HOP, LN>;
   size_t span, p, win, ptw, tw, total;
   __host__ __device__ ShflSmem() {
     size_t off = 0;
@@ -512,9 +519,9 @@ struct ShflSmem {
     win = off;
     off = align16(off + sizeof(float2) * C::N);
     ptw = off;
-    if (C::TBL_LDS) off = align16(off + sizeof(float2) * 16 * C::MP);
+    if (C::TBL_LDS) off = align16(off + sizeof(float2) * C::L * C::MP);
     tw = off;
-    if (C::TBL_LDS) off = align16(off + sizeof(float2) * 16 * M);
+    if (C::TBL_LDS) off = align16(off + sizeof(float2) * C::L * M);
     total = off;
   }
 };
@@ -538,11 +545,11 @@ __device__ __forceinline__ float lane_xor(float v) {
 #ifndef SEPT_SHFL_ABLATE
 #define SEPT_SHFL_ABLATE 0
 #endif
-template <int M, int HOP>
-__global__ __launch_bounds__(kWaves * 64, (ShflCfg<M, HOP>::WPS)) void sept_mel_shfl_kernel(MelArgs a) {
-  using C = ShflCfg<M, HOP>;
+template <int M, int HOP, int LN = 16>
+__global__ __launch_bounds__(kWaves * 64, (ShflCfg<M, HOP, LN>::WPS)) void sept_mel_shfl_kernel(MelArgs a) {
+  using C = ShflCfg<M, HOP, LN>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const ShflSmem<M, HOP> lay;
+  const ShflSmem<M, HOP, LN> lay;
   float* sp = reinterpret_cast<float*>(smem + lay.span);
   float* Pall = reinterpret_cast<float*>(smem + lay.p);
   float2* win = reinterpret_cast<float2*>(smem + lay.win);
@@ -553,32 +560,37 @@ __global__ __launch_bounds__(kWaves * 64, (ShflCfg<M, HOP>::WPS)) void sept_mel_
   const int L = a.L, F = a.F, T = a.T;
   for (int i = tid; i < C::N; i += nthr) win[i] = a.window[i];
   if constexpr (C::TBL_LDS) {
-    for (int i = tid; i < 16 * C::MP; i += nthr) reinterpret_cast<float2*>(smem + lay.ptw)[i] = a.ptw2[i];
-    for (int i = tid; i < 16 * M; i += nthr) reinterpret_cast<float2*>(smem + lay.tw)[i] = a.tw16[i];
+    for (int i = tid; i < C::L * C::MP; i += nthr) reinterpret_cast<float2*>(smem + lay.ptw)[i] = a.ptw2[i];
+    for (int i = tid; i < C::L * M; i += nthr) reinterpret_cast<float2*>(smem + lay.tw)[i] = a.tw16[i];
   }
 
   const int lane = tid & 63, wave = tid >> 6;
-  const int j = lane & 15, g = wave * C::FPW + (lane >> 4);      // lane in its row; frame of the group
-  const int k2 = ((j & 1) << 3) | ((j & 2) << 1) | ((j & 4) >> 1) | ((j & 8) >> 3);   // bitrev4(j): pass B leaves it here
+  const int j = lane & (C::L - 1), g = wave * C::FPW + lane / C::L;      // lane in its frame; frame of the group
+  auto bitrev = [](int v) {   // over log2(L) bits
+    return C::L == 16 ? (((v & 1) << 3) | ((v & 2) << 1) | ((v & 4) >> 1) | ((v & 8) >> 3)) : (((v & 1) << 2) | (v & 2) | ((v & 4) >> 2));
+  };
+  const int k2 = bitrev(j);   // pass B leaves Z[k1 + M * bitrev(j)] in lane j
   // row offsets of P: row r starts at bank 8 r (see p_offset of the transpose form: conflict-free b128 reads)
   auto prow_of = [](int r) { const int base = r * C::PROW; return base + (((8 * r - base) % 64) + 64) % 64; };
   float* P = Pall + prow_of(g);
-  const float* prow = Pall + prow_of(lane & 15) + 4 * (lane >> 4);
+  const float* prow[C::MT];
+#pragma unroll
+  for (int mt = 0; mt < C::MT; ++mt) prow[mt] = Pall + prow_of(16 * mt + (lane & 15)) + 4 * (lane >> 4);
   // Stage constants of the cross-lane transform.  A radix-2 decimation-in-frequency butterfly is t = x + y in the lower lane
   // of a pair and t = y - x in the upper one (x own, y partner), then t * w (w = 1 below, W_{2h}^(j mod h) above).  Values are
   // kept PRE-SIGNED for the stage about to run -- the upper lane holds -x -- so that both lanes evaluate the same
   // expression t = own + sigma * partner (sigma = -1 below, +1 above): one v_fmac_f32 with the partner as its DPP operand,
   // in place.  The pre-sign of the next stage is folded into this stage's twiddle, the first stage's into the column
   // twiddle table (host side).
-  float sg[4];
-  float2 st[3];
+  float sg[C::LG];
+  float2 st[C::LG - 1];
   {
-    const int hs[4] = {8, 4, 2, 1};
+    const int hs[5] = {C::L / 2, C::L / 4, C::L / 8, C::L / 16, 0};   // partner distance per stage
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < C::LG; ++s) {
       const bool up = (j & hs[s]) != 0;
       sg[s] = up ? 1.f : -1.f;
-      if (s < 3) {
+      if (s < C::LG - 1) {
         float sn, cs;
         const float ang = -3.14159265358979323846f * float(j & (hs[s] - 1)) / float(hs[s]);   // W_{2h}^(j mod h)
         sincosf(ang, &sn, &cs);
@@ -587,9 +599,9 @@ __global__ __launch_bounds__(kWaves * 64, (ShflCfg<M, HOP>::WPS)) void sept_mel_
       }
     }
   }
-  // k1 = 0: bin M k2 pairs with M ((16 - k2) mod 16): the lane of this row that holds it
-  const int k2n = (16 - k2) & 15;
-  const int src0 = (lane & 48) | (((k2n & 1) << 3) | ((k2n & 2) << 1) | ((k2n & 4) >> 1) | ((k2n & 8) >> 3));
+  // k1 = 0: bin M k2 pairs with M ((L - k2) mod L): the lane of this frame that holds it
+  const int k2n = (C::L - k2) & (C::L - 1);
+  const int src0 = (lane & ~(C::L - 1)) | bitrev(k2n);
   // this wave's share of the filterbank (whole filter tiles)
   const int* stp = a.steps + __builtin_amdgcn_readfirstlane(wave) * (kMaxSteps + 2);
   const int hdr = stp[lane];
@@ -635,7 +647,7 @@ __global__ __launch_bounds__(kWaves * 64, (ShflCfg<M, HOP>::WPS)) void sept_mel_
       const float2* fr = reinterpret_cast<const float2*>(sp + g * HOP);
 #pragma unroll
       for (int m = 0; m < M; ++m) {
-        const float2 v = fr[j + 16 * m], w = win[j + 16 * m];
+        const float2 v = fr[j + C::L * m], w = win[j + C::L * m];
         re[m] = v.x * w.x;
         im[m] = v.y * w.y;
       }
@@ -643,7 +655,7 @@ __global__ __launch_bounds__(kWaves * 64, (ShflCfg<M, HOP>::WPS)) void sept_mel_
     if constexpr (!(SEPT_SHFL_ABLATE & 2)) FftReg<M>::run(re, im);
 #pragma unroll
     for (int k1 = 0; k1 < M; ++k1) {
-      const float2 w = tws[k1 * 16 + j];
+      const float2 w = tws[k1 * C::L + j];
       const float r = re[k1] * w.x - im[k1] * w.y;
       im[k1] = re[k1] * w.y + im[k1] * w.x;
       re[k1] = r;
@@ -653,19 +665,25 @@ __global__ __launch_bounds__(kWaves * 64, (ShflCfg<M, HOP>::WPS)) void sept_mel_
   _Pragma("unroll") for (int k1 = 0; k1 < M; ++k1) {                           \
     const float tr = __builtin_fmaf(lane_xor<H>(re[k1]), sg[S], re[k1]);       \
     const float ti = __builtin_fmaf(lane_xor<H>(im[k1]), sg[S], im[k1]);       \
-    if constexpr (S < 3) {                                                     \
-      re[k1] = tr * st[S < 3 ? S : 0].x - ti * st[S < 3 ? S : 0].y;            \
-      im[k1] = tr * st[S < 3 ? S : 0].y + ti * st[S < 3 ? S : 0].x;            \
+    if constexpr (S < C::LG - 1) {                                             \
+      re[k1] = tr * st[S < C::LG - 1 ? S : 0].x - ti * st[S < C::LG - 1 ? S : 0].y;   \
+      im[k1] = tr * st[S < C::LG - 1 ? S : 0].y + ti * st[S < C::LG - 1 ? S : 0].x;   \
     } else {                                                                   \
       re[k1] = tr;                                                             \
       im[k1] = ti;                                                             \
     }                                                                          \
   }
     if constexpr (!(SEPT_SHFL_ABLATE & 4)) {
+      if constexpr (C::L == 16) {
     SEPT_SHFL_STAGE(8, 0)
     SEPT_SHFL_STAGE(4, 1)
     SEPT_SHFL_STAGE(2, 2)
     SEPT_SHFL_STAGE(1, 3)
+      } else {
+    SEPT_SHFL_STAGE(4, 0)
+    SEPT_SHFL_STAGE(2, 1)
+    SEPT_SHFL_STAGE(1, 2)
+      }
     }
 #undef SEPT_SHFL_STAGE
     MEL_T(4)
@@ -681,8 +699,8 @@ __global__ __launch_bounds__(kWaves * 64, (ShflCfg<M, HOP>::WPS)) void sept_mel_
       const float zb0x = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src0 * 4, __builtin_bit_cast(int, re[0])));
       const float zb0y = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src0 * 4, __builtin_bit_cast(int, im[0])));
       // one evaluation yields BOTH bins of a pair (p, N - p) -- |E + T|^2 and |E - T|^2 -- and the pair (k1, lane l) /
-      // (M - k1, lane 15 - l) is visited from both sides, so each lane takes the half k1 <= (M - 1) / 2 of its pairs and
-      // writes the partner's bin too (row position (M - k1) + M (15 - k2)); k1 = 0 and, for even M, k1 = M / 2 pair
+      // (M - k1, lane L - 1 - l) is visited from both sides, so each lane takes the half k1 <= (M - 1) / 2 of its pairs and
+      // writes the partner's bin too (row position (M - k1) + M (L - 1 - k2)); k1 = 0 and, for even M, k1 = M / 2 pair
       // inside their own register and are evaluated one-sided
       auto one = [&](int k1, float zbx, float zby, bool both, int other) {
         const float zax = re[k1], zay = im[k1];
@@ -707,12 +725,13 @@ __global__ __launch_bounds__(kWaves * 64, (ShflCfg<M, HOP>::WPS)) void sept_mel_
         P[C::N] = split(0.25f * (br * br + bi * bi));
       }
       if constexpr (!(SEPT_SHFL_ABLATE & 8)) {
+        constexpr int kMirror = C::L == 16 ? 0x140 : 0x141;   // row_mirror / row_half_mirror: lane L - 1 - j of the frame
 #pragma unroll
         for (int k1 = 1; k1 <= (M - 1) / 2; ++k1)
-          one(k1, dpp<0x140>(0.f, re[M - k1]), dpp<0x140>(0.f, im[M - k1]), true, (M - k1) + M * (15 - k2));   // row_mirror
-        if constexpr (M % 2 == 0) one(M / 2, dpp<0x140>(0.f, re[M / 2]), dpp<0x140>(0.f, im[M / 2]), false, 0);
+          one(k1, dpp<kMirror>(0.f, re[M - k1]), dpp<kMirror>(0.f, im[M - k1]), true, (M - k1) + M * ((C::L - 1) - k2));
+        if constexpr (M % 2 == 0) one(M / 2, dpp<kMirror>(0.f, re[M / 2]), dpp<kMirror>(0.f, im[M / 2]), false, 0);
       }
-      if (j < C::NPP - (C::N + 1)) P[C::N + 1 + j] = 0.f;   // the zero tail up to a whole 16-bin step
+      for (int q = j; q < C::NPP - (C::N + 1); q += C::L) P[C::N + 1 + q] = 0.f;   // the zero tail up to a whole 16-bin step
     }
     // B operands of the wave's filterbank steps: requested HERE, where the transform's registers have just died, so that
     // all of them are in flight across the barrier (the table is 2 KB per step from L2: fetched two steps at a time inside
@@ -733,7 +752,9 @@ __global__ __launch_bounds__(kWaves * 64, (ShflCfg<M, HOP>::WPS)) void sept_mel_
 
     // ---- filterbank on the bf16 matrix pipe (whole filter tiles per wave), dB, store ----
     if constexpr (!(SEPT_SHFL_ABLATE & 16)) {
-      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 acc[C::MT];
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
       const int nfr = min(C::TILE, T - t0);
       // every operand load is waited for HERE, the surplus ones of a wave with fewer than eight steps included: a load left
       // outstanding makes hipcc guard its destination registers with vmcnt(0) at their next use -- the sample reads of the
@@ -750,24 +771,30 @@ __global__ __launch_bounds__(kWaves * 64, (ShflCfg<M, HOP>::WPS)) void sept_mel_
           __builtin_amdgcn_s_waitcnt(0x0f70);
         }
         int h[kAll];
-        uint4 av[kAll];
+        uint4 av[C::MT][kAll];
 #pragma unroll
         for (int u = 0; u < kAll; ++u) {
           h[u] = __builtin_amdgcn_readlane(hdr, min(i0 + u, wlast));
-          av[u] = *reinterpret_cast<const uint4*>(prow + kStepBins * (h[u] & 0x3ff));
+#pragma unroll
+          for (int mt = 0; mt < C::MT; ++mt) av[mt][u] = *reinterpret_cast<const uint4*>(prow[mt] + kStepBins * (h[u] & 0x3ff));
         }
 #pragma unroll
         for (int u = 0; u < kAll; ++u) {
           if (i0 + u < wn) {
-            const bf16x8 av8 = __builtin_bit_cast(bf16x8, av[u]);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av8, __builtin_bit_cast(bf16x8, bq[u][1]), acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av8, __builtin_bit_cast(bf16x8, bq[u][0]), acc, 0, 0, 0);
-            if (h[u] & 0x400) {   // the filter tile is complete: D[row 4 (l >> 4) + i][col l & 15]
-              const int n = (h[u] >> 12) * 16 + (lane & 15), r0 = 4 * (lane >> 4);
+#pragma unroll
+            for (int mt = 0; mt < C::MT; ++mt) {
+              const bf16x8 av8 = __builtin_bit_cast(bf16x8, av[mt][u]);
+              acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av8, __builtin_bit_cast(bf16x8, bq[u][1]), acc[mt], 0, 0, 0);
+              acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av8, __builtin_bit_cast(bf16x8, bq[u][0]), acc[mt], 0, 0, 0);
+            }
+            if (h[u] & 0x400) {   // the filter tile is complete: D[row 16 mt + 4 (l >> 4) + i][col l & 15]
+#pragma unroll
+             for (int mt = 0; mt < C::MT; ++mt) {
+              const int n = (h[u] >> 12) * 16 + (lane & 15), r0 = 16 * mt + 4 * (lane >> 4);
               if (n < F && !(SEPT_SHFL_ABLATE & 32)) {
                 f32x4 db;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) db[i] = power_to_db(acc[i]);
+                for (int i = 0; i < 4; ++i) db[i] = power_to_db(acc[mt][i]);
                 if (a.layout == SEPT_MEL_LAYOUT_BFT) {
                   // the lane's four frames are consecutive floats of filter n's row: one 16-byte store (4-byte aligned: T is
                   // odd), four lanes = 64 contiguous bytes
@@ -781,7 +808,8 @@ __global__ __launch_bounds__(kWaves * 64, (ShflCfg<M, HOP>::WPS)) void sept_mel_
                   for (int i = 0; i < 4; ++i) if (r0 + i < nfr) a.out[(size_t(b) * T + t0 + r0 + i) * F + n] = db[i];
                 }
               }
-              acc = f32x4{0.f, 0.f, 0.f, 0.f};
+              acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+             }
             }
           }
         }
@@ -857,18 +885,20 @@ const Variant kVariants[] = {
 
 // the shuffle form (sept_mel_shfl_kernel): n_fft = 32 M at hop 160
 struct ShflVariant {
-  int n_fft, hop, M, MP;
+  int n_fft, hop, M, MP, L;
   const void* fn;
   const char* name;
   int tile;
   size_t smem;
 };
-#define SEPT_MEL_SHFL(nfft, hop, m)                                                                                     \
+#define SEPT_MEL_SHFL(nfft, hop, m, l)                                                                                  \
   {                                                                                                                     \
-    nfft, hop, m, ShflCfg<m, hop>::MP, reinterpret_cast<const void*>(&sept_mel_shfl_kernel<m, hop>),                  \
-        "sept_mel_shfl_kernel<" #m ", " #hop ">", ShflCfg<m, hop>::TILE, ShflSmem<m, hop>().total                       \
+    nfft, hop, m, ShflCfg<m, hop, l>::MP, l, reinterpret_cast<const void*>(&sept_mel_shfl_kernel<m, hop, l>),         \
+        "sept_mel_shfl_kernel<" #m ", " #hop ", " #l ">", ShflCfg<m, hop, l>::TILE, ShflSmem<m, hop, l>().total        \
   }
-const ShflVariant kShflVariants[] = {SEPT_MEL_SHFL(800, 160, 25), SEPT_MEL_SHFL(1024, 160, 32), SEPT_MEL_SHFL(1600, 160, 50)};
+// n_fft = 2 L M: 800 / 1024 / 1600 at hop 160 with sixteen lanes per frame; 400 at hop 200 (the MFCC front end) with eight
+const ShflVariant kShflVariants[] = {SEPT_MEL_SHFL(800, 160, 25, 16), SEPT_MEL_SHFL(1024, 160, 32, 16),
+                                     SEPT_MEL_SHFL(1600, 160, 50, 16), SEPT_MEL_SHFL(400, 200, 25, 8)};
 
 }  // namespace
 
@@ -1062,16 +1092,16 @@ extern "C" int sept_mel_plan_create(int n_fft, int hop, int n_mels, const float*
   // shuffle form: W_N^(j k1) per (k1, lane j) and the split twiddle at p = k1 + M k2 laid out [k2][k1]
   std::vector<float2> tw16, ptw2;
   if (p.shfl) {
-    const int M = sv->M, MP = sv->MP;
-    tw16.resize(size_t(M) * 16);
-    ptw2.assign(size_t(16) * MP, make_float2(0.f, 0.f));
+    const int M = sv->M, MP = sv->MP, LL = sv->L;
+    tw16.resize(size_t(M) * LL);
+    ptw2.assign(size_t(LL) * MP, make_float2(0.f, 0.f));
     for (int k1 = 0; k1 < M; ++k1)
-      for (int jj = 0; jj < 16; ++jj) {
+      for (int jj = 0; jj < LL; ++jj) {
         const double ang = -2.0 * M_PI * double((long long)jj * k1 % N) / N;
-        const double pre = (jj & 8) ? -1.0 : 1.0;   // the upper lanes of the first cross-lane stage hold -x (see the kernel)
-        tw16[size_t(k1) * 16 + jj] = make_float2(float(pre * std::cos(ang)), float(pre * std::sin(ang)));
+        const double pre = (jj & (LL / 2)) ? -1.0 : 1.0;   // the upper lanes of the first cross-lane stage hold -x (see the kernel)
+        tw16[size_t(k1) * LL + jj] = make_float2(float(pre * std::cos(ang)), float(pre * std::sin(ang)));
       }
-    for (int kk2 = 0; kk2 < 16; ++kk2)
+    for (int kk2 = 0; kk2 < LL; ++kk2)
       for (int k1 = 0; k1 < M; ++k1) {
         const double ang = -M_PI * double(k1 + M * kk2) / N;
         ptw2[size_t(kk2) * MP + k1] = make_float2(float(std::cos(ang)), float(std::sin(ang)));

@@ -19,10 +19,11 @@ def main():
     ap.add_argument("--mels", type=int, default=80)
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--layout", type=int, default=0)
+    ap.add_argument("--hop", type=int, default=160)
     a = ap.parse_args()
     g = torch.Generator().manual_seed(8)
     x = (torch.randn(a.batch, 80000, generator=g) * 0.1).clamp(-1, 1).cuda()
-    plan = get_mel_plan(a.n_fft, a.mels)
+    plan = get_mel_plan(a.n_fft, a.mels, a.hop)
     out = plan.forward(x, a.layout)
     for _ in range(5):
         plan.forward(x, a.layout, out=out)
@@ -34,8 +35,8 @@ def main():
     e.record()
     torch.cuda.synchronize()
     us = s.elapsed_time(e) * 1e3 / a.iters
-    byts = a.batch * (4 * 80000 + 4 * a.mels * 501)
-    print(f"{plan.kernel_name}: B={a.batch} n_fft={a.n_fft} F={a.mels}: {us:.1f} us/launch, "
+    byts = a.batch * (4 * 80000 + 4 * a.mels * (1 + 80000 // a.hop))
+    print(f"{plan.kernel_name}: B={a.batch} n_fft={a.n_fft} hop={a.hop} F={a.mels}: {us:.1f} us/launch, "
           f"{byts / us / 1e3:.1f} GB/s algorithmic ({byts / us / 1e3 / 8000:.3f} of 8 TB/s), "
           f"{a.batch / us * 1e6:.3e} clips/s")
 

@@ -30,6 +30,7 @@ python3 tools/step_traffic.py $O/${R}_pmc_traffic.json $O/${R}_replay_kernel_sta
 head -3 $O/${R}_step_traffic.txt
 # kernel-only timings of every (n_fft, n_mels) the reference extracts (mel1 = 800, mel2 = 1600, default 1024, MFCC 400)
 for nf in 800 1600 1024 400; do for m in 80 128; do python3 tools/bench_mel.py --n_fft $nf --mels $m --iters 30 >> $O/${R}_mel_timings.txt; done; done
+python3 tools/bench_mel.py --n_fft 400 --hop 200 --mels 128 --iters 30 >> $O/${R}_mel_timings.txt   # the MFCC front end
 SEPT_STAMPS=1 python3 tools/step_stamps.py > $O/${R}_step_stamps.txt 2>/dev/null
 # the in-kernel launch clock behind the bench line's roofline figure: against HIP events alone / on two streams, and the
 # instrumented capture against the plain one
